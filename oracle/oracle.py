@@ -1,0 +1,144 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY: import this from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg, never from the product.  PARITY UNPINNED — see
+oracle/av1o_common.h.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+TX_W = [4, 8, 16, 32, 64, 4, 8, 8, 16, 16, 32, 32, 64, 4, 16, 8, 32, 16, 64]
+TX_H = [4, 8, 16, 32, 64, 8, 4, 16, 8, 32, 16, 64, 32, 16, 4, 32, 8, 64, 16]
+TX_NAMES = ["4x4", "8x8", "16x16", "32x32", "64x64", "4x8", "8x4", "8x16", "16x8", "16x32", "32x16",
+            "32x64", "64x32", "4x16", "16x4", "8x32", "32x8", "16x64", "64x16"]
+TX_TYPE_NAMES = ["DCT_DCT", "ADST_DCT", "DCT_ADST", "ADST_ADST", "FLIPADST_DCT", "DCT_FLIPADST",
+                 "FLIPADST_FLIPADST", "ADST_FLIPADST", "FLIPADST_ADST", "IDTX", "V_DCT", "H_DCT",
+                 "V_ADST", "H_ADST", "V_FLIPADST", "H_FLIPADST"]
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build()
+        _LIB = C.CDLL(path)
+    return _LIB
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def coef_shape(tx_size):
+    return min(TX_H[tx_size], 32), min(TX_W[tx_size], 32)
+
+
+def txfm_valid(tx_size, tx_type):
+    return bool(lib().av1o_txfm_valid(tx_size, tx_type))
+
+
+def idct(x, n, bit=12, rng=0):
+    x = np.ascontiguousarray(x, np.int32)
+    out = np.zeros(n, np.int32)
+    lib().av1o_idct(_p(x, C.c_int32), _p(out, C.c_int32), n, bit, rng)
+    return out
+
+
+def fdct(x, n, bit=12):
+    x = np.ascontiguousarray(x, np.int32)
+    out = np.zeros(n, np.int32)
+    lib().av1o_fdct(_p(x, C.c_int32), _p(out, C.c_int32), n, bit)
+    return out
+
+
+def idct_explicit(x, n, rng=0):
+    x = np.ascontiguousarray(x, np.int32)
+    out = np.zeros(n, np.int32)
+    getattr(lib(), "av1o_idct%d_explicit" % n)(_p(x, C.c_int32), _p(out, C.c_int32), rng)
+    return out
+
+
+def iadst(x, n, bit=12, rng=0):
+    x = np.ascontiguousarray(x, np.int32)
+    out = np.zeros(n, np.int32)
+    if n == 4:
+        lib().av1o_iadst4(_p(x, C.c_int32), _p(out, C.c_int32), bit)
+    else:
+        getattr(lib(), "av1o_iadst%d" % n)(_p(x, C.c_int32), _p(out, C.c_int32), bit, rng)
+    return out
+
+
+def fadst(x, n, bit=12):
+    x = np.ascontiguousarray(x, np.int32)
+    out = np.zeros(n, np.int32)
+    getattr(lib(), "av1o_fadst%d" % n)(_p(x, C.c_int32), _p(out, C.c_int32), bit)
+    return out
+
+
+def identity(x, n):
+    x = np.ascontiguousarray(x, np.int32)
+    out = np.zeros(n, np.int32)
+    lib().av1o_identity(_p(x, C.c_int32), _p(out, C.c_int32), n)
+    return out
+
+
+def inv_txfm2d_add(coef, pred, tx_size, tx_type, bd, libaom_clamps=1):
+    """coef: int32 [min(h,32), min(w,32)]; pred: [h, w] uint8/uint16.  returns the reconstruction."""
+    coef = np.ascontiguousarray(coef, np.int32)
+    dt = np.uint8 if bd == 8 else np.uint16
+    dst = np.ascontiguousarray(pred, dt).copy()
+    assert coef.shape == coef_shape(tx_size) and dst.shape == (TX_H[tx_size], TX_W[tx_size])
+    rc = lib().av1o_inv_txfm2d_add(_p(coef, C.c_int32), dst.ctypes.data_as(C.c_void_p), dst.shape[1], tx_size,
+                                   tx_type, bd, libaom_clamps)
+    if rc:
+        raise ValueError("av1o_inv_txfm2d_add rc=%d" % rc)
+    return dst
+
+
+def fwd_txfm2d(resid, tx_size, tx_type, bd=8):
+    resid = np.ascontiguousarray(resid, np.int16)
+    assert resid.shape == (TX_H[tx_size], TX_W[tx_size])
+    coef = np.zeros(coef_shape(tx_size), np.int32)
+    rc = lib().av1o_fwd_txfm2d(_p(resid, C.c_int16), resid.shape[1], _p(coef, C.c_int32), tx_size, tx_type, bd)
+    if rc:
+        raise ValueError("av1o_fwd_txfm2d rc=%d" % rc)
+    return coef
+
+
+def dc_q(qindex, bd=8, delta=0):
+    return lib().av1o_dc_q(qindex, delta, bd)
+
+
+def ac_q(qindex, bd=8, delta=0):
+    return lib().av1o_ac_q(qindex, delta, bd)
+
+
+def tx_scale(tx_size):
+    return lib().av1o_tx_scale(tx_size)
+
+
+def quantize(coef, dcq, acq, log_scale):
+    coef = np.ascontiguousarray(coef, np.int32)
+    lv = np.zeros(coef.shape, np.int16)
+    dq = np.zeros(coef.shape, np.int32)
+    nz = lib().av1o_quantize(_p(coef, C.c_int32), coef.size, dcq, acq, log_scale, _p(lv, C.c_int16),
+                             _p(dq, C.c_int32))
+    return lv, dq, nz
+
+
+def dequantize(levels, dcq, acq, log_scale, bd):
+    levels = np.ascontiguousarray(levels, np.int16)
+    dq = np.zeros(levels.shape, np.int32)
+    lib().av1o_dequantize(_p(levels, C.c_int16), levels.size, dcq, acq, log_scale, bd, _p(dq, C.c_int32))
+    return dq
