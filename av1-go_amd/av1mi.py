@@ -1,0 +1,178 @@
+"""ctypes binding of libav1mi.so — the same C ABI (include/av1mi.h) a cgo wrapper binds.
+
+Used by tests/, bench.py and __graft_entry__.py.  It is plumbing, not a second implementation:
+there is no CPU fallback here.  If the HIP library is missing or no GPU is present, loading /
+opening fails loudly (reference behaviour for an unusable encoder: RunTranscode returns
+(-1, err), internal/ffmpeg/transcode.go:311).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libav1mi.so")
+
+TX_W = [4, 8, 16, 32, 64, 4, 8, 8, 16, 16, 32, 32, 64, 4, 16, 8, 32, 16, 64]
+TX_H = [4, 8, 16, 32, 64, 8, 4, 16, 8, 32, 16, 64, 32, 16, 4, 32, 8, 64, 16]
+
+
+class Av1miError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__("av1mi error %d: %s" % (code, text))
+        self.code = code
+
+
+class TxBlock(C.Structure):
+    _fields_ = [("coef_off", C.c_uint32), ("x", C.c_uint16), ("y", C.c_uint16), ("tx_type", C.c_uint32),
+                ("reserved", C.c_uint32)]
+
+
+TXB_DTYPE = np.dtype([("coef_off", "<u4"), ("x", "<u2"), ("y", "<u2"), ("tx_type", "<u4"), ("reserved", "<u4")])
+
+_lib = None
+
+
+def load():
+    """dlopen libav1mi.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError("%s not built: run `python -c 'import __graft_entry__ as g; g.build()'`" % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        lib.av1mi_version.restype = C.c_char_p
+        lib.av1mi_last_error.restype = C.c_char_p
+        lib.av1mi_device_name.restype = C.c_char_p
+        lib.av1mi_last_error.argtypes = [C.c_void_p]
+        lib.av1mi_device_name.argtypes = [C.c_void_p]
+        lib.av1mi_close.argtypes = [C.c_void_p]
+        lib.av1mi_close.restype = None
+        _lib = lib
+    return _lib
+
+
+def exported_symbols():
+    """names declared in include/av1mi.h (parsed from the header)."""
+    import re
+    hdr = open(os.path.join(_HERE, "..", "include", "av1mi.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(av1mi_[a-z0-9_]+)\s*\(", hdr)))
+
+
+class DevBuf:
+    """device allocation owned by a Context."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx, self.nbytes = ctx, int(nbytes)
+        p = C.c_void_p()
+        ctx._chk(ctx.lib.av1mi_malloc(ctx.h, C.byref(p), C.c_size_t(self.nbytes)))
+        self.ptr = p.value
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        self.ctx._chk(self.ctx.lib.av1mi_upload(self.ctx.h, C.c_void_p(self.ptr), arr.ctypes.data_as(C.c_void_p),
+                                                C.c_size_t(arr.nbytes)))
+        return self
+
+    def download(self, shape, dtype):
+        out = np.empty(shape, dtype)
+        assert out.nbytes <= self.nbytes
+        self.ctx._chk(self.ctx.lib.av1mi_download(self.ctx.h, out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr),
+                                                  C.c_size_t(out.nbytes)))
+        return out
+
+    def free(self):
+        if self.ptr:
+            self.ctx.lib.av1mi_free(self.ctx.h, C.c_void_p(self.ptr))
+            self.ptr = None
+
+
+class Context:
+    def __init__(self, device=0):
+        self.lib = load()
+        h = C.c_void_p()
+        rc = self.lib.av1mi_open(int(device), C.byref(h))
+        if rc != 0:
+            raise Av1miError(rc, "av1mi_open(device=%d) failed: no usable HIP device" % device)
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.lib.av1mi_close(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise Av1miError(rc, self.lib.av1mi_last_error(self.h).decode())
+
+    @property
+    def device_name(self):
+        return self.lib.av1mi_device_name(self.h).decode()
+
+    def alloc(self, nbytes):
+        return DevBuf(self, nbytes)
+
+    def to_device(self, arr):
+        arr = np.ascontiguousarray(arr)
+        return DevBuf(self, max(arr.nbytes, 16)).upload(arr)
+
+    def sync(self):
+        self._chk(self.lib.av1mi_sync(self.h))
+
+    def timer_begin(self):
+        self._chk(self.lib.av1mi_timer_begin(self.h))
+
+    def timer_end(self):
+        ms = C.c_float()
+        self._chk(self.lib.av1mi_timer_end(self.h, C.byref(ms)))
+        return ms.value
+
+    # ---- K2 / K1 / K8, device-resident
+    def inv_txfm_add_grid(self, tx_size, d_coef, d_plane, stride, bd, blocks_per_row, nblocks, d_types=None, uniform_type=0):
+        self._chk(self.lib.av1mi_inv_txfm_add_grid(self.h, tx_size, C.c_void_p(d_coef.ptr), C.c_void_p(d_plane.ptr), stride, bd,
+                                                   blocks_per_row, nblocks, C.c_void_p(d_types.ptr if d_types else None),
+                                                   uniform_type))
+
+    def inv_txfm_add_list(self, tx_size, d_coef, d_plane, stride, bd, d_list, nblocks):
+        self._chk(self.lib.av1mi_inv_txfm_add_list(self.h, tx_size, C.c_void_p(d_coef.ptr), C.c_void_p(d_plane.ptr), stride, bd,
+                                                   C.c_void_p(d_list.ptr), nblocks))
+
+    def fwd_txfm_grid(self, tx_size, d_resid, stride, d_coef, blocks_per_row, nblocks, d_types=None, uniform_type=0):
+        self._chk(self.lib.av1mi_fwd_txfm_grid(self.h, tx_size, C.c_void_p(d_resid.ptr), stride, C.c_void_p(d_coef.ptr),
+                                               blocks_per_row, nblocks, C.c_void_p(d_types.ptr if d_types else None),
+                                               uniform_type))
+
+    def fwd_txfm_list(self, tx_size, d_resid, stride, d_coef, d_list, nblocks):
+        self._chk(self.lib.av1mi_fwd_txfm_list(self.h, tx_size, C.c_void_p(d_resid.ptr), stride, C.c_void_p(d_coef.ptr),
+                                               C.c_void_p(d_list.ptr), nblocks))
+
+    def quantize(self, d_coef, d_levels, d_dq, n, coef_per_blk, dc_q, ac_q, log_scale):
+        self._chk(self.lib.av1mi_quantize(self.h, C.c_void_p(d_coef.ptr), C.c_void_p(d_levels.ptr),
+                                          C.c_void_p(d_dq.ptr if d_dq else None), C.c_size_t(n), coef_per_blk, dc_q, ac_q,
+                                          log_scale))
+
+    def dequantize(self, d_levels, d_dq, n, coef_per_blk, dc_q, ac_q, log_scale, bd):
+        self._chk(self.lib.av1mi_dequantize(self.h, C.c_void_p(d_levels.ptr), C.c_void_p(d_dq.ptr), C.c_size_t(n), coef_per_blk,
+                                            dc_q, ac_q, log_scale, bd))
+
+    # ---- host-pointer single-block forms
+    def inv_txfm2d_add(self, coef, pred, tx_size, tx_type, bd):
+        coef = np.ascontiguousarray(coef, np.int32)
+        dst = np.ascontiguousarray(pred, np.uint8 if bd == 8 else np.uint16).copy()
+        self._chk(self.lib.av1mi_inv_txfm2d_add(self.h, coef.ctypes.data_as(C.c_void_p), dst.ctypes.data_as(C.c_void_p),
+                                                dst.shape[1], tx_size, tx_type, bd))
+        return dst
+
+    def fwd_txfm2d(self, resid, tx_size, tx_type):
+        resid = np.ascontiguousarray(resid, np.int16)
+        coef = np.zeros((min(TX_H[tx_size], 32), min(TX_W[tx_size], 32)), np.int32)
+        self._chk(self.lib.av1mi_fwd_txfm2d(self.h, resid.ctypes.data_as(C.c_void_p), resid.shape[1],
+                                            coef.ctypes.data_as(C.c_void_p), tx_size, tx_type))
+        return coef

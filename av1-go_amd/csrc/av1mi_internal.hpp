@@ -1,0 +1,30 @@
+// av1mi_internal.hpp — declarations shared by the kernel translation units and the C ABI (capi.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/av1mi.h"
+
+namespace av1mi {
+
+// One transform launch: either a block list or an implicit grid of equal blocks.
+struct TxLaunch {
+  int32_t *coef;            // int32 coefficients (K2: in, K1: out)
+  void *plane;              // K2: uint8/uint16 prediction->reconstruction; K1: int16 residual
+  int stride;               // samples
+  int nblocks;
+  const av1mi_txb *list;    // non-null: list form
+  const uint8_t *tx_types;  // grid form: per-block type or null
+  int uniform_type;
+  int blocks_per_row;
+};
+
+int tx_width(int tx_size);
+int tx_height(int tx_size);
+hipError_t launch_inv_txfm(int tx_size, const TxLaunch &L, int bd, hipStream_t s);
+hipError_t launch_fwd_txfm(int tx_size, const TxLaunch &L, hipStream_t s);
+hipError_t launch_quantize(const int32_t *coef, int16_t *levels, int32_t *dqcoef, long long n, int coef_per_blk,
+                           int dc_q, int ac_q, int log_scale, hipStream_t s);
+hipError_t launch_dequantize(const int16_t *levels, int32_t *dqcoef, long long n, int coef_per_blk, int dc_q,
+                             int ac_q, int log_scale, int bd, hipStream_t s);
+
+}  // namespace av1mi

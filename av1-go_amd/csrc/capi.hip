@@ -1,0 +1,297 @@
+// capi.hip — the C ABI of libav1mi.so (include/av1mi.h).  Thin: argument checks, device selection,
+// error text, and launches onto the context's stream.  No CPU fallback exists: without a usable HIP
+// device av1mi_open() fails with AV1MI_E_NODEV and every other entry point needs a context.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include "av1mi_internal.hpp"
+#include "qtables.hpp"
+
+struct av1mi_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  char err[801] = { 0 };  // transcode.go:295-297 caps the reason text at 800 chars
+  char name[256] = { 0 };
+  void *scratch = nullptr;  // staging for the host-pointer single-block forms
+  size_t scratch_bytes = 0;
+};
+
+namespace {
+
+int fail(av1mi_ctx *ctx, int code, const char *fmt, ...) {
+  if (ctx) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(ctx->err, sizeof(ctx->err), fmt, ap);
+    va_end(ap);
+  }
+  return code;
+}
+#define HIP_TRY(ctx, expr)                                                                     \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess) return fail(ctx, AV1MI_E_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+#define BIND(ctx)                                                   \
+  do {                                                              \
+    if (!(ctx)) return AV1MI_E_INVAL;                               \
+    HIP_TRY(ctx, hipSetDevice((ctx)->device));                      \
+  } while (0)
+
+bool tx_valid(int tx_size, int tx_type) {
+  if (tx_size < 0 || tx_size >= AV1MI_TX_SIZES_ALL || tx_type < 0 || tx_type >= AV1MI_TX_TYPES) return false;
+  const int w = av1mi::tx_width(tx_size), h = av1mi::tx_height(tx_size);
+  static const int colk[16] = { 0, 1, 0, 1, 2, 0, 2, 1, 2, 3, 0, 3, 1, 3, 2, 3 };
+  static const int rowk[16] = { 0, 0, 1, 1, 0, 2, 2, 2, 1, 3, 3, 0, 3, 1, 3, 2 };
+  const int r = rowk[tx_type], c = colk[tx_type];
+  if ((r == 1 || r == 2) && w > 16) return false;
+  if ((c == 1 || c == 2) && h > 16) return false;
+  if (r == 3 && w > 32) return false;
+  if (c == 3 && h > 32) return false;
+  return true;
+}
+int ensure_scratch(av1mi_ctx *ctx, size_t bytes) {
+  if (ctx->scratch_bytes >= bytes) return AV1MI_OK;
+  if (ctx->scratch) (void)hipFree(ctx->scratch);
+  ctx->scratch = nullptr; ctx->scratch_bytes = 0;
+  HIP_TRY(ctx, hipMalloc(&ctx->scratch, bytes));
+  ctx->scratch_bytes = bytes;
+  return AV1MI_OK;
+}
+int check_tx_launch(av1mi_ctx *ctx, int tx_size, const void *coef, const void *plane, int stride, int nblocks) {
+  if (tx_size < 0 || tx_size >= AV1MI_TX_SIZES_ALL) return fail(ctx, AV1MI_E_INVAL, "tx_size %d out of range", tx_size);
+  if (!coef || !plane) return fail(ctx, AV1MI_E_INVAL, "null device pointer");
+  if (nblocks < 0) return fail(ctx, AV1MI_E_INVAL, "nblocks %d < 0", nblocks);
+  if (stride <= 0 || (stride & 3)) return fail(ctx, AV1MI_E_INVAL, "stride %d must be a positive multiple of 4", stride);
+  if (((uintptr_t)coef & 15) || ((uintptr_t)plane & 7)) return fail(ctx, AV1MI_E_INVAL, "misaligned device pointer");
+  return AV1MI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *av1mi_version(void) { return "av1mi 0.1.0 (gfx950)"; }
+
+int av1mi_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int av1mi_open(int device, av1mi_ctx **out) {
+  if (!out) return AV1MI_E_INVAL;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return AV1MI_E_NODEV;
+  av1mi_ctx *ctx = new (std::nothrow) av1mi_ctx();
+  if (!ctx) return AV1MI_E_NOMEM;
+  ctx->device = device;
+  hipDeviceProp_t prop;
+  if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess ||
+      hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
+    delete ctx;
+    return AV1MI_E_NODEV;
+  }
+  snprintf(ctx->name, sizeof(ctx->name), "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+  *out = ctx;
+  return AV1MI_OK;
+}
+
+void av1mi_close(av1mi_ctx *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->scratch) (void)hipFree(ctx->scratch);
+  if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char *av1mi_last_error(av1mi_ctx *ctx) { return ctx ? ctx->err : "null context"; }
+const char *av1mi_device_name(av1mi_ctx *ctx) { return ctx ? ctx->name : ""; }
+
+int av1mi_malloc(av1mi_ctx *ctx, void **d_ptr, size_t bytes) {
+  BIND(ctx);
+  if (!d_ptr) return fail(ctx, AV1MI_E_INVAL, "null out pointer");
+  *d_ptr = nullptr;
+  hipError_t e = hipMalloc(d_ptr, bytes ? bytes : 16);
+  if (e == hipErrorOutOfMemory) return fail(ctx, AV1MI_E_NOMEM, "hipMalloc(%zu): out of memory", bytes);
+  HIP_TRY(ctx, e);
+  return AV1MI_OK;
+}
+int av1mi_free(av1mi_ctx *ctx, void *d_ptr) {
+  BIND(ctx);
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, hipFree(d_ptr));
+  return AV1MI_OK;
+}
+int av1mi_upload(av1mi_ctx *ctx, void *d_dst, const void *src, size_t bytes) {
+  BIND(ctx);
+  HIP_TRY(ctx, hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return AV1MI_OK;
+}
+int av1mi_download(av1mi_ctx *ctx, void *dst, const void *d_src, size_t bytes) {
+  BIND(ctx);
+  HIP_TRY(ctx, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return AV1MI_OK;
+}
+int av1mi_memset(av1mi_ctx *ctx, void *d_dst, int value, size_t bytes) {
+  BIND(ctx);
+  HIP_TRY(ctx, hipMemsetAsync(d_dst, value, bytes, ctx->stream));
+  return AV1MI_OK;
+}
+int av1mi_sync(av1mi_ctx *ctx) {
+  BIND(ctx);
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return AV1MI_OK;
+}
+int av1mi_timer_begin(av1mi_ctx *ctx) {
+  BIND(ctx);
+  HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  return AV1MI_OK;
+}
+int av1mi_timer_end(av1mi_ctx *ctx, float *elapsed_ms) {
+  BIND(ctx);
+  if (!elapsed_ms) return fail(ctx, AV1MI_E_INVAL, "null out pointer");
+  HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
+  HIP_TRY(ctx, hipEventElapsedTime(elapsed_ms, ctx->ev0, ctx->ev1));
+  return AV1MI_OK;
+}
+
+int av1mi_txfm_valid(int tx_size, int tx_type) { return tx_valid(tx_size, tx_type) ? 1 : 0; }
+int av1mi_tx_width(int tx_size) { return tx_size < 0 || tx_size >= AV1MI_TX_SIZES_ALL ? 0 : av1mi::tx_width(tx_size); }
+int av1mi_tx_height(int tx_size) { return tx_size < 0 || tx_size >= AV1MI_TX_SIZES_ALL ? 0 : av1mi::tx_height(tx_size); }
+
+int av1mi_inv_txfm_add_grid(av1mi_ctx *ctx, int tx_size, const int32_t *d_coef, void *d_plane, int stride, int bd,
+                            int blocks_per_row, int nblocks, const uint8_t *d_tx_types, int uniform_type) {
+  BIND(ctx);
+  if (int rc = check_tx_launch(ctx, tx_size, d_coef, d_plane, stride, nblocks)) return rc;
+  if (bd != 8 && bd != 10) return fail(ctx, AV1MI_E_INVAL, "bit depth %d not supported (8 or 10)", bd);
+  if (blocks_per_row <= 0) return fail(ctx, AV1MI_E_INVAL, "blocks_per_row %d <= 0", blocks_per_row);
+  if (!d_tx_types && !tx_valid(tx_size, uniform_type))
+    return fail(ctx, AV1MI_E_INVAL, "tx_type %d is not defined for tx_size %d", uniform_type, tx_size);
+  av1mi::TxLaunch L = { const_cast<int32_t *>(d_coef), d_plane, stride, nblocks, nullptr, d_tx_types, uniform_type, blocks_per_row };
+  HIP_TRY(ctx, av1mi::launch_inv_txfm(tx_size, L, bd, ctx->stream));
+  return AV1MI_OK;
+}
+int av1mi_inv_txfm_add_list(av1mi_ctx *ctx, int tx_size, const int32_t *d_coef, void *d_plane, int stride, int bd,
+                            const av1mi_txb *d_list, int nblocks) {
+  BIND(ctx);
+  if (int rc = check_tx_launch(ctx, tx_size, d_coef, d_plane, stride, nblocks)) return rc;
+  if (bd != 8 && bd != 10) return fail(ctx, AV1MI_E_INVAL, "bit depth %d not supported (8 or 10)", bd);
+  if (!d_list) return fail(ctx, AV1MI_E_INVAL, "null block list");
+  av1mi::TxLaunch L = { const_cast<int32_t *>(d_coef), d_plane, stride, nblocks, d_list, nullptr, 0, 1 };
+  HIP_TRY(ctx, av1mi::launch_inv_txfm(tx_size, L, bd, ctx->stream));
+  return AV1MI_OK;
+}
+int av1mi_fwd_txfm_grid(av1mi_ctx *ctx, int tx_size, const int16_t *d_resid, int stride, int32_t *d_coef,
+                        int blocks_per_row, int nblocks, const uint8_t *d_tx_types, int uniform_type) {
+  BIND(ctx);
+  if (int rc = check_tx_launch(ctx, tx_size, d_coef, d_resid, stride, nblocks)) return rc;
+  if (blocks_per_row <= 0) return fail(ctx, AV1MI_E_INVAL, "blocks_per_row %d <= 0", blocks_per_row);
+  if (!d_tx_types && !tx_valid(tx_size, uniform_type))
+    return fail(ctx, AV1MI_E_INVAL, "tx_type %d is not defined for tx_size %d", uniform_type, tx_size);
+  av1mi::TxLaunch L = { d_coef, const_cast<int16_t *>(d_resid), stride, nblocks, nullptr, d_tx_types, uniform_type, blocks_per_row };
+  HIP_TRY(ctx, av1mi::launch_fwd_txfm(tx_size, L, ctx->stream));
+  return AV1MI_OK;
+}
+int av1mi_fwd_txfm_list(av1mi_ctx *ctx, int tx_size, const int16_t *d_resid, int stride, int32_t *d_coef,
+                        const av1mi_txb *d_list, int nblocks) {
+  BIND(ctx);
+  if (int rc = check_tx_launch(ctx, tx_size, d_coef, d_resid, stride, nblocks)) return rc;
+  if (!d_list) return fail(ctx, AV1MI_E_INVAL, "null block list");
+  av1mi::TxLaunch L = { d_coef, const_cast<int16_t *>(d_resid), stride, nblocks, d_list, nullptr, 0, 1 };
+  HIP_TRY(ctx, av1mi::launch_fwd_txfm(tx_size, L, ctx->stream));
+  return AV1MI_OK;
+}
+
+int av1mi_dc_q(int qindex, int bd) {
+  const int q = qindex < 0 ? 0 : qindex > 255 ? 255 : qindex;
+  return bd == 8 ? av1mi::k_dc_q8[q] : av1mi::k_dc_q10[q];
+}
+int av1mi_ac_q(int qindex, int bd) {
+  const int q = qindex < 0 ? 0 : qindex > 255 ? 255 : qindex;
+  return bd == 8 ? av1mi::k_ac_q8[q] : av1mi::k_ac_q10[q];
+}
+static int check_q(av1mi_ctx *ctx, const void *a, const void *b, size_t n, int coef_per_blk, int dc_q, int ac_q, int log_scale) {
+  if (!a || !b) return fail(ctx, AV1MI_E_INVAL, "null device pointer");
+  if (n & 3) return fail(ctx, AV1MI_E_INVAL, "coefficient count %zu must be a multiple of 4", n);
+  if (coef_per_blk < 16 || (coef_per_blk & 3)) return fail(ctx, AV1MI_E_INVAL, "coef_per_blk %d invalid", coef_per_blk);
+  if (dc_q < 4 || ac_q < 4 || dc_q > 32767 || ac_q > 32767) return fail(ctx, AV1MI_E_INVAL, "quantiser step out of range");
+  if (log_scale < 0 || log_scale > 2) return fail(ctx, AV1MI_E_INVAL, "log_scale %d out of range", log_scale);
+  return AV1MI_OK;
+}
+int av1mi_quantize(av1mi_ctx *ctx, const int32_t *d_coef, int16_t *d_levels, int32_t *d_dqcoef, size_t n,
+                   int coef_per_blk, int dc_q, int ac_q, int log_scale) {
+  BIND(ctx);
+  if (int rc = check_q(ctx, d_coef, d_levels, n, coef_per_blk, dc_q, ac_q, log_scale)) return rc;
+  HIP_TRY(ctx, av1mi::launch_quantize(d_coef, d_levels, d_dqcoef, (long long)n, coef_per_blk, dc_q, ac_q, log_scale, ctx->stream));
+  return AV1MI_OK;
+}
+int av1mi_dequantize(av1mi_ctx *ctx, const int16_t *d_levels, int32_t *d_dqcoef, size_t n, int coef_per_blk,
+                     int dc_q, int ac_q, int log_scale, int bd) {
+  BIND(ctx);
+  if (int rc = check_q(ctx, d_levels, d_dqcoef, n, coef_per_blk, dc_q, ac_q, log_scale)) return rc;
+  if (bd != 8 && bd != 10) return fail(ctx, AV1MI_E_INVAL, "bit depth %d not supported (8 or 10)", bd);
+  HIP_TRY(ctx, av1mi::launch_dequantize(d_levels, d_dqcoef, (long long)n, coef_per_blk, dc_q, ac_q, log_scale, bd, ctx->stream));
+  return AV1MI_OK;
+}
+
+int av1mi_inv_txfm2d_add(av1mi_ctx *ctx, const int32_t *coef, void *dst, int stride, int tx_size, int tx_type, int bd) {
+  BIND(ctx);
+  if (!coef || !dst) return fail(ctx, AV1MI_E_INVAL, "null pointer");
+  if (bd != 8 && bd != 10) return fail(ctx, AV1MI_E_INVAL, "bit depth %d not supported (8 or 10)", bd);
+  if (!tx_valid(tx_size, tx_type)) return fail(ctx, AV1MI_E_INVAL, "tx_type %d is not defined for tx_size %d", tx_type, tx_size);
+  const int w = av1mi::tx_width(tx_size), h = av1mi::tx_height(tx_size);
+  if (stride < w) return fail(ctx, AV1MI_E_INVAL, "stride %d < width %d", stride, w);
+  const int cw = w > 32 ? 32 : w, ch = h > 32 ? 32 : h, bps = bd == 8 ? 1 : 2;
+  const size_t coef_bytes = (size_t)cw * ch * 4, pix_bytes = (size_t)w * h * bps;
+  if (int rc = ensure_scratch(ctx, coef_bytes + pix_bytes + 64)) return rc;
+  char *d = (char *)ctx->scratch;
+  int32_t *d_coef = (int32_t *)d;
+  void *d_pix = d + coef_bytes;
+  av1mi_txb *d_list = (av1mi_txb *)(d + coef_bytes + pix_bytes);
+  const av1mi_txb blk = { 0, 0, 0, (uint32_t)tx_type, 0 };
+  HIP_TRY(ctx, hipMemcpyAsync(d_coef, coef, coef_bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpy2DAsync(d_pix, (size_t)w * bps, dst, (size_t)stride * bps, (size_t)w * bps, h, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(d_list, &blk, sizeof(blk), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // blk lives on this stack frame
+  av1mi::TxLaunch L = { d_coef, d_pix, w, 1, d_list, nullptr, 0, 1 };
+  HIP_TRY(ctx, av1mi::launch_inv_txfm(tx_size, L, bd, ctx->stream));
+  HIP_TRY(ctx, hipMemcpy2DAsync(dst, (size_t)stride * bps, d_pix, (size_t)w * bps, (size_t)w * bps, h, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return AV1MI_OK;
+}
+int av1mi_fwd_txfm2d(av1mi_ctx *ctx, const int16_t *resid, int stride, int32_t *coef, int tx_size, int tx_type) {
+  BIND(ctx);
+  if (!coef || !resid) return fail(ctx, AV1MI_E_INVAL, "null pointer");
+  if (!tx_valid(tx_size, tx_type)) return fail(ctx, AV1MI_E_INVAL, "tx_type %d is not defined for tx_size %d", tx_type, tx_size);
+  const int w = av1mi::tx_width(tx_size), h = av1mi::tx_height(tx_size);
+  if (stride < w) return fail(ctx, AV1MI_E_INVAL, "stride %d < width %d", stride, w);
+  const int cw = w > 32 ? 32 : w, ch = h > 32 ? 32 : h;
+  const size_t coef_bytes = (size_t)cw * ch * 4, pix_bytes = (size_t)w * h * 2;
+  if (int rc = ensure_scratch(ctx, coef_bytes + pix_bytes + 64)) return rc;
+  char *d = (char *)ctx->scratch;
+  int32_t *d_coef = (int32_t *)d;
+  int16_t *d_res = (int16_t *)(d + coef_bytes);
+  av1mi_txb *d_list = (av1mi_txb *)(d + coef_bytes + pix_bytes);
+  const av1mi_txb blk = { 0, 0, 0, (uint32_t)tx_type, 0 };
+  HIP_TRY(ctx, hipMemcpy2DAsync(d_res, (size_t)w * 2, resid, (size_t)stride * 2, (size_t)w * 2, h, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(d_list, &blk, sizeof(blk), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  av1mi::TxLaunch L = { d_coef, d_res, w, 1, d_list, nullptr, 0, 1 };
+  HIP_TRY(ctx, av1mi::launch_fwd_txfm(tx_size, L, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(coef, d_coef, coef_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return AV1MI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,118 @@
+/*
+ * av1mi.h — C ABI of libav1mi.so, the MI355X-native AV1 block-processing backend.
+ *
+ * Drop-in boundary.  The reference (IONIQ6000/av1-go) has no FFI for this path: its seam is
+ * the process contract of internal/ffmpeg/transcode.go:194
+ *     func RunTranscode(ffmpegPath string, args []string) (int, error)
+ * fed by TranscodeArgs (transcode.go:17) and called only from daemon.ProcessJob
+ * (internal/daemon/daemon.go:90,101).  All pixel work happens in the FFmpeg child
+ * (transcode.go:120 "-c:v:0 av1_vaapi").  This header is what a cgo replacement of
+ * RunTranscode binds instead; every entry point names the part of that
+ * contract, or the SURVEY.md §8a kernel row, it stands in for.
+ *
+ * Conventions: plain C, no C++ types, no exceptions cross the boundary.  Return 0 = OK,
+ * negative = AV1MI_E_*; av1mi_last_error(ctx) gives the text the Go wrapper turns into the
+ * (int, error) pair of transcode.go:194/311.  One context per GPU; a context is not
+ * thread-safe, distinct contexts are.  Every call selects the context's device first, so
+ * any OS thread (goroutines migrate) may call.  No callbacks.
+ * Pointers named d_* are DEVICE pointers obtained from av1mi_malloc(); others are host.
+ */
+#ifndef AV1MI_H
+#define AV1MI_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AV1MI_OK 0
+#define AV1MI_E_INVAL (-1)   /* bad argument (size/type/alignment) */
+#define AV1MI_E_DEVICE (-2)  /* HIP runtime error; text in av1mi_last_error */
+#define AV1MI_E_NOMEM (-3)
+#define AV1MI_E_NODEV (-4)   /* no gfx950 device / HIP extension unusable: the product never falls back to CPU */
+
+/* AV1 TX_SIZE / TX_TYPE numbering (AV1 spec §6.10.19). */
+enum av1mi_tx_size {
+  AV1MI_TX_4X4, AV1MI_TX_8X8, AV1MI_TX_16X16, AV1MI_TX_32X32, AV1MI_TX_64X64, AV1MI_TX_4X8, AV1MI_TX_8X4,
+  AV1MI_TX_8X16, AV1MI_TX_16X8, AV1MI_TX_16X32, AV1MI_TX_32X16, AV1MI_TX_32X64, AV1MI_TX_64X32, AV1MI_TX_4X16,
+  AV1MI_TX_16X4, AV1MI_TX_8X32, AV1MI_TX_32X8, AV1MI_TX_16X64, AV1MI_TX_64X16, AV1MI_TX_SIZES_ALL
+};
+enum av1mi_tx_type {
+  AV1MI_DCT_DCT, AV1MI_ADST_DCT, AV1MI_DCT_ADST, AV1MI_ADST_ADST, AV1MI_FLIPADST_DCT, AV1MI_DCT_FLIPADST,
+  AV1MI_FLIPADST_FLIPADST, AV1MI_ADST_FLIPADST, AV1MI_FLIPADST_ADST, AV1MI_IDTX, AV1MI_V_DCT, AV1MI_H_DCT,
+  AV1MI_V_ADST, AV1MI_H_ADST, AV1MI_V_FLIPADST, AV1MI_H_FLIPADST, AV1MI_TX_TYPES
+};
+
+typedef struct av1mi_ctx av1mi_ctx;
+
+/* One transform block of a block list (16 bytes, one dwordx4 load on the device). */
+typedef struct av1mi_txb {
+  uint32_t coef_off; /* offset of the block's coefficients in the coefficient buffer, int32 units, multiple of 4 */
+  uint16_t x, y;     /* top-left sample of the block in the plane; x multiple of 4 */
+  uint32_t tx_type;  /* enum av1mi_tx_type */
+  uint32_t reserved;
+} av1mi_txb;
+
+/* ---- library / context: stands in for ffmpeg provisioning + process spawn (binary.go:218, transcode.go:195) */
+const char *av1mi_version(void);
+int av1mi_device_count(void);                       /* number of HIP devices, 0 if none */
+int av1mi_open(int device, av1mi_ctx **out);        /* AV1MI_E_NODEV when no GPU: callers must fail the job */
+void av1mi_close(av1mi_ctx *ctx);
+const char *av1mi_last_error(av1mi_ctx *ctx);       /* <= 800 chars, the cap of transcode.go:295-297 */
+const char *av1mi_device_name(av1mi_ctx *ctx);
+
+/* ---- device memory and stream plumbing (all on the context's own HIP stream) */
+int av1mi_malloc(av1mi_ctx *ctx, void **d_ptr, size_t bytes);
+int av1mi_free(av1mi_ctx *ctx, void *d_ptr);
+int av1mi_upload(av1mi_ctx *ctx, void *d_dst, const void *src, size_t bytes);
+int av1mi_download(av1mi_ctx *ctx, void *dst, const void *d_src, size_t bytes);
+int av1mi_memset(av1mi_ctx *ctx, void *d_dst, int value, size_t bytes);
+int av1mi_sync(av1mi_ctx *ctx);
+/* HIP-event stopwatch on the context's stream: begin .. end brackets whatever was enqueued between. */
+int av1mi_timer_begin(av1mi_ctx *ctx);
+int av1mi_timer_end(av1mi_ctx *ctx, float *elapsed_ms);
+
+/* 1 when (tx_size, tx_type) is arithmetically defined: ADST needs length 4/8/16, identity <= 32. */
+int av1mi_txfm_valid(int tx_size, int tx_type);
+int av1mi_tx_width(int tx_size);
+int av1mi_tx_height(int tx_size);
+
+/* ---- K2: inverse 2-D transform + add to prediction + clip.  Asynchronous.
+ * d_plane holds the prediction on entry and the reconstruction afterwards; uint8 samples when
+ * bd == 8, uint16 when bd == 10; stride in samples, multiple of 4.
+ * Coefficients: int32, per block row-major min(w,32) x min(h,32) (64-point dimensions carry only
+ * the low 32 frequencies), blocks contiguous.
+ * grid form: block i covers (i % blocks_per_row, i / blocks_per_row) in units of the block size, its
+ * coefficients start at i * min(w,32)*min(h,32); d_tx_types (1 byte per block) may be NULL, then
+ * every block uses uniform_type. */
+int av1mi_inv_txfm_add_grid(av1mi_ctx *ctx, int tx_size, const int32_t *d_coef, void *d_plane, int stride, int bd,
+                            int blocks_per_row, int nblocks, const uint8_t *d_tx_types, int uniform_type);
+/* list form: explicit blocks, all of size tx_size. */
+int av1mi_inv_txfm_add_list(av1mi_ctx *ctx, int tx_size, const int32_t *d_coef, void *d_plane, int stride, int bd,
+                            const av1mi_txb *d_list, int nblocks);
+
+/* ---- K1: forward 2-D transform.  d_resid: int16 residual plane, stride in samples (multiple of 4). */
+int av1mi_fwd_txfm_grid(av1mi_ctx *ctx, int tx_size, const int16_t *d_resid, int stride, int32_t *d_coef,
+                        int blocks_per_row, int nblocks, const uint8_t *d_tx_types, int uniform_type);
+int av1mi_fwd_txfm_list(av1mi_ctx *ctx, int tx_size, const int16_t *d_resid, int stride, int32_t *d_coef,
+                        const av1mi_txb *d_list, int nblocks);
+
+/* ---- K8: quantise (encoder side) / dequantise (normative).  n coefficients, multiple of 4; the first
+ * coefficient of every run of coef_per_blk uses dc_q, the others ac_q.  d_dqcoef may be NULL in quantize. */
+int av1mi_dc_q(int qindex, int bd);
+int av1mi_ac_q(int qindex, int bd);
+int av1mi_quantize(av1mi_ctx *ctx, const int32_t *d_coef, int16_t *d_levels, int32_t *d_dqcoef, size_t n,
+                   int coef_per_blk, int dc_q, int ac_q, int log_scale);
+int av1mi_dequantize(av1mi_ctx *ctx, const int16_t *d_levels, int32_t *d_dqcoef, size_t n, int coef_per_blk,
+                     int dc_q, int ac_q, int log_scale, int bd);
+
+/* ---- host-pointer single-block forms (SURVEY.md §8b "per-stage test entry points"): copy in, run the
+ * same kernels, copy out, synchronous. */
+int av1mi_inv_txfm2d_add(av1mi_ctx *ctx, const int32_t *coef, void *dst, int stride, int tx_size, int tx_type, int bd);
+int av1mi_fwd_txfm2d(av1mi_ctx *ctx, const int16_t *resid, int stride, int32_t *coef, int tx_size, int tx_type);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AV1MI_H */

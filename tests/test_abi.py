@@ -1,0 +1,48 @@
+"""CPU tests of the drop-in boundary: libav1mi.so loads, exports every symbol include/av1mi.h
+declares, refuses to run without a GPU (no CPU fallback), and agrees with the oracle on which
+(size,type) pairs exist.  No compute calls here."""
+import ctypes as C
+import os
+
+import pytest
+
+
+def test_library_exports_every_declared_symbol(av1mi):
+    lib = av1mi.load()
+    names = av1mi.exported_symbols()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), "libav1mi.so does not export %s" % n
+
+
+def test_version_and_geometry(av1mi, O):
+    lib = av1mi.load()
+    assert lib.av1mi_version().decode().startswith("av1mi ")
+    for ts in range(19):
+        assert lib.av1mi_tx_width(ts) == O.TX_W[ts] and lib.av1mi_tx_height(ts) == O.TX_H[ts]
+        for tt in range(16):
+            assert bool(lib.av1mi_txfm_valid(ts, tt)) == O.txfm_valid(ts, tt)
+    assert lib.av1mi_tx_width(19) == 0 and lib.av1mi_txfm_valid(-1, 0) == 0
+
+
+def test_qtables_match_oracle(av1mi, O):
+    lib = av1mi.load()
+    for bd in (8, 10):
+        for q in range(256):
+            assert lib.av1mi_dc_q(q, bd) == O.dc_q(q, bd) and lib.av1mi_ac_q(q, bd) == O.ac_q(q, bd)
+
+
+def test_no_cpu_fallback_without_gpu(av1mi):
+    lib = av1mi.load()
+    if lib.av1mi_device_count() > 0:
+        pytest.skip("a GPU is present")
+    h = C.c_void_p()
+    assert lib.av1mi_open(0, C.byref(h)) == -4 and not h.value  # AV1MI_E_NODEV
+    with pytest.raises(av1mi.Av1miError):
+        av1mi.Context(0)
+
+
+def test_null_context_is_rejected(av1mi):
+    lib = av1mi.load()
+    assert lib.av1mi_sync(None) == -1
+    assert lib.av1mi_last_error(None) == b"null context"
