@@ -126,6 +126,9 @@ class Context:
     def sync(self):
         self._chk(self.lib.av1mi_sync(self.h))
 
+    def memset(self, d_buf, value, nbytes):
+        self._chk(self.lib.av1mi_memset(self.h, C.c_void_p(d_buf.ptr), int(value), C.c_size_t(nbytes)))
+
     def timer_begin(self):
         self._chk(self.lib.av1mi_timer_begin(self.h))
 

@@ -1,0 +1,141 @@
+#!/usr/bin/env python3
+"""bench.py — encoded-frames/sec of the MI355X block-processing hot path (BASELINE.json metric).
+
+One "step" = one closed-GOP segment of --frames synthetic frames through the device pipeline, inputs
+already resident in HBM.  N ranks (one per GPU, launched by torch.distributed.run) each process their
+own segments: no data-path collective, scaling is weak.  Rank 0 prints ONE JSON line.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 1080p8|4k10] [--frames F]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "av1-go_amd"))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="1080p8", choices=["1080p8", "4k10"])
+    ap.add_argument("--frames", type=int, default=0, help="frames per step (segment length); 0 = default")
+    ap.add_argument("--qindex", type=int, default=128)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(pipe, seconds=15.0):
+    """The oracle (own CPU restatement, kind "port") timed on this box's host cores on a bounded sample
+    of the same workload: whole frames of the segment, block rows spread over a thread pool."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as O
+    O.build()
+    cores = min(os.cpu_count() or 1, 16)
+    bd = pipe.bd
+    fh = [p.h // pipe.frames for p in pipe.planes]
+    done, t0 = 0, time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        while done < pipe.frames and (done == 0 or time.perf_counter() - t0 < seconds):
+            jobs = []
+            for p, h in zip(pipe.planes, fh):
+                src = p.src[done * h:(done + 1) * h]
+                resid = (src.astype(np.int32) - (1 << (bd - 1))).astype(np.int16)
+                pred = np.full(src.shape, 1 << (bd - 1), src.dtype)
+                nby = h // 8
+                step = max(1, nby // cores)
+                for r0 in range(0, nby, step):
+                    jobs.append(ex.submit(O.txq_plane, resid[r0 * 8:min(nby, r0 + step) * 8], pred[r0 * 8:min(nby, r0 + step) * 8],
+                                          1, pipe.dc_q, pipe.ac_q, bd))
+            for j in jobs:
+                j.result()
+            done += 1
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "%d frame(s) of the same segment through oracle/av1o_txq_plane (same stages as the GPU step), %.1f s" % (done, dt)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
+        sync_t = torch.zeros(1, device="cuda" if torch.cuda.is_available() else "cpu")
+
+    import av1mi
+    import pipeline
+
+    if args.workload == "1080p8":
+        W, H, bd = 1920, 1080, 8
+        frames = args.frames or 32
+    else:
+        W, H, bd = 3840, 2160, 10
+        frames = args.frames or 8
+    ctx = av1mi.Context(local_rank)
+    pipe = pipeline.IntraPipeline(ctx, W, H, bd, frames, args.qindex, first_frame=rank * frames)
+
+    def barrier():
+        ctx.sync()
+        if dist is not None:
+            dist.all_reduce(sync_t)
+            if sync_t.is_cuda:
+                import torch
+                torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        pipe.step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pipe.step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([dt], device=sync_t.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    total_frames = frames * args.steps * world
+    fps = total_frames / dt
+    out = {
+        "metric": "encoded 4K30 frames/sec (whole node) at fixed QP; PSNR-Y delta vs libaom",
+        "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u8" if bd == 8 else "u16", "data": "synthetic",
+        "config": {"workload": pipe.describe(), "frames_per_step": frames, "qindex": args.qindex,
+                   "sharding": "closed-GOP segment per GPU, no collective", "device": ctx.device_name},
+    }
+    if rank == 0:
+        # per-kernel roofline of the dominant kernel: HIP events on the pipeline's own stream
+        out["roofline"] = pipe.roofline(HBM_PEAK_GBPS)
+        out["stage_ms"] = pipe.stage_times()
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pipe)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    pipe.close()
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -142,3 +142,21 @@ def dequantize(levels, dcq, acq, log_scale, bd):
     dq = np.zeros(levels.shape, np.int32)
     lib().av1o_dequantize(_p(levels, C.c_int16), levels.size, dcq, acq, log_scale, bd, _p(dq, C.c_int32))
     return dq
+
+
+def txq_plane(resid, pred, tx_size, dcq, acq, bd, tx_types=None, uniform_type=0, rows=None):
+    """whole-plane residual -> fwd -> quant -> dequant -> inv+recon; returns (recon, levels)."""
+    resid = np.ascontiguousarray(resid, np.int16)
+    dt = np.uint8 if bd == 8 else np.uint16
+    rec = np.ascontiguousarray(pred, dt).copy()
+    h, w = TX_H[tx_size], TX_W[tx_size]
+    nby, nbx = resid.shape[0] // h, resid.shape[1] // w
+    ch, cw = coef_shape(tx_size)
+    levels = np.zeros((nby * nbx, ch, cw), np.int16)
+    by0, by1 = rows if rows else (0, nby)
+    tt = None if tx_types is None else np.ascontiguousarray(tx_types, np.uint8)
+    rc = lib().av1o_txq_plane(_p(resid, C.c_int16), rec.ctypes.data_as(C.c_void_p), resid.shape[1], nbx, by0, by1, tx_size,
+                              None if tt is None else _p(tt, C.c_uint8), uniform_type, dcq, acq, bd, _p(levels, C.c_int16))
+    if rc:
+        raise ValueError("av1o_txq_plane rc=%d" % rc)
+    return rec, levels
