@@ -30,6 +30,11 @@ class TxBlock(C.Structure):
 
 TXB_DTYPE = np.dtype([("coef_off", "<u4"), ("x", "<u2"), ("y", "<u2"), ("tx_type", "<u4"), ("reserved", "<u4")])
 
+INTRA_BLK_DTYPE = np.dtype([("x", "<u2"), ("y", "<u2"), ("mode", "u1"), ("angle_delta", "i1"), ("flags", "u1"),
+                            ("n_top", "u1"), ("n_topright", "u1"), ("n_left", "u1"), ("n_bottomleft", "u1"),
+                            ("reserved", "u1", (5,))])
+assert INTRA_BLK_DTYPE.itemsize == 16 and TXB_DTYPE.itemsize == 16
+
 _lib = None
 
 
@@ -164,6 +169,11 @@ class Context:
     def dequantize(self, d_levels, d_dq, n, coef_per_blk, dc_q, ac_q, log_scale, bd):
         self._chk(self.lib.av1mi_dequantize(self.h, C.c_void_p(d_levels.ptr), C.c_void_p(d_dq.ptr), C.c_size_t(n), coef_per_blk,
                                             dc_q, ac_q, log_scale, bd))
+
+    # ---- K3
+    def intra_pred_list(self, tx_size, d_ref, ref_stride, d_dst, dst_stride, bd, d_list, nblocks):
+        self._chk(self.lib.av1mi_intra_pred_list(self.h, tx_size, C.c_void_p(d_ref.ptr), ref_stride, C.c_void_p(d_dst.ptr),
+                                                 dst_stride, bd, C.c_void_p(d_list.ptr), nblocks))
 
     # ---- host-pointer single-block forms
     def inv_txfm2d_add(self, coef, pred, tx_size, tx_type, bd):

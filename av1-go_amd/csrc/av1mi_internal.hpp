@@ -18,6 +18,14 @@ struct TxLaunch {
   int blocks_per_row;
 };
 
+// K3: a list of equally-sized blocks predicted from `ref` into `dst`
+struct IntraLaunch {
+  const void *ref; void *dst;
+  int ref_stride, dst_stride, bd, nblocks;
+  const av1mi_intra_blk *blocks;
+};
+hipError_t launch_intra_pred(int tx_size, const IntraLaunch &L, hipStream_t s);
+
 int tx_width(int tx_size);
 int tx_height(int tx_size);
 hipError_t launch_inv_txfm(int tx_size, const TxLaunch &L, int bd, hipStream_t s);

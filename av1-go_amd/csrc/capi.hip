@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <string>
+#include <vector>
 #include "av1mi_internal.hpp"
 #include "qtables.hpp"
 
@@ -16,6 +17,13 @@ struct av1mi_ctx {
   char name[256] = { 0 };
   void *scratch = nullptr;  // staging for the host-pointer single-block forms
   size_t scratch_bytes = 0;
+  // per-kernel profile: one event pair per launch while enabled
+  bool prof_on = false;
+  struct ProfRec { int kind; hipEvent_t e0, e1; };
+  std::vector<ProfRec> prof_recs;
+  std::vector<hipEvent_t> prof_pool;
+  int prof_calls[AV1MI_K_KINDS] = { 0 };
+  double prof_ms[AV1MI_K_KINDS] = { 0 };
 };
 
 namespace {
@@ -39,6 +47,33 @@ int fail(av1mi_ctx *ctx, int code, const char *fmt, ...) {
     if (!(ctx)) return AV1MI_E_INVAL;                               \
     HIP_TRY(ctx, hipSetDevice((ctx)->device));                      \
   } while (0)
+
+hipEvent_t prof_event(av1mi_ctx *ctx) {
+  if (!ctx->prof_pool.empty()) { hipEvent_t e = ctx->prof_pool.back(); ctx->prof_pool.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+// RAII bracket around one kernel launch
+struct ProfScope {
+  av1mi_ctx *ctx; int kind; hipEvent_t e0 = nullptr, e1 = nullptr;
+  ProfScope(av1mi_ctx *c, int k) : ctx(c), kind(k) {
+    if (ctx->prof_on) { e0 = prof_event(ctx); e1 = prof_event(ctx); (void)hipEventRecord(e0, ctx->stream); }
+  }
+  ~ProfScope() {
+    if (e0) { (void)hipEventRecord(e1, ctx->stream); ctx->prof_recs.push_back({ kind, e0, e1 }); }
+  }
+};
+void prof_drain(av1mi_ctx *ctx) {
+  if (ctx->prof_recs.empty()) return;
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto &r : ctx->prof_recs) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) { ctx->prof_calls[r.kind]++; ctx->prof_ms[r.kind] += ms; }
+    ctx->prof_pool.push_back(r.e0); ctx->prof_pool.push_back(r.e1);
+  }
+  ctx->prof_recs.clear();
+}
 
 bool tx_valid(int tx_size, int tx_type) {
   if (tx_size < 0 || tx_size >= AV1MI_TX_SIZES_ALL || tx_type < 0 || tx_type >= AV1MI_TX_TYPES) return false;
@@ -106,6 +141,8 @@ void av1mi_close(av1mi_ctx *ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
+  for (auto &r : ctx->prof_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+  for (auto e : ctx->prof_pool) (void)hipEventDestroy(e);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -166,6 +203,32 @@ int av1mi_timer_end(av1mi_ctx *ctx, float *elapsed_ms) {
   return AV1MI_OK;
 }
 
+int av1mi_prof_enable(av1mi_ctx *ctx, int on) {
+  BIND(ctx);
+  if (!on) prof_drain(ctx);
+  ctx->prof_on = on != 0;
+  return AV1MI_OK;
+}
+int av1mi_prof_reset(av1mi_ctx *ctx) {
+  BIND(ctx);
+  prof_drain(ctx);
+  for (int k = 0; k < AV1MI_K_KINDS; k++) { ctx->prof_calls[k] = 0; ctx->prof_ms[k] = 0; }
+  return AV1MI_OK;
+}
+int av1mi_prof_get(av1mi_ctx *ctx, int kind, int *launches, double *total_ms) {
+  BIND(ctx);
+  if (kind < 0 || kind >= AV1MI_K_KINDS || !launches || !total_ms) return fail(ctx, AV1MI_E_INVAL, "bad profile query");
+  prof_drain(ctx);
+  *launches = ctx->prof_calls[kind];
+  *total_ms = ctx->prof_ms[kind];
+  return AV1MI_OK;
+}
+const char *av1mi_kernel_kind_name(int kind) {
+  static const char *n[AV1MI_K_KINDS] = { "fwd_txfm", "inv_txfm", "quantize", "dequantize", "intra_pred", "mc", "deblock",
+                                          "cdef", "loop_restoration", "intra_pipeline", "inter_pipeline", "misc" };
+  return kind < 0 || kind >= AV1MI_K_KINDS ? "?" : n[kind];
+}
+
 int av1mi_txfm_valid(int tx_size, int tx_type) { return tx_valid(tx_size, tx_type) ? 1 : 0; }
 int av1mi_tx_width(int tx_size) { return tx_size < 0 || tx_size >= AV1MI_TX_SIZES_ALL ? 0 : av1mi::tx_width(tx_size); }
 int av1mi_tx_height(int tx_size) { return tx_size < 0 || tx_size >= AV1MI_TX_SIZES_ALL ? 0 : av1mi::tx_height(tx_size); }
@@ -179,7 +242,7 @@ int av1mi_inv_txfm_add_grid(av1mi_ctx *ctx, int tx_size, const int32_t *d_coef, 
   if (!d_tx_types && !tx_valid(tx_size, uniform_type))
     return fail(ctx, AV1MI_E_INVAL, "tx_type %d is not defined for tx_size %d", uniform_type, tx_size);
   av1mi::TxLaunch L = { const_cast<int32_t *>(d_coef), d_plane, stride, nblocks, nullptr, d_tx_types, uniform_type, blocks_per_row };
-  HIP_TRY(ctx, av1mi::launch_inv_txfm(tx_size, L, bd, ctx->stream));
+  { ProfScope ps(ctx, AV1MI_K_INV_TXFM); HIP_TRY(ctx, av1mi::launch_inv_txfm(tx_size, L, bd, ctx->stream)); }
   return AV1MI_OK;
 }
 int av1mi_inv_txfm_add_list(av1mi_ctx *ctx, int tx_size, const int32_t *d_coef, void *d_plane, int stride, int bd,
@@ -189,7 +252,7 @@ int av1mi_inv_txfm_add_list(av1mi_ctx *ctx, int tx_size, const int32_t *d_coef, 
   if (bd != 8 && bd != 10) return fail(ctx, AV1MI_E_INVAL, "bit depth %d not supported (8 or 10)", bd);
   if (!d_list) return fail(ctx, AV1MI_E_INVAL, "null block list");
   av1mi::TxLaunch L = { const_cast<int32_t *>(d_coef), d_plane, stride, nblocks, d_list, nullptr, 0, 1 };
-  HIP_TRY(ctx, av1mi::launch_inv_txfm(tx_size, L, bd, ctx->stream));
+  { ProfScope ps(ctx, AV1MI_K_INV_TXFM); HIP_TRY(ctx, av1mi::launch_inv_txfm(tx_size, L, bd, ctx->stream)); }
   return AV1MI_OK;
 }
 int av1mi_fwd_txfm_grid(av1mi_ctx *ctx, int tx_size, const int16_t *d_resid, int stride, int32_t *d_coef,
@@ -200,7 +263,7 @@ int av1mi_fwd_txfm_grid(av1mi_ctx *ctx, int tx_size, const int16_t *d_resid, int
   if (!d_tx_types && !tx_valid(tx_size, uniform_type))
     return fail(ctx, AV1MI_E_INVAL, "tx_type %d is not defined for tx_size %d", uniform_type, tx_size);
   av1mi::TxLaunch L = { d_coef, const_cast<int16_t *>(d_resid), stride, nblocks, nullptr, d_tx_types, uniform_type, blocks_per_row };
-  HIP_TRY(ctx, av1mi::launch_fwd_txfm(tx_size, L, ctx->stream));
+  { ProfScope ps(ctx, AV1MI_K_FWD_TXFM); HIP_TRY(ctx, av1mi::launch_fwd_txfm(tx_size, L, ctx->stream)); }
   return AV1MI_OK;
 }
 int av1mi_fwd_txfm_list(av1mi_ctx *ctx, int tx_size, const int16_t *d_resid, int stride, int32_t *d_coef,
@@ -209,7 +272,21 @@ int av1mi_fwd_txfm_list(av1mi_ctx *ctx, int tx_size, const int16_t *d_resid, int
   if (int rc = check_tx_launch(ctx, tx_size, d_coef, d_resid, stride, nblocks)) return rc;
   if (!d_list) return fail(ctx, AV1MI_E_INVAL, "null block list");
   av1mi::TxLaunch L = { d_coef, const_cast<int16_t *>(d_resid), stride, nblocks, d_list, nullptr, 0, 1 };
-  HIP_TRY(ctx, av1mi::launch_fwd_txfm(tx_size, L, ctx->stream));
+  { ProfScope ps(ctx, AV1MI_K_FWD_TXFM); HIP_TRY(ctx, av1mi::launch_fwd_txfm(tx_size, L, ctx->stream)); }
+  return AV1MI_OK;
+}
+
+int av1mi_intra_pred_list(av1mi_ctx *ctx, int tx_size, const void *d_ref, int ref_stride, void *d_dst, int dst_stride,
+                          int bd, const av1mi_intra_blk *d_list, int nblocks) {
+  BIND(ctx);
+  if (tx_size < 0 || tx_size >= AV1MI_TX_SIZES_ALL) return fail(ctx, AV1MI_E_INVAL, "tx_size %d out of range", tx_size);
+  if (!d_ref || !d_dst || !d_list) return fail(ctx, AV1MI_E_INVAL, "null device pointer");
+  if (bd != 8 && bd != 10) return fail(ctx, AV1MI_E_INVAL, "bit depth %d not supported (8 or 10)", bd);
+  if (nblocks < 0 || ref_stride <= 0 || dst_stride <= 0 || (dst_stride & 3))
+    return fail(ctx, AV1MI_E_INVAL, "bad geometry (nblocks %d, strides %d/%d)", nblocks, ref_stride, dst_stride);
+  if ((uintptr_t)d_dst & 7) return fail(ctx, AV1MI_E_INVAL, "misaligned device pointer");
+  av1mi::IntraLaunch L = { d_ref, d_dst, ref_stride, dst_stride, bd, nblocks, d_list };
+  { ProfScope ps(ctx, AV1MI_K_INTRA_PRED); HIP_TRY(ctx, av1mi::launch_intra_pred(tx_size, L, ctx->stream)); }
   return AV1MI_OK;
 }
 
@@ -233,7 +310,7 @@ int av1mi_quantize(av1mi_ctx *ctx, const int32_t *d_coef, int16_t *d_levels, int
                    int coef_per_blk, int dc_q, int ac_q, int log_scale) {
   BIND(ctx);
   if (int rc = check_q(ctx, d_coef, d_levels, n, coef_per_blk, dc_q, ac_q, log_scale)) return rc;
-  HIP_TRY(ctx, av1mi::launch_quantize(d_coef, d_levels, d_dqcoef, (long long)n, coef_per_blk, dc_q, ac_q, log_scale, ctx->stream));
+  { ProfScope ps(ctx, AV1MI_K_QUANT); HIP_TRY(ctx, av1mi::launch_quantize(d_coef, d_levels, d_dqcoef, (long long)n, coef_per_blk, dc_q, ac_q, log_scale, ctx->stream)); }
   return AV1MI_OK;
 }
 int av1mi_dequantize(av1mi_ctx *ctx, const int16_t *d_levels, int32_t *d_dqcoef, size_t n, int coef_per_blk,
@@ -241,7 +318,7 @@ int av1mi_dequantize(av1mi_ctx *ctx, const int16_t *d_levels, int32_t *d_dqcoef,
   BIND(ctx);
   if (int rc = check_q(ctx, d_levels, d_dqcoef, n, coef_per_blk, dc_q, ac_q, log_scale)) return rc;
   if (bd != 8 && bd != 10) return fail(ctx, AV1MI_E_INVAL, "bit depth %d not supported (8 or 10)", bd);
-  HIP_TRY(ctx, av1mi::launch_dequantize(d_levels, d_dqcoef, (long long)n, coef_per_blk, dc_q, ac_q, log_scale, bd, ctx->stream));
+  { ProfScope ps(ctx, AV1MI_K_DEQUANT); HIP_TRY(ctx, av1mi::launch_dequantize(d_levels, d_dqcoef, (long long)n, coef_per_blk, dc_q, ac_q, log_scale, bd, ctx->stream)); }
   return AV1MI_OK;
 }
 

@@ -73,6 +73,18 @@ int av1mi_sync(av1mi_ctx *ctx);
 int av1mi_timer_begin(av1mi_ctx *ctx);
 int av1mi_timer_end(av1mi_ctx *ctx, float *elapsed_ms);
 
+/* Per-kernel HIP-event profile (bench.py's roofline leg).  While enabled, every kernel launch made through
+ * this context is bracketed by its own event pair on the context's stream; av1mi_prof_get() synchronises and
+ * returns, for one kernel kind, the number of launches and the summed device time since the last reset. */
+enum av1mi_kernel_kind {
+  AV1MI_K_FWD_TXFM, AV1MI_K_INV_TXFM, AV1MI_K_QUANT, AV1MI_K_DEQUANT, AV1MI_K_INTRA_PRED, AV1MI_K_MC,
+  AV1MI_K_DEBLOCK, AV1MI_K_CDEF, AV1MI_K_LR, AV1MI_K_INTRA_PIPE, AV1MI_K_INTER_PIPE, AV1MI_K_MISC, AV1MI_K_KINDS
+};
+int av1mi_prof_enable(av1mi_ctx *ctx, int on);
+int av1mi_prof_reset(av1mi_ctx *ctx);
+int av1mi_prof_get(av1mi_ctx *ctx, int kind, int *launches, double *total_ms);
+const char *av1mi_kernel_kind_name(int kind);
+
 /* 1 when (tx_size, tx_type) is arithmetically defined: ADST needs length 4/8/16, identity <= 32. */
 int av1mi_txfm_valid(int tx_size, int tx_type);
 int av1mi_tx_width(int tx_size);
@@ -106,6 +118,23 @@ int av1mi_quantize(av1mi_ctx *ctx, const int32_t *d_coef, int16_t *d_levels, int
                    int coef_per_blk, int dc_q, int ac_q, int log_scale);
 int av1mi_dequantize(av1mi_ctx *ctx, const int16_t *d_levels, int32_t *d_dqcoef, size_t n, int coef_per_blk,
                      int dc_q, int ac_q, int log_scale, int bd);
+
+/* ---- K3: intra prediction of a list of equally-sized transform blocks (AV1 spec §7.11.2).
+ * d_ref is the reconstructed plane the neighbours are read from, d_dst the plane the prediction is written to
+ * (may be the same allocation when no listed block is a neighbour of another).  Per block the caller passes what
+ * libaom's build_intra_predictors() takes: mode (0 DC, 1 V, 2 H, 3 D45, 4 D135, 5 D113, 6 D157, 7 D203, 8 D67,
+ * 9 SMOOTH, 10 SMOOTH_V, 11 SMOOTH_H, 12 PAETH), angle_delta -3..3 (directional modes), and the numbers of
+ * AVAILABLE neighbour samples (top <= w, top-right <= w, left <= h, bottom-left <= h). */
+typedef struct av1mi_intra_blk {
+  uint16_t x, y;       /* top-left sample; x multiple of 4 */
+  uint8_t mode;
+  int8_t angle_delta;
+  uint8_t flags;       /* bit 0: disable intra edge filter; bit 1: filter type (a neighbour is smooth-predicted) */
+  uint8_t n_top, n_topright, n_left, n_bottomleft;
+  uint8_t reserved[5];
+} av1mi_intra_blk;
+int av1mi_intra_pred_list(av1mi_ctx *ctx, int tx_size, const void *d_ref, int ref_stride, void *d_dst, int dst_stride,
+                          int bd, const av1mi_intra_blk *d_list, int nblocks);
 
 /* ---- host-pointer single-block forms (SURVEY.md §8b "per-stage test entry points"): copy in, run the
  * same kernels, copy out, synchronous. */

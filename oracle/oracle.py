@@ -160,3 +160,20 @@ def txq_plane(resid, pred, tx_size, dcq, acq, bd, tx_types=None, uniform_type=0,
     if rc:
         raise ValueError("av1o_txq_plane rc=%d" % rc)
     return rec, levels
+
+
+INTRA_MODE_NAMES = ["DC", "V", "H", "D45", "D135", "D113", "D157", "D203", "D67", "SMOOTH", "SMOOTH_V", "SMOOTH_H", "PAETH"]
+
+
+def intra_predict(plane, x, y, bw, bh, mode, angle_delta, bd, n_top, n_topright, n_left, n_bottomleft,
+                  disable_edge_filter=0, filter_type=0):
+    """plane: reconstructed plane (uint8 for bd 8, uint16 otherwise); returns the [bh, bw] prediction (uint16)."""
+    dt = np.uint8 if bd == 8 else np.uint16
+    plane = np.ascontiguousarray(plane, dt)
+    pred = np.zeros((bh, bw), np.uint16)
+    base = plane.ctypes.data + (y * plane.shape[1] + x) * plane.itemsize
+    rc = lib().av1o_intra_predict(C.c_void_p(base), plane.shape[1], bd, bw, bh, mode, angle_delta, disable_edge_filter,
+                                  filter_type, n_top, n_topright, n_left, n_bottomleft, _p(pred, C.c_uint16))
+    if rc:
+        raise ValueError("av1o_intra_predict rc=%d" % rc)
+    return pred
