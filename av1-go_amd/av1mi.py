@@ -175,6 +175,11 @@ class Context:
         self._chk(self.lib.av1mi_intra_pred_list(self.h, tx_size, C.c_void_p(d_ref.ptr), ref_stride, C.c_void_p(d_dst.ptr),
                                                  dst_stride, bd, C.c_void_p(d_list.ptr), nblocks))
 
+    # ---- K5
+    def deblock_plane(self, d_src, src_stride, d_dst, dst_stride, w, h, bd, is_chroma, d_mi, mi_stride, sharpness):
+        self._chk(self.lib.av1mi_deblock_plane(self.h, C.c_void_p(d_src.ptr), src_stride, C.c_void_p(d_dst.ptr), dst_stride, w, h, bd,
+                                               int(is_chroma), C.c_void_p(d_mi.ptr), mi_stride, sharpness))
+
     # ---- host-pointer single-block forms
     def inv_txfm2d_add(self, coef, pred, tx_size, tx_type, bd):
         coef = np.ascontiguousarray(coef, np.int32)

@@ -26,6 +26,15 @@ struct IntraLaunch {
 };
 hipError_t launch_intra_pred(int tx_size, const IntraLaunch &L, hipStream_t s);
 
+// K5: one plane, source -> destination (different allocations)
+struct DeblockLaunch {
+  const void *src; void *dst;
+  int src_stride, dst_stride, w, h, bd, is_chroma;
+  const uint32_t *mi; int mi_stride;   // (h/4) x (w/4) units of 4 bytes, see av1mi.h
+  int sharpness;
+};
+hipError_t launch_deblock(const DeblockLaunch &L, hipStream_t s);
+
 int tx_width(int tx_size);
 int tx_height(int tx_size);
 hipError_t launch_inv_txfm(int tx_size, const TxLaunch &L, int bd, hipStream_t s);

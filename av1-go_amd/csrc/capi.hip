@@ -290,6 +290,21 @@ int av1mi_intra_pred_list(av1mi_ctx *ctx, int tx_size, const void *d_ref, int re
   return AV1MI_OK;
 }
 
+int av1mi_deblock_plane(av1mi_ctx *ctx, const void *d_src, int src_stride, void *d_dst, int dst_stride, int w, int h,
+                        int bd, int is_chroma, const uint32_t *d_mi, int mi_stride, int sharpness) {
+  BIND(ctx);
+  if (!d_src || !d_dst || !d_mi || d_src == d_dst) return fail(ctx, AV1MI_E_INVAL, "null or aliased device pointer");
+  if (bd != 8 && bd != 10) return fail(ctx, AV1MI_E_INVAL, "bit depth %d not supported (8 or 10)", bd);
+  if (w <= 0 || h <= 0 || (w & 3) || (h & 3) || src_stride < w || dst_stride < w || (src_stride & 3) || (dst_stride & 3) ||
+      mi_stride < w / 4)
+    return fail(ctx, AV1MI_E_INVAL, "bad plane geometry %dx%d strides %d/%d/%d", w, h, src_stride, dst_stride, mi_stride);
+  if (sharpness < 0 || sharpness > 7) return fail(ctx, AV1MI_E_INVAL, "sharpness %d out of range", sharpness);
+  if (((uintptr_t)d_src & 7) || ((uintptr_t)d_dst & 7)) return fail(ctx, AV1MI_E_INVAL, "misaligned device pointer");
+  av1mi::DeblockLaunch L = { d_src, d_dst, src_stride, dst_stride, w, h, bd, is_chroma ? 1 : 0, d_mi, mi_stride, sharpness };
+  { ProfScope ps(ctx, AV1MI_K_DEBLOCK); HIP_TRY(ctx, av1mi::launch_deblock(L, ctx->stream)); }
+  return AV1MI_OK;
+}
+
 int av1mi_dc_q(int qindex, int bd) {
   const int q = qindex < 0 ? 0 : qindex > 255 ? 255 : qindex;
   return bd == 8 ? av1mi::k_dc_q8[q] : av1mi::k_dc_q10[q];

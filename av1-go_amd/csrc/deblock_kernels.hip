@@ -1,0 +1,227 @@
+// deblock_kernels.hip — SURVEY.md §8a row K5: the AV1 deblocking loop filter as ONE gfx950 kernel per plane.
+//
+// A workgroup owns a TW x TH window of output samples.  It stages the window plus a 16-sample halo of the
+// UNFILTERED source plane in LDS (coalesced row loads, uint16 per sample), runs pass 0 (vertical edges) on
+// every edge that can reach the window or the rows pass 1 will read, then pass 1 (horizontal edges) on the
+// window's columns, and writes the window back as whole rows.  Source and destination planes differ, so
+// neighbouring workgroups never see each other's output; edges in the halo are recomputed, never exchanged.
+// Within a pass edges are independent (a filter never reaches past half of the narrower transform block),
+// so lanes filter in place in LDS without ordering.
+// HBM traffic: b*S read + b*S written = the 2b*S of SURVEY.md §8d (halo re-reads come from L2).
+//
+// Restates AV1 spec §7.14 and libaom aom_dsp/loopfilter.c (highbd_filter4/6/8/14 and their masks); the
+// reference has no counterpart (internal/ffmpeg/transcode.go:120 names the external encoder only).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "av1mi_internal.hpp"
+
+namespace av1mi {
+
+struct LfThr { int lim, mblim, hev; };
+
+__device__ __forceinline__ LfThr lf_limits(int lvl, int sharp) {
+  const int shift = sharp > 4 ? 2 : (sharp > 0 ? 1 : 0);
+  int inside = lvl >> shift;
+  if (sharp > 0) inside = min(inside, 9 - sharp);
+  inside = max(inside, 1);
+  return { inside, 2 * (lvl + 2) + inside, lvl >> 4 };
+}
+
+// px[0..15] = p7..p0 q0..q7.  len in {4, 6, 8, 14}.  Every index is a compile-time constant.
+__device__ __forceinline__ void lf_filter(int (&px)[16], int len, LfThr t, int bd) {
+  const int sh = bd - 8;
+  const int lim = t.lim << sh, blim = t.mblim << sh, hevt = t.hev << sh, one = 1 << sh;
+#define P(i) px[7 - (i)]
+#define Q(i) px[8 + (i)]
+  bool mask = abs(P(1) - P(0)) <= lim && abs(Q(1) - Q(0)) <= lim && abs(P(0) - Q(0)) * 2 + abs(P(1) - Q(1)) / 2 <= blim;
+  bool flat = false, flat2 = false;
+  if (len >= 6) {
+    mask = mask && abs(P(2) - P(1)) <= lim && abs(Q(2) - Q(1)) <= lim;
+    flat = abs(P(1) - P(0)) <= one && abs(Q(1) - Q(0)) <= one && abs(P(2) - P(0)) <= one && abs(Q(2) - Q(0)) <= one;
+  }
+  if (len >= 8) {
+    mask = mask && abs(P(3) - P(2)) <= lim && abs(Q(3) - Q(2)) <= lim;
+    flat = flat && abs(P(3) - P(0)) <= one && abs(Q(3) - Q(0)) <= one;
+  }
+  if (len == 14)
+    flat2 = abs(P(4) - P(0)) <= one && abs(Q(4) - Q(0)) <= one && abs(P(5) - P(0)) <= one && abs(Q(5) - Q(0)) <= one &&
+            abs(P(6) - P(0)) <= one && abs(Q(6) - Q(0)) <= one;
+  if (!mask) return;   // filter4 with mask == 0 leaves all four samples unchanged
+  if (flat && flat2) {
+    // 13 taps [1 1 1 1 1 2 2 2 1 1 1 1 1], positions clamped to p6 / q6
+    int o[12];
+#pragma unroll
+    for (int i = -6; i < 6; i++) {
+      int s = 8;
+#pragma unroll
+      for (int k = -6; k <= 6; k++) {
+        const int pos = min(max(i + k, -7), 6);
+        s += (k >= -1 && k <= 1 ? 2 : 1) * px[8 + pos];
+      }
+      o[i + 6] = s >> 4;
+    }
+#pragma unroll
+    for (int i = 0; i < 12; i++) px[2 + i] = o[i];
+  } else if (flat && len >= 8) {
+    // 7 taps [1 1 1 2 1 1 1], clamped to p3 / q3
+    int o[6];
+#pragma unroll
+    for (int i = -3; i < 3; i++) {
+      int s = 4;
+#pragma unroll
+      for (int k = -3; k <= 3; k++) s += (k == 0 ? 2 : 1) * px[8 + min(max(i + k, -4), 3)];
+      o[i + 3] = s >> 3;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) px[5 + i] = o[i];
+  } else if (flat && len == 6) {
+    // 5 taps [1 2 2 2 1], clamped to p2 / q2
+    int o[4];
+#pragma unroll
+    for (int i = -2; i < 2; i++) {
+      int s = 4;
+#pragma unroll
+      for (int k = -2; k <= 2; k++) s += (k >= -1 && k <= 1 ? 2 : 1) * px[8 + min(max(i + k, -3), 2)];
+      o[i + 2] = s >> 3;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) px[6 + i] = o[i];
+  } else {
+    const int lo = -(128 << sh), hi = (128 << sh) - 1, t80 = 128 << sh;
+    const int ps1 = P(1) - t80, ps0 = P(0) - t80, qs0 = Q(0) - t80, qs1 = Q(1) - t80;
+    const bool hev = abs(P(1) - P(0)) > hevt || abs(Q(1) - Q(0)) > hevt;
+    int f = hev ? min(max(ps1 - qs1, lo), hi) : 0;
+    f = min(max(f + 3 * (qs0 - ps0), lo), hi);
+    const int f1 = min(f + 4, hi) >> 3, f2 = min(f + 3, hi) >> 3;
+    Q(0) = min(max(qs0 - f1, lo), hi) + t80;
+    P(0) = min(max(ps0 + f2, lo), hi) + t80;
+    f = hev ? 0 : (f1 + 1) >> 1;
+    Q(1) = min(max(qs1 - f, lo), hi) + t80;
+    P(1) = min(max(ps1 + f, lo), hi) + t80;
+  }
+#undef P
+#undef Q
+}
+
+// edge decision for the unit `cur` against `prev` (the unit on the other side): returns filter length or 0
+__device__ __forceinline__ int lf_edge(uint32_t cur, uint32_t prev, int pass, int pos, bool is_chroma, int &lvl) {
+  if (cur == 0xFFFFFFFFu || prev == 0xFFFFFFFFu) return 0;   // outside the plane
+  const int tx = pass == 0 ? (cur & 15) : ((cur >> 4) & 15);
+  if (pos & ((1 << tx) - 1)) return 0;                      // not a transform edge
+  const int flags = cur >> 24;
+  if ((flags & 1) && !((flags >> (1 + pass)) & 1)) return 0; // skipped inter block, inner edge
+  const int ptx = pass == 0 ? (prev & 15) : ((prev >> 4) & 15);
+  const int base = 1 << min(tx, ptx);
+  lvl = (cur >> (8 + 8 * pass)) & 255;
+  if (lvl == 0) lvl = (prev >> (8 + 8 * pass)) & 255;
+  if (lvl == 0) return 0;
+  if (is_chroma) return base == 4 ? 4 : 6;
+  return base == 4 ? 4 : base == 8 ? 8 : 14;
+}
+
+template <typename Pix, int TW, int TH>
+__global__ __launch_bounds__(256) void k_deblock(DeblockLaunch L) {
+  constexpr int HALO = 16, LW = TW + 2 * HALO, LH = TH + 2 * HALO, LS = LW + 2;   // +2: odd dword row stride
+  constexpr int MW = LW / 4, MH = LH / 4;
+  __shared__ uint16_t tile[LH * LS];
+  __shared__ uint32_t mis[MH * MW];
+  const int tid = threadIdx.x;
+  const int X0 = blockIdx.x * TW - HALO, Y0 = blockIdx.y * TH - HALO;   // frame coords of LDS (0,0)
+  const Pix *src = reinterpret_cast<const Pix *>(L.src);
+  const int cols = L.w >> 2, rows = L.h >> 2;
+  // mode-info units (0xFFFFFFFF outside the plane)
+  for (int i = tid; i < MH * MW; i += 256) {
+    const int ur = (Y0 >> 2) + i / MW, uc = (X0 >> 2) + i % MW;
+    uint32_t v = 0xFFFFFFFFu;
+    if (ur >= 0 && ur < rows && uc >= 0 && uc < cols) v = L.mi[(size_t)ur * L.mi_stride + uc];
+    mis[i] = v;
+  }
+  // samples, coordinates clamped into the plane, 4 per lane per step
+  for (int i = tid; i < LH * (LW / 4); i += 256) {
+    const int ly = i / (LW / 4), lx = (i % (LW / 4)) * 4;
+    const int fy = min(max(Y0 + ly, 0), L.h - 1), fx = X0 + lx;
+    const Pix *row = src + (size_t)fy * L.src_stride;
+    uint16_t *d = tile + ly * LS + lx;
+    if (fx >= 0 && fx + 3 < L.w) {
+      if constexpr (sizeof(Pix) == 1) {
+        const uint32_t u = *reinterpret_cast<const uint32_t *>(row + fx);
+        d[0] = u & 255; d[1] = (u >> 8) & 255; d[2] = (u >> 16) & 255; d[3] = u >> 24;
+      } else {
+        const uint2 u = *reinterpret_cast<const uint2 *>(row + fx);
+        d[0] = u.x & 0xffff; d[1] = u.x >> 16; d[2] = u.y & 0xffff; d[3] = u.y >> 16;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; k++) d[k] = row[min(max(fx + k, 0), L.w - 1)];
+    }
+  }
+  __syncthreads();
+  // pass 0: vertical edges at lx = 4*uc, uc in [3, TW/4+5], rows [4, TH+28)
+  {
+    constexpr int NU = TW / 4 + 3, NR = TH + 24;
+    for (int t = tid; t < NU * NR; t += 256) {
+      const int uc = 3 + t % NU, ly = 4 + t / NU;
+      const int fx = X0 + 4 * uc, fy = Y0 + ly;
+      if (fx <= 0 || fy < 0 || fy >= L.h) continue;
+      int lvl = 0;
+      const int len = lf_edge(mis[(ly >> 2) * MW + uc], mis[(ly >> 2) * MW + uc - 1], 0, fx, L.is_chroma, lvl);
+      if (!len) continue;
+      uint16_t *p = tile + ly * LS + 4 * uc;
+      int px[16];
+#pragma unroll
+      for (int k = 0; k < 16; k++) px[k] = p[k - 8];
+      lf_filter(px, len, lf_limits(lvl, L.sharpness), L.bd);
+      // write only what this length can modify: a neighbouring edge 4 samples away owns the rest
+      const int m = len == 14 ? 6 : len == 8 ? 3 : 2;
+#pragma unroll
+      for (int k = 2; k < 14; k++) if (k >= 8 - m && k < 8 + m) p[k - 8] = (uint16_t)px[k];
+    }
+  }
+  __syncthreads();
+  // pass 1: horizontal edges at ly = 4*ur, ur in [3, TH/4+5], columns of the window
+  {
+    constexpr int NU = TH / 4 + 3;
+    for (int t = tid; t < NU * TW; t += 256) {
+      const int lx = HALO + t % TW, ur = 3 + t / TW;
+      const int fx = X0 + lx, fy = Y0 + 4 * ur;
+      if (fy <= 0 || fx >= L.w) continue;
+      int lvl = 0;
+      const int len = lf_edge(mis[ur * MW + (lx >> 2)], mis[(ur - 1) * MW + (lx >> 2)], 1, fy, L.is_chroma, lvl);
+      if (!len) continue;
+      uint16_t *p = tile + (4 * ur) * LS + lx;
+      int px[16];
+#pragma unroll
+      for (int k = 0; k < 16; k++) px[k] = p[(k - 8) * LS];
+      lf_filter(px, len, lf_limits(lvl, L.sharpness), L.bd);
+      const int m = len == 14 ? 6 : len == 8 ? 3 : 2;
+#pragma unroll
+      for (int k = 2; k < 14; k++) if (k >= 8 - m && k < 8 + m) p[(k - 8) * LS] = (uint16_t)px[k];
+    }
+  }
+  __syncthreads();
+  // write the window, 4 samples per lane per step
+  Pix *dst = reinterpret_cast<Pix *>(L.dst);
+  for (int i = tid; i < TH * (TW / 4); i += 256) {
+    const int wy = i / (TW / 4), wx = (i % (TW / 4)) * 4;
+    const int fy = Y0 + HALO + wy, fx = X0 + HALO + wx;
+    if (fy >= L.h || fx >= L.w) continue;   // w, h are multiples of 4
+    const uint16_t *s = tile + (HALO + wy) * LS + HALO + wx;
+    Pix *o = dst + (size_t)fy * L.dst_stride + fx;
+    if constexpr (sizeof(Pix) == 1)
+      *reinterpret_cast<uint32_t *>(o) = (uint32_t)s[0] | ((uint32_t)s[1] << 8) | ((uint32_t)s[2] << 16) | ((uint32_t)s[3] << 24);
+    else {
+      uint2 u; u.x = (uint32_t)s[0] | ((uint32_t)s[1] << 16); u.y = (uint32_t)s[2] | ((uint32_t)s[3] << 16);
+      *reinterpret_cast<uint2 *>(o) = u;
+    }
+  }
+}
+
+hipError_t launch_deblock(const DeblockLaunch &L, hipStream_t s) {
+  constexpr int TW = 64, TH = 64;
+  const dim3 grid((L.w + TW - 1) / TW, (L.h + TH - 1) / TH);
+  if (L.bd == 8) hipLaunchKernelGGL((k_deblock<uint8_t, TW, TH>), grid, dim3(256), 0, s, L);
+  else hipLaunchKernelGGL((k_deblock<uint16_t, TW, TH>), grid, dim3(256), 0, s, L);
+  return hipGetLastError();
+}
+
+}  // namespace av1mi

@@ -136,6 +136,16 @@ typedef struct av1mi_intra_blk {
 int av1mi_intra_pred_list(av1mi_ctx *ctx, int tx_size, const void *d_ref, int ref_stride, void *d_dst, int dst_stride,
                           int bd, const av1mi_intra_blk *d_list, int nblocks);
 
+/* ---- K5: deblocking loop filter of one plane (AV1 spec §7.14), both passes in one launch, d_src -> d_dst
+ * (different allocations; w, h multiples of 4; strides in samples, multiples of 4).
+ * d_mi: (h/4) x (w/4) mode-info units of the PLANE (already subsampled for chroma), one uint32 each:
+ *   bits 0-3  log2(transform width), bits 4-7 log2(transform height) of the transform block covering the unit
+ *   bits 8-15 filter level used for vertical edges (pass 0), bits 16-23 for horizontal edges (pass 1), 0..63
+ *   bit 24    skip && is_inter (inner transform edges are not filtered)
+ *   bit 25    the unit's left edge is a prediction-block edge, bit 26 its top edge is one */
+int av1mi_deblock_plane(av1mi_ctx *ctx, const void *d_src, int src_stride, void *d_dst, int dst_stride, int w, int h,
+                        int bd, int is_chroma, const uint32_t *d_mi, int mi_stride, int sharpness);
+
 /* ---- host-pointer single-block forms (SURVEY.md §8b "per-stage test entry points"): copy in, run the
  * same kernels, copy out, synchronous. */
 int av1mi_inv_txfm2d_add(av1mi_ctx *ctx, const int32_t *coef, void *dst, int stride, int tx_size, int tx_type, int bd);

@@ -177,3 +177,22 @@ def intra_predict(plane, x, y, bw, bh, mode, angle_delta, bd, n_top, n_topright,
     if rc:
         raise ValueError("av1o_intra_predict rc=%d" % rc)
     return pred
+
+
+def lf_mi(tx_w_log2, tx_h_log2, lvl_v, lvl_h, skip_inter=0, blk_left=1, blk_top=1):
+    """pack one (or an array of) loop-filter mode-info unit(s) -> uint32"""
+    return (np.uint32(tx_w_log2) | (np.uint32(tx_h_log2) << 4) | (np.uint32(lvl_v) << 8) | (np.uint32(lvl_h) << 16)
+            | (np.uint32(skip_inter) << 24) | (np.uint32(blk_left) << 25) | (np.uint32(blk_top) << 26))
+
+
+def deblock_plane(plane, bd, is_chroma, mi, sharpness=0, pass_mask=3):
+    dt = np.uint8 if bd == 8 else np.uint16
+    out = np.ascontiguousarray(plane, dt).copy()
+    mi = np.ascontiguousarray(mi, np.uint32)
+    h, w = out.shape
+    assert mi.shape == (h // 4, w // 4)
+    rc = lib().av1o_deblock_plane(out.ctypes.data_as(C.c_void_p), w, w, h, bd, int(is_chroma), mi.ctypes.data_as(C.c_void_p),
+                                  mi.shape[1], sharpness, pass_mask)
+    if rc:
+        raise ValueError("av1o_deblock_plane rc=%d" % rc)
+    return out
