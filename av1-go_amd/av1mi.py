@@ -35,6 +35,15 @@ INTRA_BLK_DTYPE = np.dtype([("x", "<u2"), ("y", "<u2"), ("mode", "u1"), ("angle_
                             ("reserved", "u1", (5,))])
 assert INTRA_BLK_DTYPE.itemsize == 16 and TXB_DTYPE.itemsize == 16
 
+class IntraJob(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("bit_depth", C.c_int), ("nframes", C.c_int), ("qindex", C.c_int),
+                ("block_size", C.c_int), ("stride_y", C.c_int), ("stride_uv", C.c_int),
+                ("d_src_y", C.c_void_p), ("d_src_u", C.c_void_p), ("d_src_v", C.c_void_p),
+                ("d_rec_y", C.c_void_p), ("d_rec_u", C.c_void_p), ("d_rec_v", C.c_void_p),
+                ("d_lev_y", C.c_void_p), ("d_lev_u", C.c_void_p), ("d_lev_v", C.c_void_p),
+                ("d_modes_y", C.c_void_p), ("d_modes_uv", C.c_void_p)]
+
+
 _lib = None
 
 
@@ -179,6 +188,36 @@ class Context:
     def deblock_plane(self, d_src, src_stride, d_dst, dst_stride, w, h, bd, is_chroma, d_mi, mi_stride, sharpness):
         self._chk(self.lib.av1mi_deblock_plane(self.h, C.c_void_p(d_src.ptr), src_stride, C.c_void_p(d_dst.ptr), dst_stride, w, h, bd,
                                                int(is_chroma), C.c_void_p(d_mi.ptr), mi_stride, sharpness))
+
+    # ---- fused intra-only segment pipeline
+    def intra_encode(self, job):
+        self._chk(self.lib.av1mi_intra_encode(self.h, C.byref(job)))
+
+    def intra_encode_arrays(self, Y, U, V, bd, bs, qindex):
+        """convenience for tests: Y/U/V are [frames, h, w] arrays; returns dict of outputs like the oracle's"""
+        dt = np.uint8 if bd == 8 else np.uint16
+        Y, U, V = (np.ascontiguousarray(a, dt) for a in (Y, U, V))
+        nf, h, w = Y.shape
+        nb = (h // bs) * (w // bs)
+        bufs = {}
+        job = IntraJob(w, h, bd, nf, qindex, bs, w, w // 2)
+        for name, arr in (("src_y", Y), ("src_u", U), ("src_v", V)):
+            bufs[name] = self.to_device(arr)
+        for name, n in (("rec_y", Y.nbytes), ("rec_u", U.nbytes), ("rec_v", V.nbytes), ("lev_y", Y.size * 2), ("lev_u", U.size * 2),
+                        ("lev_v", V.size * 2), ("modes_y", nf * nb), ("modes_uv", nf * nb)):
+            bufs[name] = self.alloc(n)
+            self.memset(bufs[name], 0, n)
+        for name, b in bufs.items():
+            setattr(job, "d_" + name, b.ptr)
+        self.intra_encode(job)
+        cs = bs // 2
+        out = dict(rec_y=bufs["rec_y"].download(Y.shape, dt), rec_u=bufs["rec_u"].download(U.shape, dt),
+                   rec_v=bufs["rec_v"].download(V.shape, dt), lev_y=bufs["lev_y"].download((nf, nb, bs, bs), np.int16),
+                   lev_u=bufs["lev_u"].download((nf, nb, cs, cs), np.int16), lev_v=bufs["lev_v"].download((nf, nb, cs, cs), np.int16),
+                   modes_y=bufs["modes_y"].download((nf, nb), np.uint8), modes_uv=bufs["modes_uv"].download((nf, nb), np.uint8))
+        for b in bufs.values():
+            b.free()
+        return out
 
     # ---- host-pointer single-block forms
     def inv_txfm2d_add(self, coef, pred, tx_size, tx_type, bd):

@@ -35,6 +35,14 @@ struct DeblockLaunch {
 };
 hipError_t launch_deblock(const DeblockLaunch &L, hipStream_t s);
 
+// fused intra-only pipeline over a segment of stacked frames
+struct IntraPipeLaunch {
+  const void *src[3]; void *rec[3]; int16_t *lev[3];
+  uint8_t *modes_y, *modes_uv;
+  int w, h, stride_y, stride_uv, bd, nframes, dc_q, ac_q;
+};
+hipError_t launch_intra_pipe(const IntraPipeLaunch &L, int bs, hipStream_t s);
+
 int tx_width(int tx_size);
 int tx_height(int tx_size);
 hipError_t launch_inv_txfm(int tx_size, const TxLaunch &L, int bd, hipStream_t s);

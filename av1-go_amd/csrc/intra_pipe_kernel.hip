@@ -1,0 +1,281 @@
+// intra_pipe_kernel.hip — the closed-loop intra-only block pipeline (BASELINE config 2) as ONE gfx950 kernel:
+// per block: intra prediction from reconstructed neighbours (K3) -> mode decision (SAD over 11 candidate modes)
+// -> residual -> forward DCT (K1) -> quantise (K8) -> dequantise -> inverse DCT + reconstruct (K2).
+//
+// Parallelism.  Intra prediction chains every block to its reconstructed neighbours, so the unit of
+// independent work is the TILE: one 64x64 luma superblock (+ its two 32x32 chroma blocks), never predicted
+// across its border.  A tile is walked in z-order by a group of BS lanes (BS = luma block size): lane r owns
+// row r of the current block for prediction / residual / reconstruction and row-or-column r for the
+// transforms, with a BS x BS int32 LDS tile as the transpose buffer.  64/BS tiles share a wave and run in
+// lockstep, 256/BS share a workgroup; a 1080p frame has 510 tiles and a segment of F frames 510*F, so the grid
+// is F*510*BS/256 workgroups.  For chroma the group splits into two halves that code the U and the V block
+// of the same position at once (one shared uv mode, as in AV1).
+// Neighbour samples never come back from HBM: each tile keeps the last reconstructed sample of every column
+// ("above" line), of every row ("left" line) and each block's bottom-right sample in LDS, which is exactly
+// what the edge builder of intra.hpp needs in z-order.
+// HBM traffic per sample: source read b + reconstruction write b + levels write 2 (+ 1 mode byte per block).
+//
+// The arithmetic restates AV1 spec §7.11.2 / §7.13.3 / §7.12.3 (see intra.hpp, txfm1d.hpp); the encoder policy
+// (candidate list, SAD, first-minimum tie break, DCT_DCT, tile = superblock) is this project's own and is
+// mirrored by oracle/av1o_pipeline.c:av1o_intra_encode_frame for checking.  The reference has no counterpart
+// (internal/ffmpeg/transcode.go:120 hands the whole job to an external encoder).
+#include "intra.hpp"
+#include "txfm_cfg.hpp"
+#include "av1mi_internal.hpp"
+
+namespace av1mi {
+
+__device__ constexpr int kCand[11] = { DC_PRED, V_PRED, H_PRED, D45_PRED, D135_PRED, D113_PRED, D157_PRED, D203_PRED,
+                                       D67_PRED, SMOOTH_PRED, PAETH_PRED };
+
+__device__ __forceinline__ unsigned morton2(unsigned x, unsigned y) {
+  unsigned m = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) m |= ((x >> i) & 1u) << (2 * i) | ((y >> i) & 1u) << (2 * i + 1);
+  return m;
+}
+
+template <int N, typename Pix> __device__ __forceinline__ void load_row(const Pix *p, int *v) {
+  if constexpr (sizeof(Pix) == 1) {
+#pragma unroll
+    for (int c = 0; c < N; c += 4) {
+      const uint32_t u = *reinterpret_cast<const uint32_t *>(p + c);
+      v[c] = u & 255; v[c + 1] = (u >> 8) & 255; v[c + 2] = (u >> 16) & 255; v[c + 3] = u >> 24;
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < N; c += 4) {
+      const uint2 u = *reinterpret_cast<const uint2 *>(p + c);
+      v[c] = u.x & 0xffff; v[c + 1] = u.x >> 16; v[c + 2] = u.y & 0xffff; v[c + 3] = u.y >> 16;
+    }
+  }
+}
+template <int N, typename Pix> __device__ __forceinline__ void store_row(Pix *p, const int *v) {
+  if constexpr (sizeof(Pix) == 1) {
+#pragma unroll
+    for (int c = 0; c < N; c += 4)
+      *reinterpret_cast<uint32_t *>(p + c) = (uint32_t)v[c] | ((uint32_t)v[c + 1] << 8) | ((uint32_t)v[c + 2] << 16) | ((uint32_t)v[c + 3] << 24);
+  } else {
+#pragma unroll
+    for (int c = 0; c < N; c += 4) {
+      uint2 u; u.x = (uint32_t)v[c] | ((uint32_t)v[c + 1] << 16); u.y = (uint32_t)v[c + 2] | ((uint32_t)v[c + 3] << 16);
+      *reinterpret_cast<uint2 *>(p + c) = u;
+    }
+  }
+}
+
+// per-plane, per-tile neighbour context in LDS (indices in samples / blocks of that plane)
+struct TileCtx {
+  uint16_t *above;   // [tile width]  last reconstructed sample of each column
+  uint16_t *left;    // [tile height] last reconstructed sample of each row
+  uint16_t *br;      // [n*n] bottom-right sample of each coded block
+  uint16_t *edge;    // 4 edge arrays of edge_len(B,B) entries
+  int32_t *tbuf;     // B x (B+4) transpose buffer
+};
+
+// Code one B x B block with L = B lanes (`lane` in [0,B)); `gw` = lanes that share the mode decision (the whole
+// group: B for luma, 2B for the U+V pair).  Returns the chosen mode (identical in all gw lanes).
+template <int B, int GW, typename Pix>
+__device__ __forceinline__ int code_block(const TileCtx &C, int lane, int bx, int by, int n, int n_top, int n_topright, int n_left,
+                                          int n_bottomleft, int filter_type, int dc_q, int ac_q, const Pix *src_row,
+                                          Pix *rec_row, int16_t *lev_row) {
+  constexpr int EL = edge_len(B, B), RS = B + 4, bd = sizeof(Pix) == 1 ? 8 : 10;
+  uint16_t *above_e = C.edge + kEdgePad, *left_e = C.edge + EL + kEdgePad, *tmpa = C.edge + 2 * EL + kEdgePad,
+           *tmpl = C.edge + 3 * EL + kEdgePad;
+  const int x = bx * B, y = by * B;
+  auto fetch = [&](int yy, int xx) -> int {
+    if (yy < 0) return xx < 0 ? C.br[(by - 1) * n + bx - 1] : C.above[x + xx];
+    return C.left[y + yy];
+  };
+  int s[B], bp[B];
+  load_row<B>(src_row, s);
+  IntraBlk blk;
+  blk.angle_delta = 0; blk.disable_edge_filter = 0; blk.filter_type = filter_type;
+  blk.n_top = n_top; blk.n_topright = n_topright; blk.n_left = n_left; blk.n_bottomleft = n_bottomleft;
+  int best = 0x7fffffff, best_mode = 0;
+  for (int ci = 0; ci < 11; ci++) {
+    blk.mode = kCand[ci];
+    const IntraEdges E = intra_build_edges<B, B, B>(blk, bd, lane, above_e, left_e, tmpa, tmpl, fetch);
+    int out[B];
+    intra_pred_row<B, B>(blk, E, bd, lane, above_e, left_e, out);
+    int sad = 0;
+#pragma unroll
+    for (int c = 0; c < B; c++) sad += abs(s[c] - out[c]);
+#pragma unroll
+    for (int o = GW / 2; o >= 1; o >>= 1) sad += __shfl_xor(sad, o, GW);
+    if (sad < best) {
+      best = sad; best_mode = blk.mode;
+#pragma unroll
+      for (int c = 0; c < B; c++) bp[c] = out[c];
+    }
+    AV1MI_GROUP_SYNC();
+  }
+  // forward transform (libaom fwd_txfm2d_c: columns, then rows), DCT_DCT
+  int32_t *T = C.tbuf;
+  {
+    int4 *row = reinterpret_cast<int4 *>(T + lane * RS);
+#pragma unroll
+    for (int c = 0; c < B; c += 4) row[c / 4] = make_int4(s[c] - bp[c], s[c + 1] - bp[c + 1], s[c + 2] - bp[c + 2], s[c + 3] - bp[c + 3]);
+  }
+  AV1MI_GROUP_SYNC();
+  int32_t xv[B];
+#pragma unroll
+  for (int r = 0; r < B; r++) xv[r] = T[r * RS + lane] << fwd_shift(B, B, 0);
+  fdct<B, fwd_cos_bit_col(B, B)>(xv);
+  AV1MI_GROUP_SYNC();
+#pragma unroll
+  for (int r = 0; r < B; r++) T[r * RS + lane] = round2(xv[r], -fwd_shift(B, B, 1));
+  AV1MI_GROUP_SYNC();
+#pragma unroll
+  for (int c = 0; c < B; c += 4) {
+    const int4 v = *reinterpret_cast<const int4 *>(T + lane * RS + c);
+    xv[c] = v.x; xv[c + 1] = v.y; xv[c + 2] = v.z; xv[c + 3] = v.w;
+  }
+  fdct<B, fwd_cos_bit_row(B, B)>(xv);
+  // quantise / dequantise this row (libaom quantize_fp; spec 7.12.3), log_scale 0 for B <= 16
+  const int dc_quant = (1 << 16) / dc_q, ac_quant = (1 << 16) / ac_q, dc_rnd = (64 * dc_q) >> 7, ac_rnd = (64 * ac_q) >> 7;
+  const int maxv = (1 << (7 + bd)) - 1, minv = -(1 << (7 + bd));
+  int lv[B];
+#pragma unroll
+  for (int c = 0; c < B; c++) {
+    const bool dc = lane == 0 && c == 0;
+    const int q = dc ? dc_q : ac_q, quant = dc ? dc_quant : ac_quant, rnd = dc ? dc_rnd : ac_rnd;
+    const int v = round2(xv[c], -fwd_shift(B, B, 2));
+    const bool neg = v < 0;
+    int a = min(neg ? -v : v, 1 << 20), l = 0;
+    if ((a << 1) >= q) { a = min(a + rnd, 32767); l = (a * quant) >> 16; }
+    l = min(l, 32767);
+    lv[c] = neg ? -l : l;
+    const int d = (l * q) & 0xFFFFFF;
+    xv[c] = min(max(neg ? -d : d, minv), maxv);
+  }
+#pragma unroll
+  for (int c = 0; c < B; c += 4) {
+    uint2 o;
+    o.x = (uint32_t)(lv[c] & 0xffff) | ((uint32_t)lv[c + 1] << 16);
+    o.y = (uint32_t)(lv[c + 2] & 0xffff) | ((uint32_t)lv[c + 3] << 16);
+    *reinterpret_cast<uint2 *>(lev_row + c) = o;
+  }
+  // inverse transform (spec 7.13.3: rows, then columns) + reconstruction
+  constexpr int ROW_RANGE = bd + 8;
+#pragma unroll
+  for (int c = 0; c < B; c++) xv[c] = clampr<ROW_RANGE>(xv[c]);
+  idct<B, ROW_RANGE>(xv);
+  AV1MI_GROUP_SYNC();
+#pragma unroll
+  for (int c = 0; c < B; c += 4)
+    *reinterpret_cast<int4 *>(T + lane * RS + c) = make_int4(round2(xv[c], inv_row_shift(B, B)), round2(xv[c + 1], inv_row_shift(B, B)),
+                                                             round2(xv[c + 2], inv_row_shift(B, B)), round2(xv[c + 3], inv_row_shift(B, B)));
+  AV1MI_GROUP_SYNC();
+#pragma unroll
+  for (int r = 0; r < B; r++) xv[r] = min(max(T[r * RS + lane], -32768), 32767);   // max(bd+6,16) = 16 bits for bd <= 10
+  idct<B, 16>(xv);
+  AV1MI_GROUP_SYNC();
+#pragma unroll
+  for (int r = 0; r < B; r++) T[r * RS + lane] = round2(xv[r], 4);
+  AV1MI_GROUP_SYNC();
+  int rec[B];
+  const int maxpix = (1 << bd) - 1;
+#pragma unroll
+  for (int c = 0; c < B; c += 4) {
+    const int4 v = *reinterpret_cast<const int4 *>(T + lane * RS + c);
+    rec[c] = min(max(bp[c] + v.x, 0), maxpix); rec[c + 1] = min(max(bp[c + 1] + v.y, 0), maxpix);
+    rec[c + 2] = min(max(bp[c + 2] + v.z, 0), maxpix); rec[c + 3] = min(max(bp[c + 3] + v.w, 0), maxpix);
+  }
+  store_row<B>(rec_row, rec);
+  // neighbour context for the blocks to come
+  C.left[y + lane] = (uint16_t)rec[B - 1];
+  if (lane == B - 1) {
+#pragma unroll
+    for (int c = 0; c < B; c++) C.above[x + c] = (uint16_t)rec[c];
+    C.br[by * n + bx] = (uint16_t)rec[B - 1];
+  }
+  AV1MI_GROUP_SYNC();
+  return best_mode;
+}
+
+template <int BS, typename Pix>
+__global__ __launch_bounds__(256) void k_intra_pipe(IntraPipeLaunch L) {
+  constexpr int CS = BS / 2, N = 64 / BS, TPW = 256 / BS;
+  constexpr int ELY = edge_len(BS, BS), ELC = edge_len(CS, CS);
+  // per-tile LDS, uint16 units then int32 transpose buffer
+  constexpr int EDGE_U16 = 4 * ELY > 8 * ELC ? 4 * ELY : 8 * ELC;   // luma and chroma blocks alternate: one region
+  constexpr int U16_PER_TILE = (64 + 64 + N * N) + 2 * (32 + 32 + N * N) + EDGE_U16 + 2 * N * N /* mode ctx as u16 */;
+  constexpr int T32_PER_TILE = BS * (BS + 4);
+  __shared__ __attribute__((aligned(16))) int32_t tbufs[TPW * T32_PER_TILE];
+  __shared__ __attribute__((aligned(16))) uint16_t ctx16[TPW * U16_PER_TILE];
+
+  const int grp = threadIdx.x / BS, lane = threadIdx.x % BS;
+  const int sbw = (L.w + 63) / 64, sbh = (L.h + 63) / 64;
+  const long long tile = (long long)blockIdx.x * TPW + grp;
+  if (tile >= (long long)L.nframes * sbw * sbh) return;
+  const int f = (int)(tile / (sbw * sbh)), sb = (int)(tile % (sbw * sbh)), sby = sb / sbw, sbx = sb % sbw;
+  const int bw = L.w / BS, bh = L.h / BS;
+
+  uint16_t *u = ctx16 + grp * U16_PER_TILE;
+  TileCtx Y, Cp;   // Cp: this lane's chroma plane (U for the lower half of the group, V for the upper)
+  Y.above = u; Y.left = u + 64; Y.br = u + 128; u += 128 + N * N;
+  const int pl = lane / CS, cl = lane % CS;
+  uint16_t *cu = u + pl * (64 + N * N);
+  Cp.above = cu; Cp.left = cu + 32; Cp.br = cu + 64; u += 2 * (64 + N * N);
+  Y.edge = u;
+  Cp.edge = u + pl * 4 * ELC; u += EDGE_U16;
+  uint16_t *mode_y = u, *mode_c = u + N * N;
+  Y.tbuf = tbufs + grp * T32_PER_TILE;
+  Cp.tbuf = Y.tbuf + pl * (CS * (CS + 4));
+
+  const Pix *src_y = reinterpret_cast<const Pix *>(L.src[0]) + (size_t)f * L.h * L.stride_y;
+  Pix *rec_y = reinterpret_cast<Pix *>(L.rec[0]) + (size_t)f * L.h * L.stride_y;
+  const Pix *src_c = reinterpret_cast<const Pix *>(L.src[1 + pl]) + (size_t)f * (L.h / 2) * L.stride_uv;
+  Pix *rec_c = reinterpret_cast<Pix *>(L.rec[1 + pl]) + (size_t)f * (L.h / 2) * L.stride_uv;
+  int16_t *lev_y = L.lev[0] + (size_t)f * L.w * L.h;
+  int16_t *lev_c = L.lev[1 + pl] + (size_t)f * (L.w / 2) * (L.h / 2);
+  uint8_t *modes_y = L.modes_y + (size_t)f * bw * bh, *modes_uv = L.modes_uv + (size_t)f * bw * bh;
+
+  for (unsigned k = 0; k < (unsigned)(N * N); k++) {
+    unsigned bx = 0, by = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { bx |= ((k >> (2 * i)) & 1u) << i; by |= ((k >> (2 * i + 1)) & 1u) << i; }
+    const int fx = sbx * N + bx, fy = sby * N + by;
+    if (fx >= bw || fy >= bh) continue;
+    const bool have_top = by > 0, have_left = bx > 0;
+    const bool have_tr = have_top && (int)bx + 1 < N && fx + 1 < bw && morton2(bx + 1, by - 1) < k;
+    const bool have_bl = have_left && (int)by + 1 < N && fy + 1 < bh && morton2(bx - 1, by + 1) < k;
+    int ft = 0, ftc = 0;
+    if (have_top) { const int m = mode_y[(by - 1) * N + bx], mc = mode_c[(by - 1) * N + bx]; ft |= m >= 9 && m <= 11; ftc |= mc >= 9 && mc <= 11; }
+    if (have_left) { const int m = mode_y[by * N + bx - 1], mc = mode_c[by * N + bx - 1]; ft |= m >= 9 && m <= 11; ftc |= mc >= 9 && mc <= 11; }
+    const size_t blk = (size_t)fy * bw + fx;
+    {
+      const size_t off = ((size_t)fy * BS + lane) * L.stride_y + (size_t)fx * BS;
+      const int m = code_block<BS, BS, Pix>(Y, lane, bx, by, N, have_top ? BS : 0, have_tr ? BS : 0, have_left ? BS : 0,
+                                             have_bl ? BS : 0, ft, L.dc_q, L.ac_q, src_y + off, rec_y + off,
+                                             lev_y + blk * BS * BS + lane * BS);
+      if (lane == 0) { modes_y[blk] = (uint8_t)m; mode_y[by * N + bx] = (uint16_t)m; }
+    }
+    {
+      const size_t off = ((size_t)fy * CS + cl) * L.stride_uv + (size_t)fx * CS;
+      const int m = code_block<CS, BS, Pix>(Cp, cl, bx, by, N, have_top ? CS : 0, have_tr ? CS : 0, have_left ? CS : 0,
+                                             have_bl ? CS : 0, ftc, L.dc_q, L.ac_q, src_c + off, rec_c + off,
+                                             lev_c + blk * CS * CS + cl * CS);
+      if (lane == 0) { modes_uv[blk] = (uint8_t)m; mode_c[by * N + bx] = (uint16_t)m; }
+    }
+    AV1MI_GROUP_SYNC();
+  }
+}
+
+hipError_t launch_intra_pipe(const IntraPipeLaunch &L, int bs, hipStream_t s) {
+  const long long tiles = (long long)L.nframes * ((L.w + 63) / 64) * ((L.h + 63) / 64);
+  if (tiles <= 0) return hipSuccess;
+  const int tpw = 256 / bs;
+  const dim3 grid((unsigned)((tiles + tpw - 1) / tpw));
+  if (bs == 8) {
+    if (L.bd == 8) hipLaunchKernelGGL((k_intra_pipe<8, uint8_t>), grid, dim3(256), 0, s, L);
+    else hipLaunchKernelGGL((k_intra_pipe<8, uint16_t>), grid, dim3(256), 0, s, L);
+  } else if (bs == 16) {
+    if (L.bd == 8) hipLaunchKernelGGL((k_intra_pipe<16, uint8_t>), grid, dim3(256), 0, s, L);
+    else hipLaunchKernelGGL((k_intra_pipe<16, uint16_t>), grid, dim3(256), 0, s, L);
+  } else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+}  // namespace av1mi

@@ -14,45 +14,10 @@
 // av1_quantize_fp; the reference holds no arithmetic for this path (transcode.go:120 names the
 // external encoder only).
 #include "txfm1d.hpp"
+#include "txfm_cfg.hpp"
 #include "av1mi_internal.hpp"
 
 namespace av1mi {
-
-__host__ __device__ constexpr int imin(int a, int b) { return a < b ? a : b; }
-__host__ __device__ constexpr int imax(int a, int b) { return a > b ? a : b; }
-
-// spec Transform_Row_Shift, indexed by (log2 w - 2, log2 h - 2)
-__host__ __device__ constexpr int inv_row_shift(int w, int h) {
-  // {4x4:0, 8x8:1, 16x16:2, 32x32:2, 64x64:2, 4x8:0, 8x4:0, 8x16:1,16x8:1,16x32:1,32x16:1,32x64:1,64x32:1,
-  //  4x16:1,16x4:1, 8x32:2,32x8:2,16x64:2,64x16:2}
-  const int a = imin(w, h), b = imax(w, h);
-  if (a == b) return a == 4 ? 0 : a == 8 ? 1 : 2;
-  if (b == 2 * a) return a == 4 ? 0 : 1;
-  return a == 4 ? 1 : 2;  // 1:4
-}
-// libaom av1_fwd_txfm_shift_ls
-__host__ __device__ constexpr int fwd_shift(int w, int h, int i) {
-  const int a = imin(w, h), b = imax(w, h);
-  int s0 = 2, s1 = 0, s2 = 0;
-  if (a == b) { s1 = a == 4 ? 0 : a == 8 ? -1 : a == 16 ? -2 : a == 32 ? -4 : -2; if (a == 64) { s0 = 0; s2 = -2; } }
-  else if (b == 2 * a) {
-    s1 = a == 4 ? -1 : a == 8 ? -2 : a == 16 ? -4 : -2;
-    if (a == 32) { if (w == 32) { s0 = 0; s1 = -2; s2 = -2; } else { s0 = 2; s1 = -4; s2 = -2; } }
-  } else {
-    s1 = a == 4 ? -1 : a == 8 ? -2 : -4;
-    if (a == 16) { if (w == 16) { s0 = 0; s1 = -2; s2 = 0; } else { s0 = 2; s1 = -4; s2 = 0; } }
-  }
-  return i == 0 ? s0 : i == 1 ? s1 : s2;
-}
-__host__ __device__ constexpr int fwd_cos_bit_col(int w, int h) {
-  constexpr int t[5][5] = { { 13, 13, 13, 0, 0 }, { 13, 13, 13, 12, 0 }, { 13, 13, 13, 12, 13 }, { 0, 13, 13, 12, 13 }, { 0, 0, 13, 12, 13 } };
-  return t[ilog2c(w) - 2][ilog2c(h) - 2];
-}
-__host__ __device__ constexpr int fwd_cos_bit_row(int w, int h) {
-  constexpr int t[5][5] = { { 13, 13, 12, 0, 0 }, { 13, 13, 13, 12, 0 }, { 13, 13, 12, 13, 12 }, { 0, 12, 13, 12, 11 }, { 0, 0, 12, 11, 10 } };
-  return t[ilog2c(w) - 2][ilog2c(h) - 2];
-}
-__host__ __device__ constexpr bool is_rect2(int w, int h) { return w == 2 * h || h == 2 * w; }
 
 template <int W, int H> struct TxGeom {
   static constexpr int CW = imin(W, 32), CH = imin(H, 32);   // stored coefficient extent

@@ -146,6 +146,23 @@ int av1mi_intra_pred_list(av1mi_ctx *ctx, int tx_size, const void *d_ref, int re
 int av1mi_deblock_plane(av1mi_ctx *ctx, const void *d_src, int src_stride, void *d_dst, int dst_stride, int w, int h,
                         int bd, int is_chroma, const uint32_t *d_mi, int mi_stride, int sharpness);
 
+/* ---- the intra-only segment pipeline (BASELINE config 2): what stands in for the encode the reference delegates
+ * to `ffmpeg -c:v:0 av1_vaapi` (transcode.go:120) for key frames.  One launch codes `nframes` frames that are
+ * stacked in the plane buffers (frame f starts at row f*height of the luma planes, f*height/2 of the chroma planes).
+ * Every 64x64 superblock is an independent tile; blocks are block_size x block_size (8 or 16; width and height must
+ * be multiples of it), transform = block size, DCT_DCT, mode chosen per block by SAD among DC/V/H/6 diagonals/
+ * SMOOTH/PAETH.  Outputs: reconstruction planes, int16 levels (block-contiguous, raster order of blocks, per plane),
+ * one mode byte per block for luma and one for the chroma pair. */
+typedef struct av1mi_intra_job {
+  int width, height, bit_depth, nframes, qindex, block_size;
+  int stride_y, stride_uv;                 /* samples; multiples of 4 */
+  const void *d_src_y, *d_src_u, *d_src_v; /* source frames */
+  void *d_rec_y, *d_rec_u, *d_rec_v;       /* reconstruction (output) */
+  int16_t *d_lev_y, *d_lev_u, *d_lev_v;    /* quantised levels (output): nframes * width*height (/4 for chroma) */
+  uint8_t *d_modes_y, *d_modes_uv;         /* nframes * (width/bs)*(height/bs) each */
+} av1mi_intra_job;
+int av1mi_intra_encode(av1mi_ctx *ctx, const av1mi_intra_job *job);
+
 /* ---- host-pointer single-block forms (SURVEY.md §8b "per-stage test entry points"): copy in, run the
  * same kernels, copy out, synchronous. */
 int av1mi_inv_txfm2d_add(av1mi_ctx *ctx, const int32_t *coef, void *dst, int stride, int tx_size, int tx_type, int bd);

@@ -12,6 +12,9 @@ int av1o_inv_txfm2d_add(const int32_t *coef, void *dst, int stride, int tx_size,
 int av1o_quantize(const int32_t *coef, int n, int dc_q, int ac_q, int log_scale, int16_t *levels, int32_t *dqcoef);
 void av1o_dequantize(const int16_t *levels, int n, int dc_q, int ac_q, int log_scale, int bd, int32_t *dqcoef);
 int av1o_tx_scale(int tx_size);
+int av1o_dc_q(int qindex, int delta, int bd);
+int av1o_ac_q(int qindex, int delta, int bd);
+#include <stdlib.h>
 
 /*
  * rows [by0,by1) of blocks of a plane split into equal tx_size blocks:
@@ -38,5 +41,109 @@ int av1o_txq_plane(const int16_t *resid, void *recon, int stride, int blocks_per
       rc = av1o_inv_txfm2d_add(dq, (char *)recon + off * bps, stride, tx_size, tt, bd, 1);
       if (rc) return rc;
     }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Intra-only frame encoder loop (BASELINE config 2), the checker of the GPU kernel k_intra_pipe.
+ * The DECISIONS here (candidate list, SAD cost, first-minimum tie break, DCT_DCT only, one 64x64
+ * superblock per tile, all blocks bs x bs in z-order) are this project's own encoder policy; the
+ * ARITHMETIC it applies per block is the spec restatement above (intra prediction §7.11.2, forward /
+ * inverse transform, quantiser, reconstruction).
+ */
+int av1o_intra_predict(const void *ref, int ref_stride, int bd, int bw, int bh, int mode, int angle_delta,
+                       int disable_edge_filter, int filter_type, int n_top_px, int n_topright_px, int n_left_px,
+                       int n_bottomleft_px, uint16_t *pred);
+
+static const int intra_candidates[11] = { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 12 }; /* DC V H D45 D135 D113 D157 D203 D67 SMOOTH PAETH */
+
+static unsigned morton(unsigned x, unsigned y) {
+  unsigned m = 0;
+  for (int i = 0; i < 8; i++) m |= ((x >> i) & 1u) << (2 * i) | ((y >> i) & 1u) << (2 * i + 1);
+  return m;
+}
+static int px_get(const void *p, int bd, size_t i) { return bd == 8 ? ((const uint8_t *)p)[i] : ((const uint16_t *)p)[i]; }
+static void px_set(void *p, int bd, size_t i, int v) { if (bd == 8) ((uint8_t *)p)[i] = (uint8_t)v; else ((uint16_t *)p)[i] = (uint16_t)v; }
+
+/* encode one bs x bs block of nplanes planes sharing one mode (luma: 1 plane; chroma: U and V) */
+static int encode_block(int nplanes, const void *const *src, void *const *rec, int stride, int bd, int bs, int x, int y,
+                        int n_top, int n_topright, int n_left, int n_bottomleft, int filter_type, int dc_q, int ac_q,
+                        int16_t *const *levels /* per plane, this block's bs*bs */) {
+  uint16_t pred[2][64 * 64];
+  const int tx_size = bs == 4 ? TX_4X4 : bs == 8 ? TX_8X8 : bs == 16 ? TX_16X16 : bs == 32 ? TX_32X32 : TX_64X64;
+  const int bps = bd == 8 ? 1 : 2;
+  long best = -1; int best_mode = 0;
+  for (int ci = 0; ci < 11; ci++) {
+    const int mode = intra_candidates[ci];
+    long sad = 0;
+    for (int p = 0; p < nplanes; p++) {
+      av1o_intra_predict((const char *)rec[p] + ((size_t)y * stride + x) * bps, stride, bd, bs, bs, mode, 0, 0, filter_type,
+                         n_top, n_topright, n_left, n_bottomleft, pred[0]);
+      for (int r = 0; r < bs; r++)
+        for (int c = 0; c < bs; c++) sad += labs((long)px_get(src[p], bd, (size_t)(y + r) * stride + x + c) - pred[0][r * bs + c]);
+    }
+    if (best < 0 || sad < best) { best = sad; best_mode = mode; }
+  }
+  for (int p = 0; p < nplanes; p++) {
+    int16_t resid[64 * 64];
+    int32_t coef[1024], dq[1024];
+    av1o_intra_predict((const char *)rec[p] + ((size_t)y * stride + x) * bps, stride, bd, bs, bs, best_mode, 0, 0, filter_type,
+                       n_top, n_topright, n_left, n_bottomleft, pred[p]);
+    for (int r = 0; r < bs; r++)
+      for (int c = 0; c < bs; c++)
+        resid[r * bs + c] = (int16_t)(px_get(src[p], bd, (size_t)(y + r) * stride + x + c) - pred[p][r * bs + c]);
+    const int n = bs > 32 ? 1024 : bs * bs, ls = av1o_tx_scale(tx_size);
+    av1o_fwd_txfm2d(resid, bs, coef, tx_size, DCT_DCT, bd);
+    av1o_quantize(coef, n, dc_q, ac_q, ls, levels[p], NULL);
+    av1o_dequantize(levels[p], n, dc_q, ac_q, ls, bd, dq);
+    /* reconstruct: write the prediction, then add the residual in place */
+    for (int r = 0; r < bs; r++)
+      for (int c = 0; c < bs; c++) px_set(rec[p], bd, (size_t)(y + r) * stride + x + c, pred[p][r * bs + c]);
+    av1o_inv_txfm2d_add(dq, (char *)rec[p] + ((size_t)y * stride + x) * bps, stride, tx_size, DCT_DCT, bd, 1);
+  }
+  return best_mode;
+}
+
+/*
+ * One frame.  Planes are w x h (luma) and w/2 x h/2 (chroma), w and h multiples of bs (luma block size, 8 or 16).
+ * Tiles are 64x64 luma superblocks; nothing is predicted across a tile edge.  levels_*: block-contiguous int16 in
+ * raster order of blocks; modes_*: one byte per block, raster order (modes_uv shared by U and V).
+ */
+int av1o_intra_encode_frame(const void *src_y, const void *src_u, const void *src_v, void *rec_y, void *rec_u, void *rec_v,
+                            int w, int h, int stride_y, int stride_uv, int bd, int bs, int qindex, int16_t *lev_y,
+                            int16_t *lev_u, int16_t *lev_v, uint8_t *modes_y, uint8_t *modes_uv) {
+  if ((bs != 8 && bs != 16) || (w % bs) || (h % bs) || (bd != 8 && bd != 10)) return -1;
+  const int dc_q = av1o_dc_q(qindex, 0, bd), ac_q = av1o_ac_q(qindex, 0, bd);
+  const int n = 64 / bs;                                   /* blocks per superblock side */
+  const int bw = w / bs, bh = h / bs;                      /* frame size in blocks */
+  const int cs = bs / 2;
+  for (int sby = 0; sby * 64 < h; sby++)
+    for (int sbx = 0; sbx * 64 < w; sbx++)
+      for (unsigned k = 0; k < (unsigned)(n * n); k++) {
+        /* k-th block in z-order */
+        int bx = 0, by = 0;
+        for (int i = 0; i < 4; i++) { bx |= ((k >> (2 * i)) & 1) << i; by |= ((k >> (2 * i + 1)) & 1) << i; }
+        const int fx = sbx * n + bx, fy = sby * n + by;     /* frame block coordinates */
+        if (fx >= bw || fy >= bh) continue;
+        const int have_top = by > 0, have_left = bx > 0;
+        const int have_tr = have_top && bx + 1 < n && fx + 1 < bw && morton(bx + 1, by - 1) < k;
+        const int have_bl = have_left && by + 1 < n && fy + 1 < bh && morton(bx - 1, by + 1) < k;
+        const size_t blk = (size_t)fy * bw + fx;
+        /* filter type: a smooth-predicted neighbour inside the tile (spec get_filter_type) */
+        int ft = 0, ftc = 0;
+        if (have_top) { const int m = modes_y[blk - bw], mc = modes_uv[blk - bw]; ft |= m >= 9 && m <= 11; ftc |= mc >= 9 && mc <= 11; }
+        if (have_left) { const int m = modes_y[blk - 1], mc = modes_uv[blk - 1]; ft |= m >= 9 && m <= 11; ftc |= mc >= 9 && mc <= 11; }
+        {
+          const void *s[1] = { src_y }; void *r[1] = { rec_y }; int16_t *l[1] = { lev_y + blk * bs * bs };
+          modes_y[blk] = (uint8_t)encode_block(1, s, r, stride_y, bd, bs, fx * bs, fy * bs, have_top ? bs : 0, have_tr ? bs : 0,
+                                               have_left ? bs : 0, have_bl ? bs : 0, ft, dc_q, ac_q, l);
+        }
+        {
+          const void *s[2] = { src_u, src_v }; void *r[2] = { rec_u, rec_v };
+          int16_t *l[2] = { lev_u + blk * cs * cs, lev_v + blk * cs * cs };
+          modes_uv[blk] = (uint8_t)encode_block(2, s, r, stride_uv, bd, cs, fx * cs, fy * cs, have_top ? cs : 0, have_tr ? cs : 0,
+                                                have_left ? cs : 0, have_bl ? cs : 0, ftc, dc_q, ac_q, l);
+        }
+      }
   return 0;
 }

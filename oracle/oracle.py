@@ -196,3 +196,22 @@ def deblock_plane(plane, bd, is_chroma, mi, sharpness=0, pass_mask=3):
     if rc:
         raise ValueError("av1o_deblock_plane rc=%d" % rc)
     return out
+
+
+def intra_encode_frame(Y, U, V, bd, bs, qindex):
+    """oracle intra-only encoder loop; returns dict(rec_y, rec_u, rec_v, lev_y, lev_u, lev_v, modes_y, modes_uv)"""
+    dt = np.uint8 if bd == 8 else np.uint16
+    Y, U, V = (np.ascontiguousarray(a, dt) for a in (Y, U, V))
+    h, w = Y.shape
+    nb = (h // bs) * (w // bs)
+    cs = bs // 2
+    out = dict(rec_y=np.zeros_like(Y), rec_u=np.zeros_like(U), rec_v=np.zeros_like(V),
+               lev_y=np.zeros((nb, bs, bs), np.int16), lev_u=np.zeros((nb, cs, cs), np.int16), lev_v=np.zeros((nb, cs, cs), np.int16),
+               modes_y=np.zeros(nb, np.uint8), modes_uv=np.zeros(nb, np.uint8))
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    rc = lib().av1o_intra_encode_frame(vp(Y), vp(U), vp(V), vp(out["rec_y"]), vp(out["rec_u"]), vp(out["rec_v"]), w, h, w, w // 2,
+                                       bd, bs, qindex, vp(out["lev_y"]), vp(out["lev_u"]), vp(out["lev_v"]), vp(out["modes_y"]),
+                                       vp(out["modes_uv"]))
+    if rc:
+        raise ValueError("av1o_intra_encode_frame rc=%d" % rc)
+    return out

@@ -15,7 +15,8 @@ def test_image(rng, h, w, bd):
     big = rng.integers(-25, 26, (h // 32 + 1, w // 32 + 1))
     img = img + np.kron(big, np.ones((32, 32)))[:h, :w]
     img = img + rng.integers(-1, 2, (h, w))
-    img[h // 2:h // 2 + 24] += rng.integers(-40, 41, (24, w))
+    nb = min(24, h - h // 2)
+    img[h // 2:h // 2 + nb] += rng.integers(-40, 41, (nb, w))
     img = np.clip(img, 0, 255)
     if bd == 10:
         img = img * 4 + rng.integers(0, 4, (h, w))
