@@ -41,7 +41,7 @@ def test_intra_pipe_constant_frame(ctx):
     got = ctx.intra_encode_arrays(Y, U, V, 8, 8, 100)
     # the first block of a tile is predicted from the 128-ish base values, so a DC residual is allowed there
     assert np.abs(got["rec_y"].astype(int) - 90).max() <= 2 and np.abs(got["rec_u"].astype(int) - 120).max() <= 2
-    assert np.count_nonzero(got["lev_y"]) <= got["lev_y"].shape[1] // 32
+    assert np.count_nonzero(got["lev_y"]) <= 2 * 6 * 4   # at most a few DC levels per tile (2 frames x 6 tiles)
 
 
 def test_intra_pipe_rejects_bad_jobs(ctx, av1mi):
