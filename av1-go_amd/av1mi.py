@@ -189,6 +189,29 @@ class Context:
         self._chk(self.lib.av1mi_deblock_plane(self.h, C.c_void_p(d_src.ptr), src_stride, C.c_void_p(d_dst.ptr), dst_stride, w, h, bd,
                                                int(is_chroma), C.c_void_p(d_mi.ptr), mi_stride, sharpness))
 
+    def deblock_frames(self, d_src, src_stride, d_dst, dst_stride, w, h, bd, is_chroma, d_mi, mi_stride, mi_frame_stride,
+                       sharpness, nframes):
+        self._chk(self.lib.av1mi_deblock_frames(self.h, C.c_void_p(d_src.ptr), src_stride, C.c_void_p(d_dst.ptr), dst_stride, w, h,
+                                                bd, int(is_chroma), C.c_void_p(d_mi.ptr), mi_stride, C.c_size_t(mi_frame_stride),
+                                                sharpness, nframes))
+
+    def prof_enable(self, on):
+        self._chk(self.lib.av1mi_prof_enable(self.h, int(on)))
+
+    def prof_reset(self):
+        self._chk(self.lib.av1mi_prof_reset(self.h))
+
+    def prof_get(self):
+        """{kind name: (launches, total_ms)} for kinds that were launched"""
+        self.lib.av1mi_kernel_kind_name.restype = C.c_char_p
+        out = {}
+        for k in range(12):
+            n, ms = C.c_int(), C.c_double()
+            self._chk(self.lib.av1mi_prof_get(self.h, k, C.byref(n), C.byref(ms)))
+            if n.value:
+                out[self.lib.av1mi_kernel_kind_name(k).decode()] = (n.value, ms.value)
+        return out
+
     # ---- fused intra-only segment pipeline
     def intra_encode(self, job):
         self._chk(self.lib.av1mi_intra_encode(self.h, C.byref(job)))

@@ -32,6 +32,7 @@ struct DeblockLaunch {
   int src_stride, dst_stride, w, h, bd, is_chroma;
   const uint32_t *mi; int mi_stride;   // (h/4) x (w/4) units of 4 bytes, see av1mi.h
   int sharpness;
+  int nframes; size_t mi_frame_stride;   // frames stacked vertically (h rows each); mi units between frames, 0 = shared
 };
 hipError_t launch_deblock(const DeblockLaunch &L, hipStream_t s);
 

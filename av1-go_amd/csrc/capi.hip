@@ -290,8 +290,9 @@ int av1mi_intra_pred_list(av1mi_ctx *ctx, int tx_size, const void *d_ref, int re
   return AV1MI_OK;
 }
 
-int av1mi_deblock_plane(av1mi_ctx *ctx, const void *d_src, int src_stride, void *d_dst, int dst_stride, int w, int h,
-                        int bd, int is_chroma, const uint32_t *d_mi, int mi_stride, int sharpness) {
+int av1mi_deblock_frames(av1mi_ctx *ctx, const void *d_src, int src_stride, void *d_dst, int dst_stride, int w, int h,
+                         int bd, int is_chroma, const uint32_t *d_mi, int mi_stride, size_t mi_frame_stride, int sharpness,
+                         int nframes) {
   BIND(ctx);
   if (!d_src || !d_dst || !d_mi || d_src == d_dst) return fail(ctx, AV1MI_E_INVAL, "null or aliased device pointer");
   if (bd != 8 && bd != 10) return fail(ctx, AV1MI_E_INVAL, "bit depth %d not supported (8 or 10)", bd);
@@ -299,10 +300,17 @@ int av1mi_deblock_plane(av1mi_ctx *ctx, const void *d_src, int src_stride, void 
       mi_stride < w / 4)
     return fail(ctx, AV1MI_E_INVAL, "bad plane geometry %dx%d strides %d/%d/%d", w, h, src_stride, dst_stride, mi_stride);
   if (sharpness < 0 || sharpness > 7) return fail(ctx, AV1MI_E_INVAL, "sharpness %d out of range", sharpness);
+  if (nframes < 0 || nframes > 65535) return fail(ctx, AV1MI_E_INVAL, "nframes %d out of range", nframes);
   if (((uintptr_t)d_src & 7) || ((uintptr_t)d_dst & 7)) return fail(ctx, AV1MI_E_INVAL, "misaligned device pointer");
-  av1mi::DeblockLaunch L = { d_src, d_dst, src_stride, dst_stride, w, h, bd, is_chroma ? 1 : 0, d_mi, mi_stride, sharpness };
+  if (nframes == 0) return AV1MI_OK;
+  av1mi::DeblockLaunch L = { d_src, d_dst, src_stride, dst_stride, w, h, bd, is_chroma ? 1 : 0, d_mi, mi_stride, sharpness,
+                             nframes, mi_frame_stride };
   { ProfScope ps(ctx, AV1MI_K_DEBLOCK); HIP_TRY(ctx, av1mi::launch_deblock(L, ctx->stream)); }
   return AV1MI_OK;
+}
+int av1mi_deblock_plane(av1mi_ctx *ctx, const void *d_src, int src_stride, void *d_dst, int dst_stride, int w, int h,
+                        int bd, int is_chroma, const uint32_t *d_mi, int mi_stride, int sharpness) {
+  return av1mi_deblock_frames(ctx, d_src, src_stride, d_dst, dst_stride, w, h, bd, is_chroma, d_mi, mi_stride, 0, sharpness, 1);
 }
 
 int av1mi_intra_encode(av1mi_ctx *ctx, const av1mi_intra_job *j) {

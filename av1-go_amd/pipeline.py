@@ -1,8 +1,8 @@
 """Host-side orchestration of the device pipeline over one closed-GOP segment (plumbing only).
 
-All frames of a segment are stacked into one tall plane per component so that every stage is ONE
-launch per plane per segment (a 1080p frame is ~20 us of HBM traffic per stage: per-frame launches
-would be launch-bound).  Everything stays resident in HBM between stages; only the int16 levels are
+All frames of a segment are stacked into one tall plane per component so that every stage is ONE launch per
+segment (a 1080p frame is a few tens of microseconds of device work per stage: per-frame launches would be
+launch-bound).  Everything stays resident in HBM between stages; only the int16 levels and the mode bytes are
 meant to leave the device (host entropy coding, SURVEY.md §8a row H1 — not built yet).
 """
 import numpy as np
@@ -10,104 +10,79 @@ import numpy as np
 import av1mi
 import synth
 
-TX_8X8 = 1
+
+def lf_level_from_q(ac_q, bd, key_frame=True):
+    """encoder policy, not normative: libaom's LPF_PICK_FROM_Q guess of the deblocking level from the AC step."""
+    if bd == 8:
+        g = (ac_q * 17563 - 421574 + (1 << 17)) >> 18 if key_frame else (ac_q * 6017 + 650707 + (1 << 17)) >> 18
+    else:
+        g = (ac_q * 20723 + 4060632 + (1 << 19)) >> 20
+    return int(min(max(g, 0), 63))
 
 
-class Plane:
-    def __init__(self, ctx, src, bd):
-        self.h, self.w = src.shape
-        self.n = src.size
-        self.src = src
-        self.bps = 1 if bd == 8 else 2
-        self.d_resid = ctx.to_device((src.astype(np.int32) - (1 << (bd - 1))).astype(np.int16))
-        self.d_pred = ctx.alloc(self.n * self.bps)      # prediction in, reconstruction out
-        self.d_coef = ctx.alloc(self.n * 4)
-        self.d_levels = ctx.alloc(self.n * 2)
-        self.d_dq = ctx.alloc(self.n * 4)
-
-    def free(self):
-        for b in (self.d_resid, self.d_pred, self.d_coef, self.d_levels, self.d_dq):
-            b.free()
+def lf_mi_word(tx_w_log2, tx_h_log2, lvl_v, lvl_h, skip_inter=0, blk_left=1, blk_top=1):
+    return (tx_w_log2 | (tx_h_log2 << 4) | (lvl_v << 8) | (lvl_h << 16) | (skip_inter << 24) | (blk_left << 25) | (blk_top << 26))
 
 
 class IntraPipeline:
-    """v0 of BASELINE config 2 (1080p 8-bit intra-only): per 8x8 block, flat (no-neighbour DC)
-    prediction -> residual -> forward DCT -> quantise -> dequantise -> inverse DCT -> reconstruct.
-    Directional intra prediction and the in-loop filters are not in this pipeline yet."""
+    """BASELINE config 2 (intra-only, every frame a key frame): per segment
+         1 launch  k_intra_pipe   intra prediction + mode decision + fwd DCT + quant + dequant + inv DCT + recon
+         3 launches k_deblock     deblocking of Y, U, V (both passes fused), reconstruction -> filtered planes
+    CDEF and loop restoration are separate kernels that join the loop when built."""
 
-    STAGES = ("k_fwd_txfm<8,8>", "k_quantize", "k_dequantize", "k_inv_txfm_add<8,8>")
-
-    def __init__(self, ctx, width, height, bd, frames, qindex, first_frame=0):
-        self.ctx, self.bd, self.frames = ctx, bd, frames
+    def __init__(self, ctx, width, height, bd, frames, qindex, first_frame=0, block_size=8):
+        self.ctx, self.bd, self.frames, self.bs, self.qindex = ctx, bd, frames, block_size, qindex
         self.width, self.height = width, height
-        ch = (height + 15) // 16 * 16   # coded height: multiple of 16 (8 for chroma)
         Y, U, V = synth.frames(width, height, frames, bd, first_frame)
-
-        def stack(p, hh):
-            pad = hh - p.shape[1]
-            if pad:
-                p = np.concatenate([p, np.repeat(p[:, -1:, :], pad, axis=1)], axis=1)
-            return p.reshape(-1, p.shape[2])
-        self.planes = [Plane(ctx, stack(Y, ch), bd), Plane(ctx, stack(U, ch // 2), bd), Plane(ctx, stack(V, ch // 2), bd)]
+        self.src = (Y, U, V)
+        self.bps = 1 if bd == 8 else 2
+        nb = (height // block_size) * (width // block_size)
+        self.d = {}
+        for name, arr in (("src_y", Y), ("src_u", U), ("src_v", V)):
+            self.d[name] = ctx.to_device(arr)
+        for name, n in (("rec_y", Y.nbytes), ("rec_u", U.nbytes), ("rec_v", V.nbytes), ("dbl_y", Y.nbytes), ("dbl_u", U.nbytes),
+                        ("dbl_v", V.nbytes), ("lev_y", Y.size * 2), ("lev_u", U.size * 2), ("lev_v", V.size * 2),
+                        ("modes_y", frames * nb), ("modes_uv", frames * nb)):
+            self.d[name] = ctx.alloc(n)
+        self.job = av1mi.IntraJob(width, height, bd, frames, qindex, block_size, width, width // 2)
+        for k in ("src_y", "src_u", "src_v", "rec_y", "rec_u", "rec_v", "lev_y", "lev_u", "lev_v", "modes_y", "modes_uv"):
+            setattr(self.job, "d_" + k, self.d[k].ptr)
         lib = ctx.lib
         self.dc_q, self.ac_q = lib.av1mi_dc_q(qindex, bd), lib.av1mi_ac_q(qindex, bd)
-        self.samples_per_frame = width * height * 3 // 2
-        self.coded_samples = sum(p.n for p in self.planes)
+        self.lf_level = lf_level_from_q(self.ac_q, bd)
+        l2y, l2c = int(np.log2(block_size)), int(np.log2(block_size // 2))
+        self.mi_y = np.full((height // 4, width // 4), lf_mi_word(l2y, l2y, self.lf_level, self.lf_level), np.uint32)
+        self.mi_c = np.full((height // 8, width // 8), lf_mi_word(l2c, l2c, self.lf_level, self.lf_level), np.uint32)
+        self.d["mi_y"], self.d["mi_c"] = ctx.to_device(self.mi_y), ctx.to_device(self.mi_c)
+        self.samples = Y.size + U.size + V.size            # per step
 
     def describe(self):
-        return ("%dx%d %d-bit 4:2:0 intra-only, 8x8 blocks: flat pred -> fwd DCT -> quant -> dequant -> inv DCT + recon "
-                "(K1+K8+K2; intra prediction / loop filters not in the loop yet)" % (self.width, self.height, self.bd))
-
-    # ---- stages, each one launch per plane over the whole segment
-    def _pred(self, p):
-        self.ctx.memset(p.d_pred, 128 if self.bd == 8 else 2, p.n * p.bps)  # 10-bit: 0x0202 = 514
-
-    def _fwd(self, p):
-        self.ctx.fwd_txfm_grid(TX_8X8, p.d_resid, p.w, p.d_coef, p.w // 8, p.n // 64)
-
-    def _quant(self, p):
-        self.ctx.quantize(p.d_coef, p.d_levels, None, p.n, 64, self.dc_q, self.ac_q, 0)
-
-    def _dequant(self, p):
-        self.ctx.dequantize(p.d_levels, p.d_dq, p.n, 64, self.dc_q, self.ac_q, 0, self.bd)
-
-    def _inv(self, p):
-        self.ctx.inv_txfm_add_grid(TX_8X8, p.d_dq, p.d_pred, p.w, self.bd, p.w // 8, p.n // 64)
+        return ("%dx%d %d-bit 4:2:0 intra-only (all key frames), tile = 64x64 superblock, %dx%d blocks: intra prediction "
+                "(11 modes, SAD decision) + fwd DCT + quant + dequant + inv DCT + recon fused, then deblocking (level %d); "
+                "CDEF / loop restoration / entropy coding not in the loop yet"
+                % (self.width, self.height, self.bd, self.bs, self.bs, self.lf_level))
 
     def step(self):
-        for p in self.planes:
-            self._pred(p)
-            self._fwd(p)
-            self._quant(p)
-            self._dequant(p)
-            self._inv(p)
+        c, d = self.ctx, self.d
+        w, h, f = self.width, self.height, self.frames
+        c.intra_encode(self.job)
+        c.deblock_frames(d["rec_y"], w, d["dbl_y"], w, w, h, self.bd, 0, d["mi_y"], w // 4, 0, 0, f)
+        c.deblock_frames(d["rec_u"], w // 2, d["dbl_u"], w // 2, w // 2, h // 2, self.bd, 1, d["mi_c"], w // 8, 0, 0, f)
+        c.deblock_frames(d["rec_v"], w // 2, d["dbl_v"], w // 2, w // 2, h // 2, self.bd, 1, d["mi_c"], w // 8, 0, 0, f)
 
-    # ---- measurement
-    def _time(self, fn, reps=10):
-        p = self.planes[0]
-        fn(p)
-        self.ctx.sync()
-        self.ctx.timer_begin()
-        for _ in range(reps):
-            fn(p)
-        return self.ctx.timer_end() / reps
+    def algorithmic_bytes(self):
+        """per LAUNCH, by kernel kind: the fused coding kernel reads the source (b) and writes the
+        reconstruction (b) and the int16 levels (2); deblocking reads and writes a plane (2b)."""
+        b = self.bps
+        return {"intra_pipeline": (2 * b + 2) * self.samples, "deblock": 2 * b * self.samples / 3.0}
 
-    def stage_times(self):
-        """ms per launch on the luma plane of the segment (HIP events on the pipeline's stream)."""
-        fns = (self._fwd, self._quant, self._dequant, self._inv)
-        return {name: self._time(fn) for name, fn in zip(self.STAGES, fns)}
-
-    def roofline(self, peak_gbps):
-        b = self.planes[0].bps
-        S = self.planes[0].n
-        alg = {self.STAGES[0]: 6 * S, self.STAGES[1]: 6 * S, self.STAGES[2]: 6 * S, self.STAGES[3]: (4 + 2 * b) * S}
-        times = self.stage_times()
-        dom = max(times, key=times.get)
-        ach = alg[dom] / (times[dom] * 1e-3) / 1e9
-        return {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": peak_gbps, "unit": "GB/s", "frac": ach / peak_gbps,
-                "traffic": None, "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": times[dom],
-                "samples_per_launch": S}
+    def download(self):
+        d, (Y, U, V) = self.d, self.src
+        dt = Y.dtype
+        return dict(rec_y=d["rec_y"].download(Y.shape, dt), dbl_y=d["dbl_y"].download(Y.shape, dt),
+                    dbl_u=d["dbl_u"].download(U.shape, dt), dbl_v=d["dbl_v"].download(V.shape, dt),
+                    modes_y=d["modes_y"].download((self.frames, -1), np.uint8) if False else None)
 
     def close(self):
-        for p in self.planes:
-            p.free()
+        for b in self.d.values():
+            b.free()

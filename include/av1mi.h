@@ -146,6 +146,12 @@ int av1mi_intra_pred_list(av1mi_ctx *ctx, int tx_size, const void *d_ref, int re
 int av1mi_deblock_plane(av1mi_ctx *ctx, const void *d_src, int src_stride, void *d_dst, int dst_stride, int w, int h,
                         int bd, int is_chroma, const uint32_t *d_mi, int mi_stride, int sharpness);
 
+/* the same over nframes frames stacked vertically in d_src / d_dst (h rows each); the mode info of frame f starts
+ * at d_mi + f * mi_frame_stride (units), mi_frame_stride 0 = one shared map. */
+int av1mi_deblock_frames(av1mi_ctx *ctx, const void *d_src, int src_stride, void *d_dst, int dst_stride, int w, int h,
+                         int bd, int is_chroma, const uint32_t *d_mi, int mi_stride, size_t mi_frame_stride, int sharpness,
+                         int nframes);
+
 /* ---- the intra-only segment pipeline (BASELINE config 2): what stands in for the encode the reference delegates
  * to `ffmpeg -c:v:0 av1_vaapi` (transcode.go:120) for key frames.  One launch codes `nframes` frames that are
  * stacked in the plane buffers (frame f starts at row f*height of the luma planes, f*height/2 of the chroma planes).
