@@ -35,6 +35,11 @@ INTRA_BLK_DTYPE = np.dtype([("x", "<u2"), ("y", "<u2"), ("mode", "u1"), ("angle_
                             ("reserved", "u1", (5,))])
 assert INTRA_BLK_DTYPE.itemsize == 16 and TXB_DTYPE.itemsize == 16
 
+MC_BLK_DTYPE = np.dtype([("x", "<u2"), ("y", "<u2"), ("mvx", "<i2"), ("mvy", "<i2"), ("filt_x", "u1"), ("filt_y", "u1"),
+                         ("reserved", "u1", (6,))])
+assert MC_BLK_DTYPE.itemsize == 16
+
+
 class IntraJob(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("bit_depth", C.c_int), ("nframes", C.c_int), ("qindex", C.c_int),
                 ("block_size", C.c_int), ("stride_y", C.c_int), ("stride_uv", C.c_int),
@@ -183,6 +188,11 @@ class Context:
     def intra_pred_list(self, tx_size, d_ref, ref_stride, d_dst, dst_stride, bd, d_list, nblocks):
         self._chk(self.lib.av1mi_intra_pred_list(self.h, tx_size, C.c_void_p(d_ref.ptr), ref_stride, C.c_void_p(d_dst.ptr),
                                                  dst_stride, bd, C.c_void_p(d_list.ptr), nblocks))
+
+    # ---- K4
+    def mc_list(self, size_id, d_ref, ref_stride, plane_w, plane_h, d_dst, dst_stride, bd, d_list, nblocks):
+        self._chk(self.lib.av1mi_mc_list(self.h, size_id, C.c_void_p(d_ref.ptr), ref_stride, plane_w, plane_h, C.c_void_p(d_dst.ptr),
+                                         dst_stride, bd, C.c_void_p(d_list.ptr), nblocks))
 
     # ---- K5
     def deblock_plane(self, d_src, src_stride, d_dst, dst_stride, w, h, bd, is_chroma, d_mi, mi_stride, sharpness):

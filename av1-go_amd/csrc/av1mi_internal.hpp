@@ -44,6 +44,14 @@ struct IntraPipeLaunch {
 };
 hipError_t launch_intra_pipe(const IntraPipeLaunch &L, int bs, hipStream_t s);
 
+// K4: a list of equally-sized blocks predicted from `ref` into `dst`
+struct McLaunch {
+  const void *ref; void *dst;
+  int ref_stride, dst_stride, plane_w, plane_h, bd, nblocks;
+  const av1mi_mc_blk *blocks;
+};
+hipError_t launch_mc(int size_id, const McLaunch &L, hipStream_t s);
+
 int tx_width(int tx_size);
 int tx_height(int tx_size);
 hipError_t launch_inv_txfm(int tx_size, const TxLaunch &L, int bd, hipStream_t s);

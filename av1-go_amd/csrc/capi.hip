@@ -290,6 +290,20 @@ int av1mi_intra_pred_list(av1mi_ctx *ctx, int tx_size, const void *d_ref, int re
   return AV1MI_OK;
 }
 
+int av1mi_mc_list(av1mi_ctx *ctx, int size_id, const void *d_ref, int ref_stride, int plane_w, int plane_h, void *d_dst,
+                  int dst_stride, int bd, const av1mi_mc_blk *d_list, int nblocks) {
+  BIND(ctx);
+  if (size_id < 0 || size_id >= AV1MI_TX_SIZES_ALL) return fail(ctx, AV1MI_E_INVAL, "size_id %d out of range", size_id);
+  if (!d_ref || !d_dst || !d_list || d_ref == d_dst) return fail(ctx, AV1MI_E_INVAL, "null or aliased device pointer");
+  if (bd != 8 && bd != 10) return fail(ctx, AV1MI_E_INVAL, "bit depth %d not supported (8 or 10)", bd);
+  if (nblocks < 0 || plane_w <= 0 || plane_h <= 0 || ref_stride < plane_w || dst_stride <= 0 || (dst_stride & 3))
+    return fail(ctx, AV1MI_E_INVAL, "bad geometry");
+  if ((uintptr_t)d_dst & 7) return fail(ctx, AV1MI_E_INVAL, "misaligned device pointer");
+  av1mi::McLaunch L = { d_ref, d_dst, ref_stride, dst_stride, plane_w, plane_h, bd, nblocks, d_list };
+  { ProfScope ps(ctx, AV1MI_K_MC); HIP_TRY(ctx, av1mi::launch_mc(size_id, L, ctx->stream)); }
+  return AV1MI_OK;
+}
+
 int av1mi_deblock_frames(av1mi_ctx *ctx, const void *d_src, int src_stride, void *d_dst, int dst_stride, int w, int h,
                          int bd, int is_chroma, const uint32_t *d_mi, int mi_stride, size_t mi_frame_stride, int sharpness,
                          int nframes) {

@@ -136,6 +136,20 @@ typedef struct av1mi_intra_blk {
 int av1mi_intra_pred_list(av1mi_ctx *ctx, int tx_size, const void *d_ref, int ref_stride, void *d_dst, int dst_stride,
                           int bd, const av1mi_intra_blk *d_list, int nblocks);
 
+/* ---- K4: sub-pel motion compensation (AV1 spec §7.11.3.4; single reference, unscaled, no compound) of a list
+ * of blocks of one size.  size_id uses the TX_SIZE numbering for w x h (0 4x4 .. 4 64x64, 5 4x8 ...).  Each block
+ * at (x, y) of the plane (x multiple of 4) is predicted from d_ref displaced by (mvx, mvy) in 1/16-sample units of
+ * THIS plane; reference coordinates are clamped to [0, plane_w-1] x [0, plane_h-1].  filt_x / filt_y: 0 regular,
+ * 1 smooth, 2 sharp, 3 bilinear (dimensions <= 4 switch to the 4-tap variants as the spec does). */
+typedef struct av1mi_mc_blk {
+  uint16_t x, y;
+  int16_t mvx, mvy;
+  uint8_t filt_x, filt_y;
+  uint8_t reserved[6];
+} av1mi_mc_blk;
+int av1mi_mc_list(av1mi_ctx *ctx, int size_id, const void *d_ref, int ref_stride, int plane_w, int plane_h, void *d_dst,
+                  int dst_stride, int bd, const av1mi_mc_blk *d_list, int nblocks);
+
 /* ---- K5: deblocking loop filter of one plane (AV1 spec §7.14), both passes in one launch, d_src -> d_dst
  * (different allocations; w, h multiples of 4; strides in samples, multiples of 4).
  * d_mi: (h/4) x (w/4) mode-info units of the PLANE (already subsampled for chroma), one uint32 each:

@@ -215,3 +215,19 @@ def intra_encode_frame(Y, U, V, bd, bs, qindex):
     if rc:
         raise ValueError("av1o_intra_encode_frame rc=%d" % rc)
     return out
+
+
+def subpel_filters():
+    arr = (C.c_int16 * (6 * 16 * 8)).in_dll(lib(), "av1o_subpel_filters")
+    return np.frombuffer(arr, np.int16).reshape(6, 16, 8).copy()
+
+
+def mc_block(ref, bd, x, y, w, h, mvx, mvy, filt_x=0, filt_y=0):
+    dt = np.uint8 if bd == 8 else np.uint16
+    ref = np.ascontiguousarray(ref, dt)
+    pred = np.zeros((h, w), np.uint16)
+    rc = lib().av1o_mc_block(ref.ctypes.data_as(C.c_void_p), ref.shape[1], ref.shape[1], ref.shape[0], bd, x, y, w, h, mvx, mvy,
+                             filt_x, filt_y, _p(pred, C.c_uint16))
+    if rc:
+        raise ValueError("av1o_mc_block rc=%d" % rc)
+    return pred
