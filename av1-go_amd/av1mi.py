@@ -40,6 +40,15 @@ MC_BLK_DTYPE = np.dtype([("x", "<u2"), ("y", "<u2"), ("mvx", "<i2"), ("mvy", "<i
 assert MC_BLK_DTYPE.itemsize == 16
 
 
+class CdefJob(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("bit_depth", C.c_int), ("nframes", C.c_int), ("damping", C.c_int),
+                ("stride_y", C.c_int), ("stride_uv", C.c_int),
+                ("d_src_y", C.c_void_p), ("d_src_u", C.c_void_p), ("d_src_v", C.c_void_p),
+                ("d_dst_y", C.c_void_p), ("d_dst_u", C.c_void_p), ("d_dst_v", C.c_void_p),
+                ("d_sb_strength", C.c_void_p), ("sb_frame_stride", C.c_size_t),
+                ("d_skip8", C.c_void_p), ("skip_frame_stride", C.c_size_t)]
+
+
 class IntraJob(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("bit_depth", C.c_int), ("nframes", C.c_int), ("qindex", C.c_int),
                 ("block_size", C.c_int), ("stride_y", C.c_int), ("stride_uv", C.c_int),
@@ -220,6 +229,26 @@ class Context:
             self._chk(self.lib.av1mi_prof_get(self.h, k, C.byref(n), C.byref(ms)))
             if n.value:
                 out[self.lib.av1mi_kernel_kind_name(k).decode()] = (n.value, ms.value)
+        return out
+
+    # ---- K6
+    def cdef_frames(self, job):
+        self._chk(self.lib.av1mi_cdef_frames(self.h, C.byref(job)))
+
+    def cdef_arrays(self, Y, U, V, bd, damping, sb_strength, skip8):
+        """tests: Y/U/V [frames,h,w]; sb_strength [frames or 1, nsb, 4]; skip8 [frames or 1, h/8, w/8]"""
+        dt = np.uint8 if bd == 8 else np.uint16
+        Y, U, V = (np.ascontiguousarray(a, dt) for a in (Y, U, V))
+        nf, h, w = Y.shape
+        sb_strength = np.ascontiguousarray(sb_strength, np.uint8); skip8 = np.ascontiguousarray(skip8, np.uint8)
+        bufs = [self.to_device(a) for a in (Y, U, V)] + [self.alloc(a.nbytes) for a in (Y, U, V)] + [self.to_device(sb_strength), self.to_device(skip8)]
+        job = CdefJob(w, h, bd, nf, damping, w, w // 2, *[b.ptr for b in bufs[:6]], bufs[6].ptr,
+                      0 if sb_strength.shape[0] == 1 else sb_strength.shape[1], bufs[7].ptr,
+                      0 if skip8.shape[0] == 1 else skip8.shape[1] * skip8.shape[2])
+        self.cdef_frames(job)
+        out = (bufs[3].download(Y.shape, dt), bufs[4].download(U.shape, dt), bufs[5].download(V.shape, dt))
+        for b in bufs:
+            b.free()
         return out
 
     # ---- fused intra-only segment pipeline

@@ -52,6 +52,15 @@ struct McLaunch {
 };
 hipError_t launch_mc(int size_id, const McLaunch &L, hipStream_t s);
 
+// K6: CDEF of 4:2:0 frames stacked vertically
+struct CdefLaunch {
+  const void *src[3]; void *dst[3];
+  int w, h, stride_y, stride_uv, bd, damping, nframes;
+  const uint8_t *sb_strength; size_t sb_frame_stride;   // 4 bytes per 64x64; entries between frames (0 = shared)
+  const uint8_t *skip8; size_t skip_frame_stride;       // 1 byte per 8x8 luma block; bytes between frames (0 = shared)
+};
+hipError_t launch_cdef(const CdefLaunch &L, hipStream_t s);
+
 int tx_width(int tx_size);
 int tx_height(int tx_size);
 hipError_t launch_inv_txfm(int tx_size, const TxLaunch &L, int bd, hipStream_t s);

@@ -327,6 +327,28 @@ int av1mi_deblock_plane(av1mi_ctx *ctx, const void *d_src, int src_stride, void 
   return av1mi_deblock_frames(ctx, d_src, src_stride, d_dst, dst_stride, w, h, bd, is_chroma, d_mi, mi_stride, 0, sharpness, 1);
 }
 
+int av1mi_cdef_frames(av1mi_ctx *ctx, const av1mi_cdef_job *j) {
+  BIND(ctx);
+  if (!j) return fail(ctx, AV1MI_E_INVAL, "null job");
+  if (j->bit_depth != 8 && j->bit_depth != 10) return fail(ctx, AV1MI_E_INVAL, "bit depth %d not supported (8 or 10)", j->bit_depth);
+  if (j->width <= 0 || j->height <= 0 || (j->width & 7) || (j->height & 7)) return fail(ctx, AV1MI_E_INVAL, "frame %dx%d must be a multiple of 8", j->width, j->height);
+  if (j->damping < 3 || j->damping > 6 || j->nframes < 0 || j->nframes > 65535) return fail(ctx, AV1MI_E_INVAL, "bad damping/nframes");
+  if (j->stride_y < j->width || j->stride_uv < j->width / 2 || (j->stride_y & 3) || (j->stride_uv & 3)) return fail(ctx, AV1MI_E_INVAL, "bad strides");
+  const void *ptrs[] = { j->d_src_y, j->d_src_u, j->d_src_v, j->d_dst_y, j->d_dst_u, j->d_dst_v };
+  for (const void *p : ptrs) if (!p || ((uintptr_t)p & 7)) return fail(ctx, AV1MI_E_INVAL, "null or misaligned device pointer");
+  if (!j->d_sb_strength || !j->d_skip8) return fail(ctx, AV1MI_E_INVAL, "null map pointer");
+  if (j->d_src_y == j->d_dst_y || j->d_src_u == j->d_dst_u || j->d_src_v == j->d_dst_v) return fail(ctx, AV1MI_E_INVAL, "CDEF cannot run in place");
+  if (j->nframes == 0) return AV1MI_OK;
+  av1mi::CdefLaunch L;
+  L.src[0] = j->d_src_y; L.src[1] = j->d_src_u; L.src[2] = j->d_src_v;
+  L.dst[0] = j->d_dst_y; L.dst[1] = j->d_dst_u; L.dst[2] = j->d_dst_v;
+  L.w = j->width; L.h = j->height; L.stride_y = j->stride_y; L.stride_uv = j->stride_uv; L.bd = j->bit_depth; L.damping = j->damping;
+  L.nframes = j->nframes; L.sb_strength = j->d_sb_strength; L.sb_frame_stride = j->sb_frame_stride;
+  L.skip8 = j->d_skip8; L.skip_frame_stride = j->skip_frame_stride;
+  { ProfScope ps(ctx, AV1MI_K_CDEF); HIP_TRY(ctx, av1mi::launch_cdef(L, ctx->stream)); }
+  return AV1MI_OK;
+}
+
 int av1mi_intra_encode(av1mi_ctx *ctx, const av1mi_intra_job *j) {
   BIND(ctx);
   if (!j) return fail(ctx, AV1MI_E_INVAL, "null job");

@@ -1,0 +1,184 @@
+// cdef_kernel.hip — SURVEY.md §8a row K6: CDEF of 4:2:0 frames, one 64x64 luma superblock (+ its 32x32 U and V
+// blocks) per workgroup, frames of a segment along blockIdx.z.
+//
+// The workgroup stages the deblocked luma block with a 2-sample halo (and both chroma blocks likewise) in LDS as
+// uint16, samples outside the picture stored as 0xFFFF = "not available" (taps skip them, as the spec's
+// CdefAvailable).  Wave 0 then runs the direction search, one 8x8 block per lane with every bin index a
+// compile-time constant; afterwards all 256 lanes filter: 16 luma + 8 chroma samples each, 12 taps per sample
+// read from LDS.  Output goes to separate planes, so taps never see filtered samples and superblocks are
+// independent.  HBM traffic: b*S read + b*S written (= 2b*S of SURVEY.md §8d); halo re-reads hit L2.
+//
+// Restates AV1 spec §7.15 and libaom cdef_find_dir_c / cdef_filter_block_c / constrain(); the reference has no
+// counterpart (internal/ffmpeg/transcode.go:120).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "av1mi_internal.hpp"
+
+namespace av1mi {
+
+__device__ constexpr int8_t kCdefDir[8][2][2] = {
+  { { -1, 1 }, { -2, 2 } }, { { 0, 1 }, { -1, 2 } }, { { 0, 1 }, { 0, 2 } }, { { 0, 1 }, { 1, 2 } },
+  { { 1, 1 }, { 2, 2 } },   { { 1, 0 }, { 2, 1 } },  { { 1, 0 }, { 2, 0 } }, { { 1, 0 }, { 2, -1 } } };
+
+__device__ __forceinline__ int msb(unsigned v) { return 31 - __clz(v); }
+__device__ __forceinline__ int cdef_constrain(int diff, int threshold, int shift) {
+  const int mag = abs(diff);
+  const int v = min(mag, max(0, threshold - (mag >> shift)));
+  return diff < 0 ? -v : v;
+}
+
+// one sample: p = centre pointer in an LDS tile with row stride LS
+template <int LS>
+__device__ __forceinline__ int cdef_sample(const uint16_t *p, int pri, int sec, int damping, int dir, int cs) {
+  const int x = *p;
+  int sum = 0, mx = x, mn = x;
+  const int pshift = pri ? max(0, damping - msb(pri)) : 0, sshift = sec ? max(0, damping - msb(sec)) : 0;
+  const int pt0 = ((pri >> cs) & 1) ? 3 : 4, pt1 = ((pri >> cs) & 1) ? 3 : 2;
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const int o0 = kCdefDir[dir][k][0] * LS + kCdefDir[dir][k][1];
+    const int o1 = kCdefDir[(dir + 2) & 7][k][0] * LS + kCdefDir[(dir + 2) & 7][k][1];
+    const int o2 = kCdefDir[(dir + 6) & 7][k][0] * LS + kCdefDir[(dir + 6) & 7][k][1];
+    const int ptap = k ? pt1 : pt0, stap = k ? 1 : 2;
+#pragma unroll
+    for (int sg = 0; sg < 2; sg++) {
+      const int a = sg ? p[o0] : p[-o0], b = sg ? p[o1] : p[-o1], c = sg ? p[o2] : p[-o2];
+      if (a != 0xFFFF) { if (pri) sum += ptap * cdef_constrain(a - x, pri, pshift); mx = max(mx, a); mn = min(mn, a); }
+      if (b != 0xFFFF) { if (sec) sum += stap * cdef_constrain(b - x, sec, sshift); mx = max(mx, b); mn = min(mn, b); }
+      if (c != 0xFFFF) { if (sec) sum += stap * cdef_constrain(c - x, sec, sshift); mx = max(mx, c); mn = min(mn, c); }
+    }
+  }
+  return min(max(x + ((8 + sum - (sum < 0)) >> 4), mn), mx);
+}
+
+template <typename Pix>
+__global__ __launch_bounds__(256) void k_cdef(CdefLaunch L) {
+  constexpr int YS = 64 + 4 + 2, CSZ = 32 + 4 + 2;   // LDS row strides (halo 2 each side, +2 pad)
+  __shared__ uint16_t ty[(64 + 4) * YS];
+  __shared__ uint16_t tc[2][(32 + 4) * CSZ];
+  __shared__ uint8_t bdir[64];
+  __shared__ int bvar[64];
+  const int tid = threadIdx.x;
+  const int sbx = blockIdx.x, sby = blockIdx.y, f = blockIdx.z;
+  const int bd = L.bd, cs = bd - 8;
+  const Pix *sy = reinterpret_cast<const Pix *>(L.src[0]) + (size_t)f * L.h * L.stride_y;
+  Pix *dy = reinterpret_cast<Pix *>(L.dst[0]) + (size_t)f * L.h * L.stride_y;
+  const int cw = L.w / 2, chh = L.h / 2;
+  // stage luma 68x68 and chroma 36x36 x2
+  for (int i = tid; i < 68 * 68; i += 256) {
+    const int r = i / 68, c = i - r * 68;
+    const int fy = sby * 64 - 2 + r, fx = sbx * 64 - 2 + c;
+    ty[r * YS + c] = (fy >= 0 && fy < L.h && fx >= 0 && fx < L.w) ? (uint16_t)sy[(size_t)fy * L.stride_y + fx] : (uint16_t)0xFFFF;
+  }
+  for (int i = tid; i < 2 * 36 * 36; i += 256) {
+    const int pl = i / (36 * 36), j = i - pl * 36 * 36, r = j / 36, c = j - r * 36;
+    const int fy = sby * 32 - 2 + r, fx = sbx * 32 - 2 + c;
+    const Pix *sc = reinterpret_cast<const Pix *>(L.src[1 + pl]) + (size_t)f * chh * L.stride_uv;
+    tc[pl][r * CSZ + c] = (fy >= 0 && fy < chh && fx >= 0 && fx < cw) ? (uint16_t)sc[(size_t)fy * L.stride_uv + fx] : (uint16_t)0xFFFF;
+  }
+  __syncthreads();
+  const int sbw = (L.w + 63) / 64;
+  const uint8_t *st = L.sb_strength + ((size_t)f * L.sb_frame_stride + (size_t)sby * sbw + sbx) * 4;
+  const bool enabled = st[0] != 255;
+  // direction search: lane b of wave 0 owns 8x8 block b (raster within the superblock)
+  if (tid < 64 && enabled) {
+    const int by = tid >> 3, bx = tid & 7;
+    if (sby * 64 + by * 8 < L.h && sbx * 64 + bx * 8 < L.w) {
+      const uint16_t *p = ty + (2 + by * 8) * YS + 2 + bx * 8;
+      int partial[8][15];
+#pragma unroll
+      for (int d = 0; d < 8; d++)
+#pragma unroll
+        for (int k = 0; k < 15; k++) partial[d][k] = 0;
+#pragma unroll
+      for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          const int x = (p[i * YS + j] >> cs) - 128;
+          partial[0][i + j] += x; partial[1][i + j / 2] += x; partial[2][i] += x; partial[3][3 + i - j / 2] += x;
+          partial[4][7 + i - j] += x; partial[5][3 - i / 2 + j] += x; partial[6][j] += x; partial[7][i / 2 + j] += x;
+        }
+      constexpr int div_table[9] = { 0, 840, 420, 280, 210, 168, 140, 120, 105 };
+      int cost[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+#pragma unroll
+      for (int i = 0; i < 8; i++) { cost[2] += partial[2][i] * partial[2][i]; cost[6] += partial[6][i] * partial[6][i]; }
+      cost[2] *= 105; cost[6] *= 105;
+#pragma unroll
+      for (int i = 0; i < 7; i++) {
+        cost[0] += (partial[0][i] * partial[0][i] + partial[0][14 - i] * partial[0][14 - i]) * div_table[i + 1];
+        cost[4] += (partial[4][i] * partial[4][i] + partial[4][14 - i] * partial[4][14 - i]) * div_table[i + 1];
+      }
+      cost[0] += partial[0][7] * partial[0][7] * 105;
+      cost[4] += partial[4][7] * partial[4][7] * 105;
+#pragma unroll
+      for (int i = 1; i < 8; i += 2) {
+#pragma unroll
+        for (int j = 0; j < 5; j++) cost[i] += partial[i][3 + j] * partial[i][3 + j];
+        cost[i] *= 105;
+#pragma unroll
+        for (int j = 0; j < 3; j++) cost[i] += (partial[i][j] * partial[i][j] + partial[i][10 - j] * partial[i][10 - j]) * div_table[2 * j + 2];
+      }
+      int best = 0, best_cost = 0;
+#pragma unroll
+      for (int i = 0; i < 8; i++) if (cost[i] > best_cost) { best_cost = cost[i]; best = i; }
+      int opp = 0;
+#pragma unroll
+      for (int i = 0; i < 8; i++) if (i == ((best + 4) & 7)) opp = cost[i];
+      bdir[tid] = (uint8_t)best;
+      bvar[tid] = (best_cost - opp) >> 10;
+    }
+  }
+  __syncthreads();
+  // filter: luma 64x64 -> 16 samples per lane (4 rows x 4 columns), chroma 2 x 32x32 -> 2 x 4 samples per lane
+  const int ypri0 = st[0] << cs, ysec = (st[1] == 3 ? 4 : st[1]) << cs;
+  const int upri = st[2] << cs, usec = (st[3] == 3 ? 4 : st[3]) << cs;
+  const uint8_t *skip8 = L.skip8 + (size_t)f * L.skip_frame_stride;
+  for (int q = tid; q < 64 * 16; q += 256) {         // q -> (row, group of 4 columns)
+    const int r = q >> 4, c = (q & 15) * 4;
+    const int fy = sby * 64 + r, fx = sbx * 64 + c;
+    if (fy >= L.h || fx >= L.w) continue;
+    const int b = (r >> 3) * 8 + (c >> 3);
+    const bool skip = !enabled || skip8[(size_t)(fy >> 3) * (L.w >> 3) + (fx >> 3)];
+    const uint16_t *p = ty + (2 + r) * YS + 2 + c;
+    int o[4];
+    if (skip) { o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; o[3] = p[3]; }
+    else {
+      const int var = bvar[b];
+      const int vs = (var >> 6) ? min(msb((unsigned)(var >> 6)), 12) : 0;
+      const int pri = var ? (ypri0 * (4 + vs) + 8) >> 4 : 0;
+      const int dir = ypri0 == 0 ? 0 : bdir[b];
+#pragma unroll
+      for (int k = 0; k < 4; k++) o[k] = cdef_sample<YS>(p + k, pri, ysec, L.damping + cs, dir, cs);
+    }
+    Pix *d = dy + (size_t)fy * L.stride_y + fx;
+    if constexpr (sizeof(Pix) == 1) *reinterpret_cast<uint32_t *>(d) = (uint32_t)o[0] | ((uint32_t)o[1] << 8) | ((uint32_t)o[2] << 16) | ((uint32_t)o[3] << 24);
+    else { uint2 u; u.x = (uint32_t)o[0] | ((uint32_t)o[1] << 16); u.y = (uint32_t)o[2] | ((uint32_t)o[3] << 16); *reinterpret_cast<uint2 *>(d) = u; }
+  }
+  for (int q = tid; q < 2 * 32 * 8; q += 256) {
+    const int pl = q >> 8, r = (q >> 3) & 31, c = (q & 7) * 4;
+    const int fy = sby * 32 + r, fx = sbx * 32 + c;
+    if (fy >= chh || fx >= cw) continue;
+    const int b = (r >> 2) * 8 + (c >> 2);
+    const bool skip = !enabled || skip8[(size_t)(fy >> 2) * (L.w >> 3) + (fx >> 2)];
+    const uint16_t *p = tc[pl] + (2 + r) * CSZ + 2 + c;
+    int o[4];
+    if (skip) { o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; o[3] = p[3]; }
+    else {
+      const int dir = upri == 0 ? 0 : bdir[b];
+#pragma unroll
+      for (int k = 0; k < 4; k++) o[k] = cdef_sample<CSZ>(p + k, upri, usec, L.damping + cs - 1, dir, cs);
+    }
+    Pix *d = reinterpret_cast<Pix *>(L.dst[1 + pl]) + (size_t)f * chh * L.stride_uv + (size_t)fy * L.stride_uv + fx;
+    if constexpr (sizeof(Pix) == 1) *reinterpret_cast<uint32_t *>(d) = (uint32_t)o[0] | ((uint32_t)o[1] << 8) | ((uint32_t)o[2] << 16) | ((uint32_t)o[3] << 24);
+    else { uint2 u; u.x = (uint32_t)o[0] | ((uint32_t)o[1] << 16); u.y = (uint32_t)o[2] | ((uint32_t)o[3] << 16); *reinterpret_cast<uint2 *>(d) = u; }
+  }
+}
+
+hipError_t launch_cdef(const CdefLaunch &L, hipStream_t s) {
+  const dim3 grid((L.w + 63) / 64, (L.h + 63) / 64, L.nframes);
+  if (L.bd == 8) hipLaunchKernelGGL(k_cdef<uint8_t>, grid, dim3(256), 0, s, L);
+  else hipLaunchKernelGGL(k_cdef<uint16_t>, grid, dim3(256), 0, s, L);
+  return hipGetLastError();
+}
+
+}  // namespace av1mi

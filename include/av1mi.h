@@ -166,6 +166,21 @@ int av1mi_deblock_frames(av1mi_ctx *ctx, const void *d_src, int src_stride, void
                          int bd, int is_chroma, const uint32_t *d_mi, int mi_stride, size_t mi_frame_stride, int sharpness,
                          int nframes);
 
+/* ---- K6: CDEF (AV1 spec §7.15) of nframes 4:2:0 frames stacked vertically; deblocked planes in, separate planes out.
+ * width/height: luma size, multiples of 8.  d_sb_strength: 4 bytes per 64x64 luma block in raster order
+ * {y_pri 0..15, y_sec 0..3, uv_pri, uv_sec}; y_pri = 255 switches CDEF off for that block.  d_skip8: one byte per
+ * 8x8 luma block, 1 = all of its mode-info units are skipped (block left untouched).  damping 3..6.
+ * sb_frame_stride (entries) / skip_frame_stride (bytes) separate the per-frame maps; 0 = one map shared by all frames. */
+typedef struct av1mi_cdef_job {
+  int width, height, bit_depth, nframes, damping;
+  int stride_y, stride_uv;
+  const void *d_src_y, *d_src_u, *d_src_v;
+  void *d_dst_y, *d_dst_u, *d_dst_v;
+  const uint8_t *d_sb_strength; size_t sb_frame_stride;
+  const uint8_t *d_skip8; size_t skip_frame_stride;
+} av1mi_cdef_job;
+int av1mi_cdef_frames(av1mi_ctx *ctx, const av1mi_cdef_job *job);
+
 /* ---- the intra-only segment pipeline (BASELINE config 2): what stands in for the encode the reference delegates
  * to `ffmpeg -c:v:0 av1_vaapi` (transcode.go:120) for key frames.  One launch codes `nframes` frames that are
  * stacked in the plane buffers (frame f starts at row f*height of the luma planes, f*height/2 of the chroma planes).

@@ -231,3 +231,26 @@ def mc_block(ref, bd, x, y, w, h, mvx, mvy, filt_x=0, filt_y=0):
     if rc:
         raise ValueError("av1o_mc_block rc=%d" % rc)
     return pred
+
+
+def cdef_find_dir(block, bd):
+    dt = np.uint8 if bd == 8 else np.uint16
+    block = np.ascontiguousarray(block, dt)
+    var = C.c_int()
+    d = lib().av1o_cdef_find_dir(block.ctypes.data_as(C.c_void_p), block.shape[1], bd, C.byref(var))
+    return d, var.value
+
+
+def cdef_frame(Y, U, V, bd, damping, sb_strength, skip8):
+    """sb_strength: [nsb, 4] uint8; skip8: [h/8, w/8] uint8; returns filtered (Y, U, V)"""
+    dt = np.uint8 if bd == 8 else np.uint16
+    Y, U, V = (np.ascontiguousarray(a, dt) for a in (Y, U, V))
+    oy, ou, ov = np.zeros_like(Y), np.zeros_like(U), np.zeros_like(V)
+    sb = np.ascontiguousarray(sb_strength, np.uint8)
+    sk = np.ascontiguousarray(skip8, np.uint8)
+    h, w = Y.shape
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    rc = lib().av1o_cdef_frame(vp(Y), vp(U), vp(V), vp(oy), vp(ou), vp(ov), w, h, w, w // 2, bd, damping, vp(sb), vp(sk))
+    if rc:
+        raise ValueError("av1o_cdef_frame rc=%d" % rc)
+    return oy, ou, ov
