@@ -251,6 +251,11 @@ class Context:
             b.free()
         return out
 
+    # ---- K7
+    def lr_frames(self, d_cdef, d_dbl, d_out, stride, w, h, bd, ss, unit_size, d_units, unit_frame_stride, nframes):
+        self._chk(self.lib.av1mi_lr_frames(self.h, C.c_void_p(d_cdef.ptr), C.c_void_p(d_dbl.ptr), C.c_void_p(d_out.ptr), stride, w, h, bd,
+                                           int(ss), unit_size, C.c_void_p(d_units.ptr), C.c_size_t(unit_frame_stride), nframes))
+
     # ---- fused intra-only segment pipeline
     def intra_encode(self, job):
         self._chk(self.lib.av1mi_intra_encode(self.h, C.byref(job)))

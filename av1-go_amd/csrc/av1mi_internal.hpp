@@ -61,6 +61,14 @@ struct CdefLaunch {
 };
 hipError_t launch_cdef(const CdefLaunch &L, hipStream_t s);
 
+// K7: loop restoration of one plane, frames stacked vertically
+struct LrLaunch {
+  const void *cdef, *dbl; void *out;
+  int stride, w, h, bd, ss, unit_size, nframes;
+  const int8_t *units; size_t unit_frame_stride;   // 8 bytes per unit; units between frames (0 = shared)
+};
+hipError_t launch_lr(const LrLaunch &L, hipStream_t s);
+
 int tx_width(int tx_size);
 int tx_height(int tx_size);
 hipError_t launch_inv_txfm(int tx_size, const TxLaunch &L, int bd, hipStream_t s);

@@ -349,6 +349,22 @@ int av1mi_cdef_frames(av1mi_ctx *ctx, const av1mi_cdef_job *j) {
   return AV1MI_OK;
 }
 
+int av1mi_lr_frames(av1mi_ctx *ctx, const void *d_cdef, const void *d_deblocked, void *d_out, int stride, int w, int h,
+                    int bd, int subsampled, int unit_size, const int8_t *d_units, size_t unit_frame_stride, int nframes) {
+  BIND(ctx);
+  if (!d_cdef || !d_deblocked || !d_out || !d_units || d_out == d_cdef || d_out == d_deblocked)
+    return fail(ctx, AV1MI_E_INVAL, "null or aliased device pointer");
+  if (bd != 8 && bd != 10) return fail(ctx, AV1MI_E_INVAL, "bit depth %d not supported (8 or 10)", bd);
+  if (w <= 0 || h <= 0 || stride < w) return fail(ctx, AV1MI_E_INVAL, "bad plane geometry %dx%d stride %d", w, h, stride);
+  if (!(unit_size == 64 || unit_size == 128 || unit_size == 256 || (unit_size == 32 && subsampled)))
+    return fail(ctx, AV1MI_E_INVAL, "restoration unit size %d not allowed", unit_size);
+  if (nframes < 0 || nframes > 65535) return fail(ctx, AV1MI_E_INVAL, "nframes %d out of range", nframes);
+  if (nframes == 0) return AV1MI_OK;
+  av1mi::LrLaunch L = { d_cdef, d_deblocked, d_out, stride, w, h, bd, subsampled ? 1 : 0, unit_size, nframes, d_units, unit_frame_stride };
+  { ProfScope ps(ctx, AV1MI_K_LR); HIP_TRY(ctx, av1mi::launch_lr(L, ctx->stream)); }
+  return AV1MI_OK;
+}
+
 int av1mi_intra_encode(av1mi_ctx *ctx, const av1mi_intra_job *j) {
   BIND(ctx);
   if (!j) return fail(ctx, AV1MI_E_INVAL, "null job");

@@ -1,0 +1,168 @@
+// lr_kernel.hip — SURVEY.md §8a row K7: loop restoration (Wiener and self-guided) of one plane, frames of a
+// segment along blockIdx.z.
+//
+// A workgroup owns the intersection of one 64-row stripe (32 for 4:2:0 chroma; stripes are offset 8 luma rows
+// upwards, AV1 spec §7.17) with one column band no wider than a restoration unit, so every sample it writes has
+// the same stripe limits AND the same unit parameters: no divergence.  It stages that block plus a 3-sample halo
+// in LDS through the spec's get_source_sample rule (picture-edge clamp; up to two rows beyond the stripe come from
+// the DEBLOCKED frame, further rows replicate them; inside the stripe the CDEF output), then runs
+//   Wiener:      7-tap rows -> int16 intermediate in LDS -> 7-tap columns, rounds 3 / 11;
+//   self-guided: box sums (r = 2 on odd rows, then r = 1) -> A (u16) / B (i32) in LDS -> 3x3 weighted a*x + b,
+//                both passes kept in registers, projection with (w0, w1, 128 - w0 - w1).
+// Reads two planes, writes one: algorithmic HBM traffic 2b*S (SURVEY.md §8d counts b read + b written; the
+// deblocked rows are 4 of every 64).  Restates spec §7.17.3/4/6 and libaom av1_highbd_wiener_convolve_add_src_c /
+// av1_selfguided_restoration_c; the reference has no counterpart (internal/ffmpeg/transcode.go:120).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "av1mi_internal.hpp"
+
+namespace av1mi {
+
+__device__ constexpr int kSgrParams[16][4] = {
+  { 2, 140, 1, 3236 }, { 2, 112, 1, 2158 }, { 2, 93, 1, 1618 }, { 2, 80, 1, 1438 }, { 2, 70, 1, 1295 }, { 2, 58, 1, 1177 },
+  { 2, 47, 1, 1079 }, { 2, 37, 1, 996 }, { 2, 30, 1, 925 }, { 2, 25, 1, 863 }, { 0, -1, 1, 2589 }, { 0, -1, 1, 1618 },
+  { 0, -1, 1, 1177 }, { 0, -1, 1, 925 }, { 2, 56, 0, -1 }, { 2, 22, 0, -1 } };
+
+template <typename Pix>
+__global__ __launch_bounds__(256) void k_lr(LrLaunch L) {
+  constexpr int MAXH = 64, MAXW = 64, SS = MAXW + 6 + 2;   // source tile row stride (u16)
+  constexpr int AS = MAXW + 2 + 2;                         // A/B row stride
+  __shared__ uint16_t src[(MAXH + 6) * SS];
+  __shared__ __attribute__((aligned(16))) unsigned char scratch[(MAXH + 2) * AS * 2 + (MAXH + 2) * AS * 4];
+  int16_t *inter = reinterpret_cast<int16_t *>(scratch);                       // Wiener: (SH+6) x tw
+  uint16_t *Abuf = reinterpret_cast<uint16_t *>(scratch);                      // self-guided: (SH+2) x (tw+2)
+  int32_t *Bbuf = reinterpret_cast<int32_t *>(scratch + (MAXH + 2) * AS * 2);
+
+  const int tid = threadIdx.x, bd = L.bd, ss = L.ss;
+  const int SH = 64 >> ss, off = 8 >> ss;
+  const int tw = L.unit_size < 64 ? L.unit_size : 64;
+  const int X0 = blockIdx.x * tw, stripe = blockIdx.y, f = blockIdx.z;
+  const int sstart = stripe * SH - off, send = sstart + SH - 1;
+  const int y0 = max(sstart, 0), y1 = min(send, L.h - 1);    // rows this workgroup writes
+  if (y0 > y1 || X0 >= L.w) return;
+  const int bw = min(tw, L.w - X0), bh = y1 - y0 + 1;
+  const Pix *cdef = reinterpret_cast<const Pix *>(L.cdef) + (size_t)f * L.h * L.stride;
+  const Pix *dbl = reinterpret_cast<const Pix *>(L.dbl) + (size_t)f * L.h * L.stride;
+  Pix *out = reinterpret_cast<Pix *>(L.out) + (size_t)f * L.h * L.stride;
+  const int urows = max((L.h + (L.unit_size >> 1)) / L.unit_size, 1), ucols = max((L.w + (L.unit_size >> 1)) / L.unit_size, 1);
+  const int ur = min(urows - 1, (y0 + off) / L.unit_size), uc = min(ucols - 1, X0 / L.unit_size);
+  const int8_t *U = L.units + ((size_t)f * L.unit_frame_stride + (size_t)ur * ucols + uc) * 8;
+  const int type = U[0];
+
+  if (type == 0) {   // no restoration: copy the CDEF output
+    for (int i = tid; i < bh * bw; i += 256) {
+      const int r = i / bw, c = i - r * bw;
+      out[(size_t)(y0 + r) * L.stride + X0 + c] = cdef[(size_t)(y0 + r) * L.stride + X0 + c];
+    }
+    return;
+  }
+  // stage (bh + 6) x (bw + 6) source samples, local (0,0) == (y0 - 3, X0 - 3)
+  for (int i = tid; i < (bh + 6) * (bw + 6); i += 256) {
+    const int r = i / (bw + 6), c = i - r * (bw + 6);
+    const int x = min(max(X0 - 3 + c, 0), L.w - 1);
+    int y = min(max(y0 - 3 + r, 0), L.h - 1);
+    const Pix *p = cdef;
+    if (y < sstart) { y = max(sstart - 2, y); p = dbl; }
+    else if (y > send) { y = min(send + 2, y); p = dbl; }
+    src[r * SS + c] = p[(size_t)y * L.stride + x];
+  }
+  __syncthreads();
+  const int maxpix = (1 << bd) - 1;
+  if (type == 1) {
+    int vf[7], hf[7];
+#pragma unroll
+    for (int i = 0; i < 3; i++) { vf[i] = vf[6 - i] = U[1 + i]; hf[i] = hf[6 - i] = U[4 + i]; }
+    vf[3] = 128 - 2 * (U[1] + U[2] + U[3]);
+    hf[3] = 128 - 2 * (U[4] + U[5] + U[6]);
+    const int offset = 1 << (bd + 3), limit = (1 << (bd + 5)) - 1;
+    for (int i = tid; i < (bh + 6) * bw; i += 256) {
+      const int r = i / bw, c = i - r * bw;
+      const uint16_t *p = src + r * SS + c;
+      int s = 0;
+#pragma unroll
+      for (int t = 0; t < 7; t++) s += hf[t] * p[t];
+      inter[r * MAXW + c] = (int16_t)min(max((s + 4) >> 3, -offset), limit - offset);
+    }
+    __syncthreads();
+    for (int i = tid; i < bh * bw; i += 256) {
+      const int r = i / bw, c = i - r * bw;
+      int s = 0;
+#pragma unroll
+      for (int t = 0; t < 7; t++) s += vf[t] * inter[(r + t) * MAXW + c];
+      out[(size_t)(y0 + r) * L.stride + X0 + c] = (Pix)min(max((s + 1024) >> 11, 0), maxpix);
+    }
+    return;
+  }
+  // self-guided
+  const int set = U[1] & 15, w0 = U[2], w1 = U[3], w2 = 128 - w0 - w1;
+  int flt[2][16];   // this lane's samples: index k <-> sample tid + 256 k of the block (row-major)
+#pragma unroll
+  for (int pass = 0; pass < 2; pass++) {
+    const int r = kSgrParams[set][2 * pass], eps = kSgrParams[set][2 * pass + 1];
+    if (r == 0) continue;   // uniform across the workgroup
+    const unsigned n = (2 * r + 1) * (2 * r + 1), n2e = n * n * (unsigned)eps;
+    const unsigned sfac = ((1u << 20) + n2e / 2) / n2e, one_by_n = ((1u << 12) + n / 2) / n;
+    // A/B at local (i, j) for i in -1..bh, j in -1..bw; stored at [(i+1) * AS + (j+1)]
+    for (int q = tid; q < (bh + 2) * (bw + 2); q += 256) {
+      const int i = q / (bw + 2) - 1, j = q % (bw + 2) - 1;
+      if (pass == 0 && !((y0 + i) & 1)) continue;            // the r = 2 pass only ever reads odd rows
+      const uint16_t *p = src + (i + 3) * SS + (j + 3);
+      unsigned a = 0, b = 0;
+      for (int dy = -r; dy <= r; dy++)
+        for (int dx = -r; dx <= r; dx++) { const unsigned v = p[dy * SS + dx]; a += v * v; b += v; }
+      const unsigned as = bd == 8 ? a : (a + 8) >> 4, d = bd == 8 ? b : (b + 2) >> 2;
+      const unsigned pv = as * n > d * d ? as * n - d * d : 0;
+      const unsigned z = (unsigned)(((unsigned long long)pv * sfac + (1u << 19)) >> 20);
+      const unsigned a2 = z >= 255 ? 256 : z == 0 ? 1 : ((z << 8) + z / 2) / (z + 1);
+      Abuf[(i + 1) * AS + j + 1] = (uint16_t)a2;
+      Bbuf[(i + 1) * AS + j + 1] = (int32_t)(((256 - a2) * b * one_by_n + (1u << 11)) >> 12);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const int q = tid + 256 * k;
+      if (q >= bh * bw) continue;
+      const int i = q / bw, j = q - i * bw;
+      const uint16_t *pa = Abuf + (i + 1) * AS + j + 1;
+      const int32_t *pb = Bbuf + (i + 1) * AS + j + 1;
+      int a, b, shift = 5;
+      if (pass == 0) {
+        if ((y0 + i) & 1) {
+          a = 6 * pa[0] + 5 * (pa[-1] + pa[1]); b = 6 * pb[0] + 5 * (pb[-1] + pb[1]); shift = 4;
+        } else {
+          a = 6 * (pa[-AS] + pa[AS]) + 5 * (pa[-AS - 1] + pa[-AS + 1] + pa[AS - 1] + pa[AS + 1]);
+          b = 6 * (pb[-AS] + pb[AS]) + 5 * (pb[-AS - 1] + pb[-AS + 1] + pb[AS - 1] + pb[AS + 1]);
+        }
+      } else {
+        a = 4 * (pa[0] + pa[-1] + pa[1] + pa[-AS] + pa[AS]) + 3 * (pa[-AS - 1] + pa[-AS + 1] + pa[AS - 1] + pa[AS + 1]);
+        b = 4 * (pb[0] + pb[-1] + pb[1] + pb[-AS] + pb[AS]) + 3 * (pb[-AS - 1] + pb[-AS + 1] + pb[AS - 1] + pb[AS + 1]);
+      }
+      const int v = a * (int)src[(i + 3) * SS + j + 3] + b;
+      flt[pass][k] = (v + (1 << (shift + 3))) >> (shift + 4);   // Round2(v, SGR_BITS 8 + shift - RST_BITS 4)
+    }
+    __syncthreads();
+  }
+  const int r0 = kSgrParams[set][0], r1 = kSgrParams[set][2];
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    const int q = tid + 256 * k;
+    if (q >= bh * bw) continue;
+    const int i = q / bw, j = q - i * bw;
+    const int u = (int)src[(i + 3) * SS + j + 3] << 4;
+    int v = w1 * u;
+    v += w0 * (r0 ? flt[0][k] : u);
+    v += w2 * (r1 ? flt[1][k] : u);
+    out[(size_t)(y0 + i) * L.stride + X0 + j] = (Pix)min(max((v + 1024) >> 11, 0), maxpix);
+  }
+}
+
+hipError_t launch_lr(const LrLaunch &L, hipStream_t s) {
+  const int SH = 64 >> L.ss, off = 8 >> L.ss;
+  const int tw = L.unit_size < 64 ? L.unit_size : 64;
+  const dim3 grid((L.w + tw - 1) / tw, (L.h + off + SH - 1) / SH, L.nframes);
+  if (L.bd == 8) hipLaunchKernelGGL(k_lr<uint8_t>, grid, dim3(256), 0, s, L);
+  else hipLaunchKernelGGL(k_lr<uint16_t>, grid, dim3(256), 0, s, L);
+  return hipGetLastError();
+}
+
+}  // namespace av1mi

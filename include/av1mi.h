@@ -181,6 +181,16 @@ typedef struct av1mi_cdef_job {
 } av1mi_cdef_job;
 int av1mi_cdef_frames(av1mi_ctx *ctx, const av1mi_cdef_job *job);
 
+/* ---- K7: loop restoration (AV1 spec §7.17) of one plane of nframes frames stacked vertically.  d_cdef: the CDEF
+ * output, d_deblocked: the deblocked (pre-CDEF) plane used beyond stripe boundaries, d_out: the restored plane
+ * (distinct from both).  subsampled = 1 for the chroma planes of 4:2:0 (32-row stripes offset by 4), 0 for luma.
+ * unit_size: 32 (chroma only), 64, 128 or 256.  d_units: rows x cols entries of 8 bytes, rows =
+ * max(1, (h + unit/2) / unit), cols likewise: {type: 0 none / 1 Wiener / 2 self-guided,
+ *   Wiener: v0 v1 v2 h0 h1 h2 (int8 taps; the centre tap is 128 - 2*(sum)), pad |
+ *   self-guided: set 0..15, xqd0, xqd1 (int8), pad}.  unit_frame_stride: units between frames, 0 = shared. */
+int av1mi_lr_frames(av1mi_ctx *ctx, const void *d_cdef, const void *d_deblocked, void *d_out, int stride, int w, int h,
+                    int bd, int subsampled, int unit_size, const int8_t *d_units, size_t unit_frame_stride, int nframes);
+
 /* ---- the intra-only segment pipeline (BASELINE config 2): what stands in for the encode the reference delegates
  * to `ffmpeg -c:v:0 av1_vaapi` (transcode.go:120) for key frames.  One launch codes `nframes` frames that are
  * stacked in the plane buffers (frame f starts at row f*height of the luma planes, f*height/2 of the chroma planes).

@@ -254,3 +254,34 @@ def cdef_frame(Y, U, V, bd, damping, sb_strength, skip8):
     if rc:
         raise ValueError("av1o_cdef_frame rc=%d" % rc)
     return oy, ou, ov
+
+
+def lr_units(unit_size, plane_size):
+    return lib().av1o_lr_units(unit_size, plane_size)
+
+
+def lr_unit_none():
+    return np.zeros(8, np.int8)
+
+
+def lr_unit_wiener(v, h):
+    return np.array([1, v[0], v[1], v[2], h[0], h[1], h[2], 0], np.int8)
+
+
+def lr_unit_sgr(sgr_set, xqd0, xqd1):
+    return np.array([2, sgr_set, xqd0, xqd1, 0, 0, 0, 0], np.int8)
+
+
+def lr_plane(cdef, dbl, bd, ss, unit_size, units):
+    """cdef: CDEF output plane, dbl: deblocked (pre-CDEF) plane; units: [rows, cols, 8] int8.  Returns the restored plane."""
+    dt = np.uint8 if bd == 8 else np.uint16
+    cdef, dbl = np.ascontiguousarray(cdef, dt), np.ascontiguousarray(dbl, dt)
+    out = np.zeros_like(cdef)
+    h, w = cdef.shape
+    units = np.ascontiguousarray(units, np.int8)
+    assert units.shape == (lr_units(unit_size, h), lr_units(unit_size, w), 8)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    rc = lib().av1o_lr_plane(vp(cdef), vp(dbl), vp(out), w, w, h, bd, ss, unit_size, vp(units))
+    if rc:
+        raise ValueError("av1o_lr_plane rc=%d" % rc)
+    return out

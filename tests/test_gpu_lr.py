@@ -1,0 +1,70 @@
+"""GPU parity for K7 (loop restoration: Wiener + self-guided) vs the CPU oracle, bit-exact."""
+import numpy as np
+import pytest
+
+from lf_util import test_image as make_image
+
+pytestmark = pytest.mark.gpu
+
+
+def _random_units(rng, O, unit, h, w):
+    u = np.zeros((O.lr_units(unit, h), O.lr_units(unit, w), 8), np.int8)
+    for r in range(u.shape[0]):
+        for c in range(u.shape[1]):
+            t = int(rng.integers(0, 3))
+            if t == 1:
+                u[r, c] = O.lr_unit_wiener((rng.integers(-5, 11), rng.integers(-23, 9), rng.integers(-17, 47)),
+                                           (rng.integers(-5, 11), rng.integers(-23, 9), rng.integers(-17, 47)))
+            elif t == 2:
+                u[r, c] = O.lr_unit_sgr(int(rng.integers(0, 16)), int(rng.integers(-96, 32)), int(rng.integers(-32, 96)))
+    return u
+
+
+def _run(ctx, cdef, dbl, bd, ss, unit, units):
+    nf, h, w = cdef.shape
+    d_c, d_d, d_u = ctx.to_device(cdef), ctx.to_device(dbl), ctx.to_device(units)
+    d_o = ctx.alloc(cdef.nbytes)
+    ctx.lr_frames(d_c, d_d, d_o, w, w, h, bd, ss, unit, d_u, 0 if units.ndim == 3 else units.shape[1] * units.shape[2], nf)
+    out = d_o.download(cdef.shape, cdef.dtype)
+    for b in (d_c, d_d, d_u, d_o):
+        b.free()
+    return out
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+@pytest.mark.parametrize("ss", [0, 1])
+def test_lr_random_units(ctx, O, bd, ss):
+    rng = np.random.default_rng(90 + bd + ss)
+    for (h, w), unit in (((136, 200), 64), ((72, 100), 32 if ss else 64), ((300, 260), 128), ((40, 24), 64), ((130, 520), 256)):
+        nf = 2
+        cdef = np.stack([make_image(rng, h, w, bd) for _ in range(nf)])
+        dbl = np.stack([make_image(rng, h, w, bd) for _ in range(nf)])   # deliberately different from cdef
+        units = np.stack([_random_units(rng, O, unit, h, w) for _ in range(nf)])
+        got = _run(ctx, cdef, dbl, bd, ss, unit, units)
+        for f in range(nf):
+            exp = O.lr_plane(cdef[f], dbl[f], bd, ss, unit, units[f])
+            assert (got[f] == exp).all(), ((h, w), unit, bd, ss, f, np.argwhere(got[f] != exp)[:4])
+
+
+def test_lr_every_sgr_set_and_extreme_wiener(ctx, O):
+    rng = np.random.default_rng(95)
+    h, w = 96, 16 * 64
+    cdef = make_image(rng, h, w, 10)[None]
+    dbl = make_image(rng, h, w, 10)[None]
+    units = np.zeros((O.lr_units(64, h), 16, 8), np.int8)
+    for s in range(16):
+        units[:, s] = O.lr_unit_sgr(s, -96 if s & 1 else 31, 95 if s & 2 else -32)
+    got = _run(ctx, cdef, dbl, 10, 0, 64, units)
+    assert (got[0] == O.lr_plane(cdef[0], dbl[0], 10, 0, 64, units)).all()
+    units[:] = O.lr_unit_wiener((10, 8, 46), (-5, -23, -17))
+    got = _run(ctx, cdef, dbl, 10, 0, 64, units)
+    assert (got[0] == O.lr_plane(cdef[0], dbl[0], 10, 0, 64, units)).all()
+
+
+def test_lr_1080p_fixed_point(ctx, O):
+    """BASELINE size, size-independent property: a flat 1920x1080 plane is a fixed point of every filter type"""
+    h, w = 1080, 1920
+    flat = np.full((1, h, w), 131, np.uint8)
+    rng = np.random.default_rng(96)
+    units = _random_units(rng, O, 64, h, w)
+    assert (_run(ctx, flat, flat, 8, 0, 64, units) == 131).all()
