@@ -24,11 +24,24 @@ def lf_mi_word(tx_w_log2, tx_h_log2, lvl_v, lvl_h, skip_inter=0, blk_left=1, blk
     return (tx_w_log2 | (tx_h_log2 << 4) | (lvl_v << 8) | (lvl_h << 16) | (skip_inter << 24) | (blk_left << 25) | (blk_top << 26))
 
 
+def cdef_strength_from_q(ac_q, bd):
+    """encoder policy, not normative: one CDEF strength set per frame from the AC step (libaom's CDEF_PICK_FROM_Q idea)."""
+    q = ac_q >> (bd - 8)
+    y_pri = int(min(max((q * q * 3 + 32768) >> 16, 0), 15)) if q < 700 else 15
+    return np.array([min(15, max(1, y_pri + 2)), 1, min(15, max(1, y_pri)), 1], np.uint8)
+
+
+WIENER_DEFAULT_LUMA = (1, 3, -7, 15, 3, -7, 15, 0)     # type, v0 v1 v2, h0 h1 h2: libaom's mid-range default taps
+WIENER_DEFAULT_CHROMA = (1, 0, -7, 15, 0, -7, 15, 0)   # chroma: 5 taps (outer tap 0)
+
+
 class IntraPipeline:
-    """BASELINE config 2 (intra-only, every frame a key frame): per segment
-         1 launch  k_intra_pipe   intra prediction + mode decision + fwd DCT + quant + dequant + inv DCT + recon
-         3 launches k_deblock     deblocking of Y, U, V (both passes fused), reconstruction -> filtered planes
-    CDEF and loop restoration are separate kernels that join the loop when built."""
+    """BASELINE config 2 (intra-only, every frame a key frame) + the rest of the in-loop filter chain: per segment
+         1 launch   k_intra_pipe  intra prediction + mode decision + fwd DCT + quant + dequant + inv DCT + recon
+         3 launches k_deblock     deblocking of Y, U, V (both passes fused)         rec -> dbl
+         1 launch   k_cdef        CDEF of the three planes                          dbl -> cdef
+         3 launches k_lr          loop restoration (Wiener, fixed default taps)     cdef (+ dbl rows) -> out
+    Filter parameters are fixed per segment by simple policies (no RD search); entropy coding is not built."""
 
     def __init__(self, ctx, width, height, bd, frames, qindex, first_frame=0, block_size=8):
         self.ctx, self.bd, self.frames, self.bs, self.qindex = ctx, bd, frames, block_size, qindex
@@ -41,7 +54,9 @@ class IntraPipeline:
         for name, arr in (("src_y", Y), ("src_u", U), ("src_v", V)):
             self.d[name] = ctx.to_device(arr)
         for name, n in (("rec_y", Y.nbytes), ("rec_u", U.nbytes), ("rec_v", V.nbytes), ("dbl_y", Y.nbytes), ("dbl_u", U.nbytes),
-                        ("dbl_v", V.nbytes), ("lev_y", Y.size * 2), ("lev_u", U.size * 2), ("lev_v", V.size * 2),
+                        ("dbl_v", V.nbytes), ("cdef_y", Y.nbytes), ("cdef_u", U.nbytes), ("cdef_v", V.nbytes),
+                        ("out_y", Y.nbytes), ("out_u", U.nbytes), ("out_v", V.nbytes),
+                        ("lev_y", Y.size * 2), ("lev_u", U.size * 2), ("lev_v", V.size * 2),
                         ("modes_y", frames * nb), ("modes_uv", frames * nb)):
             self.d[name] = ctx.alloc(n)
         self.job = av1mi.IntraJob(width, height, bd, frames, qindex, block_size, width, width // 2)
@@ -55,12 +70,28 @@ class IntraPipeline:
         self.mi_c = np.full((height // 8, width // 8), lf_mi_word(l2c, l2c, self.lf_level, self.lf_level), np.uint32)
         self.d["mi_y"], self.d["mi_c"] = ctx.to_device(self.mi_y), ctx.to_device(self.mi_c)
         self.samples = Y.size + U.size + V.size            # per step
+        # CDEF: one strength set for every superblock, nothing skipped; LR: every unit Wiener with the default taps
+        nsb = ((height + 63) // 64) * ((width + 63) // 64)
+        self.cdef_damping = 3 + (self.ac_q >> (bd - 8) > 100) + (self.ac_q >> (bd - 8) > 300)
+        self.cdef_sb = np.tile(cdef_strength_from_q(self.ac_q, bd), (nsb, 1))
+        self.cdef_skip = np.zeros((height // 8, width // 8), np.uint8)
+        self.lr_unit = 64
+        ur = lambda n: max(1, (n + 32) // 64)
+        self.lr_units_y = np.tile(np.array(WIENER_DEFAULT_LUMA, np.int8), (ur(height), ur(width), 1))
+        self.lr_units_c = np.tile(np.array(WIENER_DEFAULT_CHROMA, np.int8), (ur(height // 2), ur(width // 2), 1))
+        for k, a in (("cdef_sb", self.cdef_sb), ("cdef_skip", self.cdef_skip), ("lr_y", self.lr_units_y), ("lr_c", self.lr_units_c)):
+            self.d[k] = ctx.to_device(a)
+        d = self.d
+        self.cdef_job = av1mi.CdefJob(width, height, bd, frames, self.cdef_damping, width, width // 2,
+                                      d["dbl_y"].ptr, d["dbl_u"].ptr, d["dbl_v"].ptr, d["cdef_y"].ptr, d["cdef_u"].ptr,
+                                      d["cdef_v"].ptr, d["cdef_sb"].ptr, 0, d["cdef_skip"].ptr, 0)
 
     def describe(self):
         return ("%dx%d %d-bit 4:2:0 intra-only (all key frames), tile = 64x64 superblock, %dx%d blocks: intra prediction "
-                "(11 modes, SAD decision) + fwd DCT + quant + dequant + inv DCT + recon fused, then deblocking (level %d); "
-                "CDEF / loop restoration / entropy coding not in the loop yet"
-                % (self.width, self.height, self.bd, self.bs, self.bs, self.lf_level))
+                "(11 modes, SAD decision) + fwd DCT + quant + dequant + inv DCT + recon fused, then deblocking (level %d), "
+                "CDEF (strengths %s, damping %d) and Wiener loop restoration (64x64 units, default taps); "
+                "entropy coding / OBU packing not built (levels + modes stay in HBM)"
+                % (self.width, self.height, self.bd, self.bs, self.bs, self.lf_level, self.cdef_sb[0].tolist(), self.cdef_damping))
 
     def step(self):
         c, d = self.ctx, self.d
@@ -69,19 +100,26 @@ class IntraPipeline:
         c.deblock_frames(d["rec_y"], w, d["dbl_y"], w, w, h, self.bd, 0, d["mi_y"], w // 4, 0, 0, f)
         c.deblock_frames(d["rec_u"], w // 2, d["dbl_u"], w // 2, w // 2, h // 2, self.bd, 1, d["mi_c"], w // 8, 0, 0, f)
         c.deblock_frames(d["rec_v"], w // 2, d["dbl_v"], w // 2, w // 2, h // 2, self.bd, 1, d["mi_c"], w // 8, 0, 0, f)
+        c.cdef_frames(self.cdef_job)
+        c.lr_frames(d["cdef_y"], d["dbl_y"], d["out_y"], w, w, h, self.bd, 0, self.lr_unit, d["lr_y"], 0, f)
+        c.lr_frames(d["cdef_u"], d["dbl_u"], d["out_u"], w // 2, w // 2, h // 2, self.bd, 1, self.lr_unit, d["lr_c"], 0, f)
+        c.lr_frames(d["cdef_v"], d["dbl_v"], d["out_v"], w // 2, w // 2, h // 2, self.bd, 1, self.lr_unit, d["lr_c"], 0, f)
 
     def algorithmic_bytes(self):
         """per LAUNCH, by kernel kind: the fused coding kernel reads the source (b) and writes the
         reconstruction (b) and the int16 levels (2); deblocking reads and writes a plane (2b)."""
         b = self.bps
-        return {"intra_pipeline": (2 * b + 2) * self.samples, "deblock": 2 * b * self.samples / 3.0}
+        return {"intra_pipeline": (2 * b + 2) * self.samples, "deblock": 2 * b * self.samples / 3.0,
+                "cdef": 2 * b * self.samples, "loop_restoration": 2 * b * self.samples / 3.0}
 
-    def download(self):
-        d, (Y, U, V) = self.d, self.src
-        dt = Y.dtype
-        return dict(rec_y=d["rec_y"].download(Y.shape, dt), dbl_y=d["dbl_y"].download(Y.shape, dt),
-                    dbl_u=d["dbl_u"].download(U.shape, dt), dbl_v=d["dbl_v"].download(V.shape, dt),
-                    modes_y=d["modes_y"].download((self.frames, -1), np.uint8) if False else None)
+    def download(self, frame=0):
+        """outputs of one frame of the segment (tests / PSNR)"""
+        out = {}
+        for k, src in (("rec_y", 0), ("rec_u", 1), ("rec_v", 2), ("dbl_y", 0), ("dbl_u", 1), ("dbl_v", 2), ("cdef_y", 0),
+                       ("cdef_u", 1), ("cdef_v", 2), ("out_y", 0), ("out_u", 1), ("out_v", 2)):
+            a = self.src[src]
+            out[k] = self.d[k].download(a.shape, a.dtype)[frame]
+        return out
 
     def close(self):
         for b in self.d.values():

@@ -46,9 +46,12 @@ def cpu_baseline(pipe, seconds=12.0):
 
     def one(f):
         r = O.intra_encode_frame(Y[f], U[f], V[f], pipe.bd, pipe.bs, pipe.qindex)
-        O.deblock_plane(r["rec_y"], pipe.bd, 0, pipe.mi_y)
-        O.deblock_plane(r["rec_u"], pipe.bd, 1, pipe.mi_c)
-        O.deblock_plane(r["rec_v"], pipe.bd, 1, pipe.mi_c)
+        dbl = [O.deblock_plane(r["rec_y"], pipe.bd, 0, pipe.mi_y), O.deblock_plane(r["rec_u"], pipe.bd, 1, pipe.mi_c),
+               O.deblock_plane(r["rec_v"], pipe.bd, 1, pipe.mi_c)]
+        cdef = O.cdef_frame(dbl[0], dbl[1], dbl[2], pipe.bd, pipe.cdef_damping, pipe.cdef_sb, pipe.cdef_skip)
+        O.lr_plane(cdef[0], dbl[0], pipe.bd, 0, pipe.lr_unit, pipe.lr_units_y)
+        O.lr_plane(cdef[1], dbl[1], pipe.bd, 1, pipe.lr_unit, pipe.lr_units_c)
+        O.lr_plane(cdef[2], dbl[2], pipe.bd, 1, pipe.lr_unit, pipe.lr_units_c)
         return 1
 
     done, t0 = 0, time.perf_counter()
@@ -57,8 +60,8 @@ def cpu_baseline(pipe, seconds=12.0):
             done += sum(ex.map(one, [(done + i) % pipe.frames for i in range(cores)]))
     dt = time.perf_counter() - t0
     return {"value": done / dt, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": "%d frames of the same segment through oracle/av1o_intra_encode_frame + av1o_deblock_plane "
-                      "(same stages as the GPU step) in %.1f s" % (done, dt)}
+            "sample": "%d frames of the same segment through the oracle's intra encoder loop + deblock + CDEF + loop "
+                      "restoration (same stages as the GPU step) in %.1f s" % (done, dt)}
 
 
 def main():
