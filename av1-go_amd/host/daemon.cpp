@@ -1,0 +1,110 @@
+// daemon.cpp — see daemon.hpp.
+#include "daemon.hpp"
+#include <sys/stat.h>
+#include <unistd.h>
+#include <cerrno>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+
+namespace av1mi_host {
+namespace {
+bool stat_size(const std::string &p, int64_t *sz) { struct stat st; if (stat(p.c_str(), &st)) return false; *sz = st.st_size; return true; }
+void split(const std::string &path, std::string *dir, std::string *stem, std::string *ext) {
+  const size_t sl = path.find_last_of('/');
+  *dir = sl == std::string::npos ? "." : path.substr(0, sl);
+  const std::string base = sl == std::string::npos ? path : path.substr(sl + 1);
+  const size_t dot = base.find_last_of('.');
+  *stem = dot == std::string::npos || dot == 0 ? base : base.substr(0, dot);
+  *ext = dot == std::string::npos || dot == 0 ? "" : base.substr(dot);
+}
+void write_text(const std::string &path, const std::string &text) { std::ofstream f(path); f << text; }
+void save_job(const Job &j, const std::string &dir) {     // jobs.SaveJob, jobs.go:61-79 (fields this path owns)
+  if (dir.empty() || j.ID.empty()) return;
+  std::ofstream f(dir + "/" + j.ID + ".json");
+  f << "{\n  \"id\": \"" << j.ID << "\",\n  \"source_path\": \"" << j.SourcePath << "\",\n  \"output_path\": \"" << j.OutputPath
+    << "\",\n  \"status\": \"" << j.Status << "\",\n  \"reason\": \"" << j.Reason << "\",\n  \"original_bytes\": " << j.OriginalSize
+    << ",\n  \"new_bytes\": " << j.NewSize << ",\n  \"is_webrip_like\": " << (j.IsWebRipLike ? "true" : "false") << "\n}\n";
+}
+void write_why(const std::string &source, const std::string &reason) {   // metadata.WriteWhyFile, probe.go:398
+  std::string dir, stem, ext; split(source, &dir, &stem, &ext);
+  write_text(dir + "/" + stem + ".av1qsvd-why.txt", reason);
+}
+}  // namespace
+
+bool CheckSizeGate(int64_t origBytes, int64_t newBytes, double maxRatio) { return (double)newBytes <= (double)origBytes * maxRatio; }
+
+bool AtomicReplaceFile(const std::string &originalPath, const std::string &newPath, std::string *err) {
+  std::string dir, stem, ext; split(originalPath, &dir, &stem, &ext);
+  const std::string tmp = dir + "/" + stem + ".av1-tmp.mkv";
+  if (newPath != tmp && rename(newPath.c_str(), tmp.c_str())) { *err = std::string("failed to move new file to temp: ") + strerror(errno); return false; }
+  int64_t sz;
+  if (!stat_size(tmp, &sz)) { *err = std::string("temp file does not exist: ") + strerror(errno); return false; }
+  if (rename(tmp.c_str(), originalPath.c_str())) { *err = std::string("failed to replace original file: ") + strerror(errno); return false; }
+  return true;
+}
+
+bool CheckFileStable(const std::string &path, int waitSeconds, bool *stable, std::string *err) {
+  int64_t s0, s1;
+  if (!stat_size(path, &s0)) { *err = std::string("failed to stat file: ") + strerror(errno); return false; }
+  if (waitSeconds > 0) sleep((unsigned)waitSeconds);
+  if (!stat_size(path, &s1)) { *err = std::string("failed to stat file after wait: ") + strerror(errno); return false; }
+  *stable = s0 == s1;
+  return true;
+}
+
+std::string ProcessJob(Job *job, const std::string &backendPath, const ProbeResult &probeResult, const TranscodeConfig &cfg) {
+  bool stable = false;
+  std::string err;
+  if (!CheckFileStable(job->SourcePath, cfg.StableWaitSeconds, &stable, &err)) return "failed to check file stability: " + err;   // :59-62
+  if (!stable) { job->Status = "skipped"; job->Reason = "file still copying"; write_why(job->SourcePath, job->Reason); return ""; }       // :63-71
+  job->Status = "running";                                                                                                             // :74-79
+  save_job(*job, cfg.JobStateDir);
+  std::string dir, stem, ext; split(job->SourcePath, &dir, &stem, &ext);
+  const std::string outputPath = dir + "/" + stem + ".av1-tmp.mkv";                                                                     // :82-87
+  job->OutputPath = outputPath;
+  std::vector<std::string> args;
+  if (!TranscodeArgs(backendPath, job->SourcePath, outputPath, probeResult, job->IsWebRipLike, &args, &err)) {                          // :90-98
+    job->Status = "failed"; job->Reason = "failed to build ffmpeg args: " + err; save_job(*job, cfg.JobStateDir);
+    return "failed to build transcode args: " + err;
+  }
+  const RunResult rr = RunTranscode(backendPath, args);                                                                                 // :101
+  if (!rr.err.empty() || rr.exitCode != 0) {                                                                                            // :102-112
+    job->Status = "failed"; job->Reason = "ffmpeg exit code " + std::to_string(rr.exitCode) + ": " + rr.err;
+    save_job(*job, cfg.JobStateDir); write_why(job->SourcePath, job->Reason); remove(outputPath.c_str());
+    return "transcode failed: " + rr.err;
+  }
+  int64_t newSize = 0;
+  if (!stat_size(outputPath, &newSize)) {                                                                                               // :115-124
+    job->Status = "failed"; job->Reason = std::string("failed to stat output file: ") + strerror(errno);
+    save_job(*job, cfg.JobStateDir); remove(outputPath.c_str());
+    return std::string("output file not found: ") + strerror(errno);
+  }
+  job->NewSize = newSize;
+  if (!CheckSizeGate(job->OriginalSize, job->NewSize, cfg.MaxSizeRatio)) {                                                              // :129-150
+    char buf[160];
+    snprintf(buf, sizeof(buf), "size gate: new %.1f MB vs orig %.1f MB (>%.0f%%)", job->NewSize / 1048576.0, job->OriginalSize / 1048576.0,
+             cfg.MaxSizeRatio * 100);
+    job->Status = "skipped"; job->Reason = buf;
+    write_why(job->SourcePath, job->Reason);
+    write_text(dir + "/" + stem + ".av1qsvd-skip", "skip");
+    remove(outputPath.c_str());
+    save_job(*job, cfg.JobStateDir);
+    return "";
+  }
+  if (!AtomicReplaceFile(job->SourcePath, outputPath, &err)) {                                                                          // :154-163
+    job->Status = "failed"; job->Reason = "failed to replace file: " + err; save_job(*job, cfg.JobStateDir); remove(outputPath.c_str());
+    return "failed to replace file: " + err;
+  }
+  int64_t sz;
+  if (!stat_size(job->SourcePath, &sz)) {                                                                                               // :166-172
+    job->Status = "failed"; job->Reason = std::string("replaced file verification failed: ") + strerror(errno);
+    save_job(*job, cfg.JobStateDir);
+    return job->Reason;
+  }
+  job->Status = "success";                                                                                                             // :176-179
+  save_job(*job, cfg.JobStateDir);
+  return "";
+}
+
+}  // namespace av1mi_host

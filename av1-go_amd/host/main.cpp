@@ -1,0 +1,31 @@
+// av1mi_transcode — CLI with the reference's process contract (exit code, stderr text, output file last):
+//   av1mi_transcode [ffmpeg-style args] -i in.y4m [-global_quality:v:0 Q] [-g GOP] out.av1-tmp.mkv
+//   av1mi_transcode --job in.y4m [--ratio 0.9] [--state DIR] [--wait S]     (the ProcessJob lifecycle)
+#include <cstdio>
+#include <cstring>
+#include <sys/stat.h>
+#include "daemon.hpp"
+
+using namespace av1mi_host;
+
+int main(int argc, char **argv) {
+  if (argc >= 3 && !strcmp(argv[1], "--job")) {
+    Job job; job.ID = "cli"; job.SourcePath = argv[2];
+    TranscodeConfig cfg; cfg.StableWaitSeconds = 0;
+    for (int i = 3; i + 1 < argc; i += 2) {
+      if (!strcmp(argv[i], "--ratio")) cfg.MaxSizeRatio = atof(argv[i + 1]);
+      else if (!strcmp(argv[i], "--state")) cfg.JobStateDir = argv[i + 1];
+      else if (!strcmp(argv[i], "--wait")) cfg.StableWaitSeconds = atoi(argv[i + 1]);
+    }
+    struct stat st;
+    if (!stat(job.SourcePath.c_str(), &st)) job.OriginalSize = st.st_size;
+    ProbeResult pr; pr.HasVideo = true; pr.has_video_stream = true; pr.VideoStream.Height = 1080;
+    const std::string e = ProcessJob(&job, "av1mi", pr, cfg);
+    fprintf(stderr, "job %s: %s%s%s\n", job.Status.c_str(), job.Reason.c_str(), e.empty() ? "" : " | ", e.c_str());
+    return e.empty() ? 0 : 1;
+  }
+  std::vector<std::string> args(argv + 1, argv + argc);
+  const RunResult rr = RunTranscode(argv[0], args);
+  if (rr.exitCode != 0) fprintf(stderr, "%s\n", rr.err.c_str());
+  return rr.exitCode < 0 ? 255 : rr.exitCode;
+}

@@ -1,0 +1,110 @@
+"""Host-side mirror of the reference's transcode-job API (C++, av1-go_amd/host) pinned against values read off the
+reference source: internal/ffmpeg/transcode.go:17-165, internal/daemon/daemon.go:18-21."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+HOST = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "av1-go_amd", "host", "libav1mi_host.so")
+
+
+@pytest.fixture(scope="module")
+def host():
+    if not os.path.exists(HOST):
+        import subprocess
+        subprocess.check_call(["make", "-s", "-C", os.path.dirname(HOST)])
+    lib = C.CDLL(HOST)
+    lib.av1mi_host_check_size_gate.argtypes = [C.c_longlong, C.c_longlong, C.c_double]
+    lib.av1mi_host_process_job.argtypes = [C.c_char_p, C.c_longlong, C.c_double, C.c_char_p, C.c_int, C.c_char_p, C.c_char_p, C.c_int]
+    return lib
+
+
+def _args(host, inp, out, has_video=1, index=0, height=1080, webrip=0):
+    buf = C.create_string_buffer(8192)
+    n = host.av1mi_host_transcode_args(inp.encode(), out.encode(), has_video, index, height, webrip, buf, 8192)
+    return n, buf.value.decode().split("\n")
+
+
+def test_determine_quality_thresholds(host):   # transcode.go:157-165
+    for h, q in ((0, 25), (720, 25), (1079, 25), (1080, 24), (1439, 24), (1440, 23), (2160, 23)):
+        assert host.av1mi_host_determine_quality(h) == q
+
+
+def test_check_size_gate_edges(host):          # daemon.go:18-21
+    assert host.av1mi_host_check_size_gate(1000, 900, 0.90) == 1
+    assert host.av1mi_host_check_size_gate(1000, 901, 0.90) == 0
+    assert host.av1mi_host_check_size_gate(0, 0, 0.90) == 1 and host.av1mi_host_check_size_gate(0, 1, 0.90) == 0
+
+
+def test_transcode_args_match_the_reference_argv(host):
+    n, a = _args(host, "/m/in.mkv", "/m/in.av1-tmp.mkv", index=2, height=1080, webrip=0)
+    expect = ["-hide_banner", "-analyzeduration", "50M", "-probesize", "50M", "-init_hw_device", "vaapi=va", "-hwaccel", "vaapi",
+              "-hwaccel_output_format", "vaapi", "-filter_hw_device", "va", "-i", "/m/in.mkv", "-map", "0", "-map", "-0:v", "-map", "-0:t",
+              "-map", "0:v:2", "-map", "0:a?", "-map", "-0:a:m:language:rus", "-map", "-0:a:m:language:ru", "-map", "0:s?",
+              "-map", "-0:s:m:language:rus", "-map", "-0:s:m:language:ru", "-map_chapters", "0", "-vf:v:0",
+              "scale_vaapi=w=ceil(iw/2)*2:h=ceil(ih/2)*2,hwdownload,format=nv12,setsar=1,format=nv12,hwupload",
+              "-c:v:0", "av1_vaapi", "-global_quality:v:0", "24", "-compression_level", "2", "-c:a", "copy", "-c:s", "copy",
+              "-max_muxing_queue_size", "2048", "-map_metadata", "0", "-f", "matroska", "-movflags", "+faststart", "/m/in.av1-tmp.mkv"]
+    assert n == len(expect) and a == expect
+    n, w = _args(host, "a.mkv", "b.mkv", height=2160, webrip=1)
+    assert w[13:17] == ["-fflags", "+genpts", "-copyts", "-start_at_zero"] and w[17:19] == ["-i", "a.mkv"]
+    assert w[w.index("-vf:v:0") + 1].startswith("scale_vaapi=w='if(gt(iw,iw*sar),iw,iw*sar)':h='if(gt(iw,iw*sar),iw/sar,ih)',scale_vaapi=w=ceil")
+    assert w[w.index("-global_quality:v:0") + 1] == "23"
+    i = w.index("-compression_level")
+    assert w[i + 2:i + 6] == ["-vsync", "0", "-avoid_negative_ts", "make_zero"] and w[-1] == "b.mkv" and n == len(w) == len(expect) + 8
+
+
+def test_transcode_args_without_video_stream(host):   # transcode.go:18-20
+    n, a = _args(host, "a", "b", has_video=0)
+    assert n == -1 and a == ["no video stream found in probe result"]
+
+
+def _write_y4m(path, w, h, n, bd=8):
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(HOST), ".."))
+    import synth
+    Y, U, V = synth.frames(w, h, n, bd)
+    with open(path, "wb") as f:
+        f.write(("YUV4MPEG2 W%d H%d F30:1 Ip A1:1 C%s\n" % (w, h, "420jpeg" if bd == 8 else "420p10")).encode())
+        for i in range(n):
+            f.write(b"FRAME\n")
+            for p in (Y[i], U[i], V[i]):
+                f.write(p.astype("<u2" if bd == 10 else np.uint8).tobytes())
+
+
+def test_run_transcode_fails_cleanly_without_gpu_or_input(host, tmp_path, av1mi):
+    buf = C.create_string_buffer(1024)
+    args = "\n".join(["-i", str(tmp_path / "missing.y4m"), "-global_quality:v:0", "25", str(tmp_path / "o.mkv")])
+    rc = host.av1mi_host_run_transcode(args.encode(), buf, 1024)
+    if av1mi.load().av1mi_device_count() == 0:
+        assert rc == -1 and b"no usable HIP device" in buf.value      # "could not run": transcode.go:311
+    else:
+        assert rc == 1 and b"No such file or directory" in buf.value
+    assert not (tmp_path / "o.mkv").exists()
+    rc = host.av1mi_host_run_transcode(b"-x", buf, 1024)
+    assert rc == 1 and b"Invalid argument" in buf.value
+
+
+@pytest.mark.gpu
+def test_run_transcode_and_process_job_on_gpu(host, tmp_path):
+    src = tmp_path / "clip.y4m"
+    _write_y4m(str(src), 192, 128, 7)
+    out = tmp_path / "clip.av1-tmp.mkv"
+    buf = C.create_string_buffer(1024)
+    args = "\n".join(["-hide_banner", "-i", str(src), "-global_quality:v:0", "120", "-g", "3", str(out)])
+    assert host.av1mi_host_run_transcode(args.encode(), buf, 1024) == 0 and buf.value == b""
+    data = out.read_bytes()
+    assert data.startswith(b"AV1MI1 W192 H128 B8 F30:1 Q120 G3\n") and data.count(b"SEG 3 ") == 2 and data.count(b"SEG 1 ") == 1
+    assert len(data) < src.stat().st_size            # coarse quantiser: packed levels are smaller than the raw input
+    out.unlink()
+    # lifecycle: generous ratio -> the source is replaced by the coded file; tight ratio -> skipped with markers
+    status, reason = C.create_string_buffer(256), C.create_string_buffer(1024)
+    orig = src.stat().st_size
+    src2 = tmp_path / "other.y4m"
+    src2.write_bytes(src.read_bytes())
+    assert host.av1mi_host_process_job(str(src2).encode(), orig, 1e-4, str(tmp_path).encode(), 0, status, reason, 256) == 0
+    assert status.value == b"skipped" and reason.value.startswith(b"size gate: new ") and (tmp_path / "other.av1qsvd-skip").exists()
+    assert (tmp_path / "other.av1qsvd-why.txt").exists() and not (tmp_path / "other.av1-tmp.mkv").exists() and src2.stat().st_size == orig
+    assert host.av1mi_host_process_job(str(src).encode(), orig, 5.0, str(tmp_path).encode(), 0, status, reason, 256) == 0
+    assert status.value == b"success" and src.read_bytes().startswith(b"AV1MI1 ") and (tmp_path / "test.json").exists()
