@@ -31,6 +31,8 @@ def parse():
     ap.add_argument("--frames", type=int, default=0, help="frames per step (segment length); 0 = default")
     ap.add_argument("--qindex", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dry-run-cpu", action="store_true",
+                    help="no GPU: exercise the rank/sharding/timing/aggregation plumbing with a stand-in step (gloo tests)")
     return ap.parse_args()
 
 
@@ -64,6 +66,41 @@ def cpu_baseline(pipe, seconds=12.0):
                       "restoration (same stages as the GPU step) in %.1f s" % (done, dt)}
 
 
+def segment_of_rank(rank, frames_per_step):
+    """closed-GOP sharding: rank r codes the r-th run of frames_per_step frames (no data exchanged between ranks)"""
+    return rank * frames_per_step
+
+
+def aggregate(dist, dt, device):
+    """max over ranks of the timed region (the job is as slow as its slowest GPU)"""
+    if dist is None:
+        return dt
+    import torch
+    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def dry_run(args, rank, world, dist):
+    """CPU stand-in used by tests/test_distributed.py: same control flow as the GPU path, a sleep as the step."""
+    frames = args.frames or 4
+    first = segment_of_rank(rank, frames)
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.01 * (1 + rank))        # uneven ranks: the aggregate must follow the slowest
+    if dist is not None:
+        dist.barrier()
+    dt = aggregate(dist, time.perf_counter() - t0, "cpu")
+    if rank == 0:
+        print(json.dumps({"metric": "dry-run", "value": frames * args.steps * world / dt, "unit": "frames/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "scaling": "weak",
+                          "first_frame_rank0": first, "frames_per_step": frames}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -74,9 +111,14 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
-        sync_t = torch.zeros(1, device="cuda" if torch.cuda.is_available() else "cpu")
+        use_cuda = torch.cuda.is_available() and not args.dry_run_cpu
+        if use_cuda:
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl" if use_cuda else "gloo")   # nccl == RCCL on ROCm; only barrier + max-reduce use it
+        sync_t = torch.zeros(1, device="cuda" if use_cuda else "cpu")
+
+    if args.dry_run_cpu:
+        return dry_run(args, rank, world, dist)
 
     import av1mi
     import pipeline
@@ -88,7 +130,7 @@ def main():
         W, H, bd = 3840, 2160, 10
         frames = args.frames or 8
     ctx = av1mi.Context(local_rank)
-    pipe = pipeline.IntraPipeline(ctx, W, H, bd, frames, args.qindex, first_frame=rank * frames)
+    pipe = pipeline.IntraPipeline(ctx, W, H, bd, frames, args.qindex, first_frame=segment_of_rank(rank, frames))
 
     def barrier():
         ctx.sync()
@@ -111,11 +153,7 @@ def main():
     dt = time.perf_counter() - t0
     ctx.prof_enable(False)
     prof = ctx.prof_get()
-    if dist is not None:
-        import torch
-        t = torch.tensor([dt], device=sync_t.device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = aggregate(dist, dt, sync_t.device if dist is not None else None)
 
     total_frames = frames * args.steps * world
     fps = total_frames / dt

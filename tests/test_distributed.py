@@ -1,0 +1,38 @@
+"""N > 1 path of bench.py on CPU: two ranks over gloo (world_size 2) through the real launcher, stand-in step.
+Checks the rank/segment sharding, the barrier-bracketed timing and the max-over-ranks aggregation."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_two_ranks_gloo():
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1", "--dry-run-cpu"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                       # rank 0 prints ONE line
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 5 and j["scaling"] == "weak" and j["first_frame_rank0"] == 0
+    # rank 1 sleeps 20 ms per step, rank 0 10 ms: the aggregate time is the slower rank's
+    assert j["ms_per_step"] >= 19.0
+    assert abs(j["value"] - 2 * j["frames_per_step"] * 5 / (j["ms_per_step"] * 5e-3)) < 1e-6 * j["value"] + 1e-6
+
+
+def test_single_rank_dry_run():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run-cpu", "--steps", "2"], capture_output=True, text=True,
+                         timeout=120, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert j["n_gpus"] == 1 and j["ms_per_step"] >= 9.0
+
+
+def test_segment_sharding_is_disjoint():
+    sys.path.insert(0, ROOT)
+    import bench
+    starts = [bench.segment_of_rank(r, 32) for r in range(8)]
+    assert starts == [0, 32, 64, 96, 128, 160, 192, 224]
