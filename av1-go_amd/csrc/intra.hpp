@@ -206,10 +206,10 @@ __device__ __forceinline__ IntraEdges intra_build_edges(const IntraBlk &B, int b
   return E;
 }
 
-// prediction of row r (BW samples) of the block into out[]
-template <int BW, int BH>
-__device__ __forceinline__ void intra_pred_row(const IntraBlk &B, const IntraEdges &E, int bd, int r, const uint16_t *above,
-                                               const uint16_t *left, int *out) {
+// prediction of row r (BW samples) of the block into out[]; T = sample type of the edge arrays (uint8_t / uint16_t)
+template <int BW, int BH, typename T = uint16_t>
+__device__ __forceinline__ void intra_pred_row(const IntraBlk &B, const IntraEdges &E, int bd, int r, const T *above,
+                                               const T *left, int *out) {
   if (E.flat) {
 #pragma unroll
     for (int c = 0; c < BW; c++) out[c] = E.flat_val;

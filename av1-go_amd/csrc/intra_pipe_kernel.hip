@@ -19,7 +19,7 @@
 // (candidate list, SAD, first-minimum tie break, DCT_DCT, tile = superblock) is this project's own and is
 // mirrored by oracle/av1o_pipeline.c:av1o_intra_encode_frame for checking.  The reference has no counterpart
 // (internal/ffmpeg/transcode.go:120 hands the whole job to an external encoder).
-#include "intra.hpp"
+#include "intra_fast.hpp"
 #include "txfm_cfg.hpp"
 #include "av1mi_internal.hpp"
 
@@ -64,24 +64,23 @@ template <int N, typename Pix> __device__ __forceinline__ void store_row(Pix *p,
   }
 }
 
-// per-plane, per-tile neighbour context in LDS (indices in samples / blocks of that plane)
-struct TileCtx {
-  uint16_t *above;   // [tile width]  last reconstructed sample of each column
-  uint16_t *left;    // [tile height] last reconstructed sample of each row
-  uint16_t *br;      // [n*n] bottom-right sample of each coded block
-  uint16_t *edge;    // 4 edge arrays of edge_len(B,B) entries
-  int32_t *tbuf;     // B x (B+4) transpose buffer
+// per-plane, per-tile neighbour context in LDS (indices in samples / blocks of that plane); ES = sample type
+template <typename ES> struct TileCtx {
+  ES *above;       // [tile width]  last reconstructed sample of each column
+  ES *left;        // [tile height] last reconstructed sample of each row
+  ES *br;          // [n*n] bottom-right sample of each coded block
+  ES *edge;        // raw + derived edge arrays, fast_edge_len(B) entries
+  int32_t *tbuf;   // B x (B+4) transpose buffer
 };
 
 // Code one B x B block with L = B lanes (`lane` in [0,B)); `gw` = lanes that share the mode decision (the whole
 // group: B for luma, 2B for the U+V pair).  Returns the chosen mode (identical in all gw lanes).
 template <int B, int GW, typename Pix>
-__device__ __forceinline__ int code_block(const TileCtx &C, int lane, int bx, int by, int n, int n_top, int n_topright, int n_left,
+__device__ __forceinline__ int code_block(const TileCtx<Pix> &C, int lane, int bx, int by, int n, int n_top, int n_topright, int n_left,
                                           int n_bottomleft, int filter_type, int dc_q, int ac_q, const Pix *src_row,
                                           Pix *rec_row, int16_t *lev_row) {
-  constexpr int EL = edge_len(B, B), RS = B + 4, bd = sizeof(Pix) == 1 ? 8 : 10;
-  uint16_t *above_e = C.edge + kEdgePad, *left_e = C.edge + EL + kEdgePad, *tmpa = C.edge + 2 * EL + kEdgePad,
-           *tmpl = C.edge + 3 * EL + kEdgePad;
+  constexpr int RS = B + 4, bd = sizeof(Pix) == 1 ? 8 : 10;
+  using ES = Pix;
   const int x = bx * B, y = by * B;
   auto fetch = [&](int yy, int xx) -> int {
     if (yy < 0) return xx < 0 ? C.br[(by - 1) * n + bx - 1] : C.above[x + xx];
@@ -89,27 +88,33 @@ __device__ __forceinline__ int code_block(const TileCtx &C, int lane, int bx, in
   };
   int s[B], bp[B];
   load_row<B>(src_row, s);
-  IntraBlk blk;
-  blk.angle_delta = 0; blk.disable_edge_filter = 0; blk.filter_type = filter_type;
-  blk.n_top = n_top; blk.n_topright = n_topright; blk.n_left = n_left; blk.n_bottomleft = n_bottomleft;
+  // all edge variants of the block in two LDS phases, then 11 predictions without further hand-offs
+  fast_build<B>(C.edge, lane, bd, n_top, n_topright, n_left, n_bottomleft, filter_type, fetch);
   int best = 0x7fffffff, best_mode = 0;
   for (int ci = 0; ci < 11; ci++) {
-    blk.mode = kCand[ci];
-    const IntraEdges E = intra_build_edges<B, B, B>(blk, bd, lane, above_e, left_e, tmpa, tmpl, fetch);
+    const FastMode M = fast_mode_setup<B>(kCand[ci], bd, n_top, n_left, filter_type, fetch);
+    IntraBlk blk;
+    blk.mode = M.mode; blk.angle_delta = 0; blk.disable_edge_filter = 0; blk.filter_type = filter_type;
+    blk.n_top = n_top; blk.n_topright = n_topright; blk.n_left = n_left; blk.n_bottomleft = n_bottomleft;
+    IntraEdges E;
+    E.p_angle = M.p_angle; E.is_dr = M.is_dr; E.flat = M.flat; E.flat_val = M.flat_val;
+    E.upsample_above = M.upsample_above; E.upsample_left = M.upsample_left; E.have_top = n_top > 0; E.have_left = n_left > 0;
+    const ES *above_e, *left_e;
+    fast_arrays<B>((const ES *)C.edge, M, above_e, left_e);
     int out[B];
-    intra_pred_row<B, B>(blk, E, bd, lane, above_e, left_e, out);
+    intra_pred_row<B, B, ES>(blk, E, bd, lane, above_e, left_e, out);
     int sad = 0;
 #pragma unroll
     for (int c = 0; c < B; c++) sad += abs(s[c] - out[c]);
 #pragma unroll
     for (int o = GW / 2; o >= 1; o >>= 1) sad += __shfl_xor(sad, o, GW);
     if (sad < best) {
-      best = sad; best_mode = blk.mode;
+      best = sad; best_mode = M.mode;
 #pragma unroll
       for (int c = 0; c < B; c++) bp[c] = out[c];
     }
-    AV1MI_GROUP_SYNC();
   }
+  AV1MI_GROUP_SYNC();
   // forward transform (libaom fwd_txfm2d_c: columns, then rows), DCT_DCT
   int32_t *T = C.tbuf;
   {
@@ -184,11 +189,11 @@ __device__ __forceinline__ int code_block(const TileCtx &C, int lane, int bx, in
   }
   store_row<B>(rec_row, rec);
   // neighbour context for the blocks to come
-  C.left[y + lane] = (uint16_t)rec[B - 1];
+  C.left[y + lane] = (ES)rec[B - 1];
   if (lane == B - 1) {
 #pragma unroll
-    for (int c = 0; c < B; c++) C.above[x + c] = (uint16_t)rec[c];
-    C.br[by * n + bx] = (uint16_t)rec[B - 1];
+    for (int c = 0; c < B; c++) C.above[x + c] = (ES)rec[c];
+    C.br[by * n + bx] = (ES)rec[B - 1];
   }
   AV1MI_GROUP_SYNC();
   return best_mode;
@@ -197,13 +202,17 @@ __device__ __forceinline__ int code_block(const TileCtx &C, int lane, int bx, in
 template <int BS, typename Pix>
 __global__ __launch_bounds__(256) void k_intra_pipe(IntraPipeLaunch L) {
   constexpr int CS = BS / 2, N = 64 / BS, TPW = 256 / BS;
-  constexpr int ELY = edge_len(BS, BS), ELC = edge_len(CS, CS);
-  // per-tile LDS, uint16 units then int32 transpose buffer
-  constexpr int EDGE_U16 = 4 * ELY > 8 * ELC ? 4 * ELY : 8 * ELC;   // luma and chroma blocks alternate: one region
-  constexpr int U16_PER_TILE = (64 + 64 + N * N) + 2 * (32 + 32 + N * N) + EDGE_U16 + 2 * N * N /* mode ctx as u16 */;
-  constexpr int T32_PER_TILE = BS * (BS + 4);
+  using ES = Pix;                                      // LDS sample type: 1 byte for 8-bit content, 2 for 10-bit
+  constexpr int ELY = fast_edge_len(BS), ELC = fast_edge_len(CS);
+  constexpr int EDGE_N = ELY > 2 * ELC ? ELY : 2 * ELC;   // luma and chroma blocks alternate: one region
+  // entries per tile: line buffers + bottom-right samples (Y, U, V), edge region, two mode maps (one byte each)
+  constexpr int CTX_N = (64 + 64 + N * N) + 2 * (32 + 32 + N * N) + EDGE_N;
+  constexpr int CTX_BYTES_RAW = CTX_N * (int)sizeof(ES) + 2 * N * N;
+  // per-tile strides padded so that the tiles of a wave (which run in lockstep at equal offsets) start 4 banks apart
+  constexpr int CTX_BYTES = ((CTX_BYTES_RAW + 127) / 128) * 128 + 16;
+  constexpr int T32_PER_TILE = ((BS * (BS + 4) + 31) / 32) * 32 + 8;
   __shared__ __attribute__((aligned(16))) int32_t tbufs[TPW * T32_PER_TILE];
-  __shared__ __attribute__((aligned(16))) uint16_t ctx16[TPW * U16_PER_TILE];
+  __shared__ __attribute__((aligned(16))) unsigned char ctxb[TPW * CTX_BYTES];
 
   const int grp = threadIdx.x / BS, lane = threadIdx.x % BS;
   const int sbw = (L.w + 63) / 64, sbh = (L.h + 63) / 64;
@@ -212,15 +221,15 @@ __global__ __launch_bounds__(256) void k_intra_pipe(IntraPipeLaunch L) {
   const int f = (int)(tile / (sbw * sbh)), sb = (int)(tile % (sbw * sbh)), sby = sb / sbw, sbx = sb % sbw;
   const int bw = L.w / BS, bh = L.h / BS;
 
-  uint16_t *u = ctx16 + grp * U16_PER_TILE;
-  TileCtx Y, Cp;   // Cp: this lane's chroma plane (U for the lower half of the group, V for the upper)
+  ES *u = reinterpret_cast<ES *>(ctxb + grp * CTX_BYTES);
+  TileCtx<ES> Y, Cp;   // Cp: this lane's chroma plane (U for the lower half of the group, V for the upper)
   Y.above = u; Y.left = u + 64; Y.br = u + 128; u += 128 + N * N;
   const int pl = lane / CS, cl = lane % CS;
-  uint16_t *cu = u + pl * (64 + N * N);
+  ES *cu = u + pl * (64 + N * N);
   Cp.above = cu; Cp.left = cu + 32; Cp.br = cu + 64; u += 2 * (64 + N * N);
   Y.edge = u;
-  Cp.edge = u + pl * 4 * ELC; u += EDGE_U16;
-  uint16_t *mode_y = u, *mode_c = u + N * N;
+  Cp.edge = u + pl * ELC; u += EDGE_N;
+  uint8_t *mode_y = reinterpret_cast<uint8_t *>(u), *mode_c = mode_y + N * N;
   Y.tbuf = tbufs + grp * T32_PER_TILE;
   Cp.tbuf = Y.tbuf + pl * (CS * (CS + 4));
 
@@ -250,14 +259,14 @@ __global__ __launch_bounds__(256) void k_intra_pipe(IntraPipeLaunch L) {
       const int m = code_block<BS, BS, Pix>(Y, lane, bx, by, N, have_top ? BS : 0, have_tr ? BS : 0, have_left ? BS : 0,
                                              have_bl ? BS : 0, ft, L.dc_q, L.ac_q, src_y + off, rec_y + off,
                                              lev_y + blk * BS * BS + lane * BS);
-      if (lane == 0) { modes_y[blk] = (uint8_t)m; mode_y[by * N + bx] = (uint16_t)m; }
+      if (lane == 0) { modes_y[blk] = (uint8_t)m; mode_y[by * N + bx] = (uint8_t)m; }
     }
     {
       const size_t off = ((size_t)fy * CS + cl) * L.stride_uv + (size_t)fx * CS;
       const int m = code_block<CS, BS, Pix>(Cp, cl, bx, by, N, have_top ? CS : 0, have_tr ? CS : 0, have_left ? CS : 0,
                                              have_bl ? CS : 0, ftc, L.dc_q, L.ac_q, src_c + off, rec_c + off,
                                              lev_c + blk * CS * CS + cl * CS);
-      if (lane == 0) { modes_uv[blk] = (uint8_t)m; mode_c[by * N + bx] = (uint16_t)m; }
+      if (lane == 0) { modes_uv[blk] = (uint8_t)m; mode_c[by * N + bx] = (uint8_t)m; }
     }
     AV1MI_GROUP_SYNC();
   }
