@@ -19,6 +19,7 @@
 // (candidate list, SAD, first-minimum tie break, DCT_DCT, tile = superblock) is this project's own and is
 // mirrored by oracle/av1o_pipeline.c:av1o_intra_encode_frame for checking.  The reference has no counterpart
 // (internal/ffmpeg/transcode.go:120 hands the whole job to an external encoder).
+#include <type_traits>
 #include "intra_fast.hpp"
 #include "txfm_cfg.hpp"
 #include "av1mi_internal.hpp"
@@ -88,32 +89,30 @@ __device__ __forceinline__ int code_block(const TileCtx<Pix> &C, int lane, int b
   };
   int s[B], bp[B];
   load_row<B>(src_row, s);
-  // all edge variants of the block in two LDS phases, then 11 predictions without further hand-offs
+  // all edge variants of the block in two LDS phases, then 11 compile-time-specialised predictions, no hand-offs
   fast_build<B>(C.edge, lane, bd, n_top, n_topright, n_left, n_bottomleft, filter_type, fetch);
   int best = 0x7fffffff, best_mode = 0;
-  for (int ci = 0; ci < 11; ci++) {
-    const FastMode M = fast_mode_setup<B>(kCand[ci], bd, n_top, n_left, filter_type, fetch);
-    IntraBlk blk;
-    blk.mode = M.mode; blk.angle_delta = 0; blk.disable_edge_filter = 0; blk.filter_type = filter_type;
-    blk.n_top = n_top; blk.n_topright = n_topright; blk.n_left = n_left; blk.n_bottomleft = n_bottomleft;
-    IntraEdges E;
-    E.p_angle = M.p_angle; E.is_dr = M.is_dr; E.flat = M.flat; E.flat_val = M.flat_val;
-    E.upsample_above = M.upsample_above; E.upsample_left = M.upsample_left; E.have_top = n_top > 0; E.have_left = n_left > 0;
-    const ES *above_e, *left_e;
-    fast_arrays<B>((const ES *)C.edge, M, above_e, left_e);
+  auto eval = [&](auto mode_tag) {
+    constexpr int MODE = decltype(mode_tag)::value;
     int out[B];
-    intra_pred_row<B, B, ES>(blk, E, bd, lane, above_e, left_e, out);
+    fast_pred_row<MODE, B, ES>((const ES *)C.edge, lane, bd, n_top, n_left, filter_type, out);
     int sad = 0;
 #pragma unroll
     for (int c = 0; c < B; c++) sad += abs(s[c] - out[c]);
 #pragma unroll
     for (int o = GW / 2; o >= 1; o >>= 1) sad += __shfl_xor(sad, o, GW);
-    if (sad < best) {
-      best = sad; best_mode = M.mode;
+    const bool better = sad < best;
+    best = better ? sad : best; best_mode = better ? MODE : best_mode;
 #pragma unroll
-      for (int c = 0; c < B; c++) bp[c] = out[c];
-    }
-  }
+    for (int c = 0; c < B; c++) bp[c] = better ? out[c] : bp[c];
+  };
+  // candidate order == kCand == oracle/av1o_pipeline.c:intra_candidates (first minimum wins)
+  eval(std::integral_constant<int, DC_PRED>{});   eval(std::integral_constant<int, V_PRED>{});
+  eval(std::integral_constant<int, H_PRED>{});    eval(std::integral_constant<int, D45_PRED>{});
+  eval(std::integral_constant<int, D135_PRED>{}); eval(std::integral_constant<int, D113_PRED>{});
+  eval(std::integral_constant<int, D157_PRED>{}); eval(std::integral_constant<int, D203_PRED>{});
+  eval(std::integral_constant<int, D67_PRED>{});  eval(std::integral_constant<int, SMOOTH_PRED>{});
+  eval(std::integral_constant<int, PAETH_PRED>{});
   AV1MI_GROUP_SYNC();
   // forward transform (libaom fwd_txfm2d_c: columns, then rows), DCT_DCT
   int32_t *T = C.tbuf;
