@@ -58,6 +58,16 @@ class IntraJob(C.Structure):
                 ("d_modes_y", C.c_void_p), ("d_modes_uv", C.c_void_p)]
 
 
+class InterJob(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("bit_depth", C.c_int), ("nframes", C.c_int), ("qindex", C.c_int),
+                ("search_range", C.c_int), ("stride_y", C.c_int), ("stride_uv", C.c_int),
+                ("d_src_y", C.c_void_p), ("d_src_u", C.c_void_p), ("d_src_v", C.c_void_p),
+                ("d_ref_y", C.c_void_p), ("d_ref_u", C.c_void_p), ("d_ref_v", C.c_void_p),
+                ("d_rec_y", C.c_void_p), ("d_rec_u", C.c_void_p), ("d_rec_v", C.c_void_p),
+                ("d_lev_y", C.c_void_p), ("d_lev_u", C.c_void_p), ("d_lev_v", C.c_void_p),
+                ("d_mvs", C.c_void_p), ("d_skip", C.c_void_p)]
+
+
 _lib = None
 
 
@@ -282,6 +292,36 @@ class Context:
                    rec_v=bufs["rec_v"].download(V.shape, dt), lev_y=bufs["lev_y"].download((nf, nb, bs, bs), np.int16),
                    lev_u=bufs["lev_u"].download((nf, nb, cs, cs), np.int16), lev_v=bufs["lev_v"].download((nf, nb, cs, cs), np.int16),
                    modes_y=bufs["modes_y"].download((nf, nb), np.uint8), modes_uv=bufs["modes_uv"].download((nf, nb), np.uint8))
+        for b in bufs.values():
+            b.free()
+        return out
+
+    # ---- inter (P-frame) pipeline
+    def inter_encode(self, job):
+        self._chk(self.lib.av1mi_inter_encode(self.h, C.byref(job)))
+
+    def inter_encode_arrays(self, src, ref, bd, qindex, search_range=8):
+        """tests: src / ref = (Y, U, V) with arrays [frames, h, w]; returns dict like the oracle's"""
+        dt = np.uint8 if bd == 8 else np.uint16
+        S = [np.ascontiguousarray(a, dt) for a in src]
+        R = [np.ascontiguousarray(a, dt) for a in ref]
+        nf, h, w = S[0].shape
+        nb = (h // 8) * (w // 8)
+        bufs = {}
+        for i, p in enumerate("yuv"):
+            bufs["src_" + p], bufs["ref_" + p] = self.to_device(S[i]), self.to_device(R[i])
+            bufs["rec_" + p] = self.alloc(S[i].nbytes)
+            bufs["lev_" + p] = self.alloc(S[i].size * 2)
+        bufs["mvs"], bufs["skip"] = self.alloc(nf * nb * 4), self.alloc(nf * nb)
+        job = InterJob(w, h, bd, nf, qindex, search_range, w, w // 2)
+        for k, b in bufs.items():
+            setattr(job, "d_" + k, b.ptr)
+        self.inter_encode(job)
+        out = dict(mvs=bufs["mvs"].download((nf, nb, 2), np.int16), skip=bufs["skip"].download((nf, nb), np.uint8))
+        for i, p in enumerate("yuv"):
+            bs = 8 if i == 0 else 4
+            out["rec_" + p] = bufs["rec_" + p].download(S[i].shape, dt)
+            out["lev_" + p] = bufs["lev_" + p].download((nf, nb, bs, bs), np.int16)
         for b in bufs.values():
             b.free()
         return out

@@ -69,6 +69,14 @@ struct LrLaunch {
 };
 hipError_t launch_lr(const LrLaunch &L, hipStream_t s);
 
+// inter (P-frame) pipeline over the t-th frames of a batch of segments, stacked like the intra job
+struct InterLaunch {
+  const void *src[3]; const void *ref[3]; void *rec[3]; int16_t *lev[3];
+  int16_t *mvs; uint8_t *skip;
+  int w, h, stride_y, stride_uv, bd, nframes, dc_q, ac_q, range;
+};
+hipError_t launch_inter(const InterLaunch &L, hipStream_t s);
+
 int tx_width(int tx_size);
 int tx_height(int tx_size);
 hipError_t launch_inv_txfm(int tx_size, const TxLaunch &L, int bd, hipStream_t s);

@@ -389,6 +389,32 @@ int av1mi_intra_encode(av1mi_ctx *ctx, const av1mi_intra_job *j) {
   return AV1MI_OK;
 }
 
+int av1mi_inter_encode(av1mi_ctx *ctx, const av1mi_inter_job *j) {
+  BIND(ctx);
+  if (!j) return fail(ctx, AV1MI_E_INVAL, "null job");
+  if (j->bit_depth != 8 && j->bit_depth != 10) return fail(ctx, AV1MI_E_INVAL, "bit depth %d not supported (8 or 10)", j->bit_depth);
+  if (j->width <= 0 || j->height <= 0 || (j->width & 7) || (j->height & 7) || j->width > 16384 || j->height > 16384)
+    return fail(ctx, AV1MI_E_INVAL, "frame %dx%d must be a multiple of 8", j->width, j->height);
+  if (j->nframes < 0 || j->nframes > 65535 || j->qindex < 0 || j->qindex > 255 || j->search_range < 0 || j->search_range > 15)
+    return fail(ctx, AV1MI_E_INVAL, "bad nframes/qindex/search_range");
+  if (j->stride_y < j->width || j->stride_uv < j->width / 2 || (j->stride_y & 3) || (j->stride_uv & 3))
+    return fail(ctx, AV1MI_E_INVAL, "bad strides %d/%d", j->stride_y, j->stride_uv);
+  const void *ptrs[] = { j->d_src_y, j->d_src_u, j->d_src_v, j->d_ref_y, j->d_ref_u, j->d_ref_v, j->d_rec_y, j->d_rec_u, j->d_rec_v,
+                         j->d_lev_y, j->d_lev_u, j->d_lev_v, j->d_mvs, j->d_skip };
+  for (const void *p : ptrs) if (!p || ((uintptr_t)p & 7)) return fail(ctx, AV1MI_E_INVAL, "null or misaligned device pointer");
+  if (j->d_ref_y == j->d_rec_y || j->d_ref_u == j->d_rec_u || j->d_ref_v == j->d_rec_v) return fail(ctx, AV1MI_E_INVAL, "reference and reconstruction must differ");
+  av1mi::InterLaunch L;
+  L.src[0] = j->d_src_y; L.src[1] = j->d_src_u; L.src[2] = j->d_src_v;
+  L.ref[0] = j->d_ref_y; L.ref[1] = j->d_ref_u; L.ref[2] = j->d_ref_v;
+  L.rec[0] = j->d_rec_y; L.rec[1] = j->d_rec_u; L.rec[2] = j->d_rec_v;
+  L.lev[0] = j->d_lev_y; L.lev[1] = j->d_lev_u; L.lev[2] = j->d_lev_v;
+  L.mvs = j->d_mvs; L.skip = j->d_skip;
+  L.w = j->width; L.h = j->height; L.stride_y = j->stride_y; L.stride_uv = j->stride_uv; L.bd = j->bit_depth; L.nframes = j->nframes;
+  L.dc_q = av1mi_dc_q(j->qindex, j->bit_depth); L.ac_q = av1mi_ac_q(j->qindex, j->bit_depth); L.range = j->search_range;
+  { ProfScope ps(ctx, AV1MI_K_INTER_PIPE); HIP_TRY(ctx, av1mi::launch_inter(L, ctx->stream)); }
+  return AV1MI_OK;
+}
+
 int av1mi_dc_q(int qindex, int bd) {
   const int q = qindex < 0 ? 0 : qindex > 255 ? 255 : qindex;
   return bd == 8 ? av1mi::k_dc_q8[q] : av1mi::k_dc_q10[q];

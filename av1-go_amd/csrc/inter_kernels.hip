@@ -1,0 +1,249 @@
+// inter_kernels.hip — the inter (P-frame) block pipeline of BASELINE config 3 as two gfx950 kernels:
+//
+//   k_me_int     integer motion search.  One workgroup per 64x64 luma tile: source tile and the reference window
+//                (tile + search range, coordinates clamped = the spec's edge extension) staged in LDS; one 8x8 block
+//                per wave at a time, ONE CANDIDATE VECTOR PER LANE, the 64 source samples broadcast from LDS;
+//                (SAD, raster rank) packed into one integer and min-reduced across the wave with xor-shuffles.
+//   k_inter_pipe per block, 8 lanes of one wave (8 blocks per wave, no dependency between blocks): half- and
+//                quarter-pel refinement with the real 8-tap sub-pel filter (K4 arithmetic, window in LDS), final
+//                luma + chroma motion compensation, then the shared residual tail (K1 + K8 + K2, block_code.hpp),
+//                skip flag and final vector.
+// Inter blocks only depend on the PREVIOUS frame, so a P frame is embarrassingly parallel; the serial dependency is
+// frame-to-frame inside a GOP and the pipeline batches the t-th frames of many segments into one launch.
+// HBM traffic per sample (k_inter_pipe): source b + reference window (L2-served after first touch) ~b + reconstruction
+// b + levels 2.
+//
+// Arithmetic: AV1 spec §7.11.3.4 (see mc_kernels.hip) + §7.13.3 / §7.12.3; search policy is this project's own and
+// mirrored by oracle/av1o_pipeline.c:av1o_inter_encode_frame.  Reference tree: nothing (transcode.go:120).
+#include "block_code.hpp"
+#include "av1mi_internal.hpp"
+
+namespace av1mi {
+
+// regular 8-tap (Subpel_Filters[0]) and regular 4-tap (Subpel_Filters[4]) rows, the only ones this encoder policy uses
+__constant__ int16_t kRegular8[16][8] = {
+  { 0, 0, 0, 128, 0, 0, 0, 0 }, { 0, 2, -6, 126, 8, -2, 0, 0 }, { 0, 2, -10, 122, 18, -4, 0, 0 }, { 0, 2, -12, 116, 28, -8, 2, 0 },
+  { 0, 2, -14, 110, 38, -10, 2, 0 }, { 0, 2, -14, 102, 48, -12, 2, 0 }, { 0, 2, -16, 94, 58, -12, 2, 0 }, { 0, 2, -14, 84, 66, -12, 2, 0 },
+  { 0, 2, -14, 76, 76, -14, 2, 0 }, { 0, 2, -12, 66, 84, -14, 2, 0 }, { 0, 2, -12, 58, 94, -16, 2, 0 }, { 0, 2, -12, 48, 102, -14, 2, 0 },
+  { 0, 2, -10, 38, 110, -14, 2, 0 }, { 0, 2, -8, 28, 116, -12, 2, 0 }, { 0, 0, -4, 18, 122, -10, 2, 0 }, { 0, 0, -2, 8, 126, -6, 2, 0 } };
+__constant__ int16_t kRegular4[16][8] = {
+  { 0, 0, 0, 128, 0, 0, 0, 0 }, { 0, 0, -4, 126, 8, -2, 0, 0 }, { 0, 0, -8, 122, 18, -4, 0, 0 }, { 0, 0, -10, 116, 28, -6, 0, 0 },
+  { 0, 0, -12, 110, 38, -8, 0, 0 }, { 0, 0, -12, 102, 48, -10, 0, 0 }, { 0, 0, -14, 94, 58, -10, 0, 0 }, { 0, 0, -12, 84, 66, -10, 0, 0 },
+  { 0, 0, -12, 76, 76, -12, 0, 0 }, { 0, 0, -10, 66, 84, -12, 0, 0 }, { 0, 0, -10, 58, 94, -14, 0, 0 }, { 0, 0, -10, 48, 102, -12, 0, 0 },
+  { 0, 0, -8, 38, 110, -12, 0, 0 }, { 0, 0, -6, 28, 116, -10, 0, 0 }, { 0, 0, -4, 18, 122, -8, 0, 0 }, { 0, 0, -2, 8, 126, -4, 0, 0 } };
+
+// ------------------------------------------------------------------------------------------ integer search
+template <typename Pix>
+__global__ __launch_bounds__(256) void k_me_int(InterLaunch L) {
+  constexpr int MAXR = 15, WS = 64 + 2 * MAXR + 2;   // window row stride
+  __shared__ Pix win[(64 + 2 * MAXR) * WS];
+  __shared__ Pix srct[64 * 64];
+  const int tid = threadIdx.x, R = L.range, WD = 64 + 2 * R, NC = 2 * R + 1;
+  const int sbw = (L.w + 63) / 64;
+  const int f = blockIdx.y, sb = blockIdx.x, sby = sb / sbw, sbx = sb % sbw;
+  const Pix *src = reinterpret_cast<const Pix *>(L.src[0]) + (size_t)f * L.h * L.stride_y;
+  const Pix *ref = reinterpret_cast<const Pix *>(L.ref[0]) + (size_t)f * L.h * L.stride_y;
+  for (int i = tid; i < WD * WD; i += 256) {
+    const int r = i / WD, c = i - r * WD;
+    const int fy = min(max(sby * 64 - R + r, 0), L.h - 1), fx = min(max(sbx * 64 - R + c, 0), L.w - 1);
+    win[r * WS + c] = ref[(size_t)fy * L.stride_y + fx];
+  }
+  for (int i = tid; i < 64 * 64; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    const int fy = min(sby * 64 + r, L.h - 1), fx = min(sbx * 64 + c, L.w - 1);
+    srct[i] = src[(size_t)fy * L.stride_y + fx];
+  }
+  __syncthreads();
+  const int wave = tid >> 6, lane = tid & 63;
+  const int bw = L.w / 8, bh = L.h / 8;
+  int16_t *mvs = L.mvs + (size_t)f * bw * bh * 2;
+  for (int b = wave; b < 64; b += 4) {   // 16 blocks per wave
+    const int by = b >> 3, bx = b & 7;
+    const int fbx = sbx * 8 + bx, fby = sby * 8 + by;
+    if (fbx >= bw || fby >= bh) continue;
+    unsigned best = 0xFFFFFFFFu;
+    for (int c0 = 0; c0 < NC * NC; c0 += 64) {
+      const int cand = c0 + lane;
+      if (cand < NC * NC) {
+        const int dy = cand / NC - R, dx = cand - (cand / NC) * NC - R;
+        const Pix *p = win + (by * 8 + dy + R) * WS + bx * 8 + dx + R;
+        const Pix *s = srct + (by * 8) * 64 + bx * 8;
+        int sad = 0;
+#pragma unroll
+        for (int r = 0; r < 8; r++)
+#pragma unroll
+          for (int c = 0; c < 8; c++) sad += abs((int)s[r * 64 + c] - (int)p[r * WS + c]);
+        // (0,0) ranks first, the others in raster order; ties keep the lower rank
+        const unsigned key = (unsigned)sad * 1024u + ((dx | dy) ? (unsigned)cand + 1u : 0u);
+        best = min(best, key);
+      }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) best = min(best, (unsigned)__shfl_xor((int)best, o, 64));
+    if (lane == 0) {
+      const int rank = best & 1023;
+      const int dy = rank ? (rank - 1) / NC - R : 0, dx = rank ? (rank - 1) % NC - R : 0;
+      mvs[((size_t)fby * bw + fbx) * 2] = (int16_t)(dx * 8);
+      mvs[((size_t)fby * bw + fbx) * 2 + 1] = (int16_t)(dy * 8);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ refinement + coding
+// 2-D sub-pel prediction of row `lane` of a B x B block from a window in LDS (origin = integer position - 4, i.e. the
+// window starts 4 samples left of / above the integer-vector block): posx/posy = displacement from the window's block
+// origin in 1/16 samples, in [-16, 15].  im: (B+7) x B int16 scratch of the group.  NL = lanes of the block.
+template <int B, typename ES>
+__device__ __forceinline__ void mc_row(const ES *win, int ws, int16_t *im, int lane, int posx, int posy, const int16_t (*filt)[8], int bd,
+                                       int *out) {
+  const int ox = 4 + (posx >> 4) - 3, oy = 4 + (posy >> 4) - 3;   // window column / row of tap 0 of sample (0,0)
+  int fx[8], fy[8];
+#pragma unroll
+  for (int t = 0; t < 8; t++) { fx[t] = filt[posx & 15][t]; fy[t] = filt[posy & 15][t]; }
+#pragma unroll
+  for (int it = 0; it < (2 * B + 6) / B; it++) {   // B + 7 intermediate rows over B lanes
+    const int j = lane + it * B;
+    if (j < B + 7) {
+      const ES *p = win + (oy + j) * ws + ox;
+#pragma unroll
+      for (int c = 0; c < B; c++) {
+        int s = 0;
+#pragma unroll
+        for (int t = 0; t < 8; t++) s += fx[t] * (int)p[c + t];
+        im[j * B + c] = (int16_t)((s + 4) >> 3);
+      }
+    }
+  }
+  AV1MI_GROUP_SYNC();
+  const int maxpix = (1 << bd) - 1;
+#pragma unroll
+  for (int c = 0; c < B; c++) {
+    int s = 0;
+#pragma unroll
+    for (int t = 0; t < 8; t++) s += fy[t] * (int)im[(lane + t) * B + c];
+    out[c] = min(max((s + 1024) >> 11, 0), maxpix);
+  }
+  AV1MI_GROUP_SYNC();
+}
+
+template <typename Pix>
+__global__ __launch_bounds__(256) void k_inter_pipe(InterLaunch L) {
+  using ES = Pix;
+  constexpr int bd = sizeof(Pix) == 1 ? 8 : 10;
+  constexpr int GPW = 32;                        // groups (blocks) per workgroup
+  constexpr int YW = 16, YWS = 18;               // luma window 16 x 16 (integer vector -4 .. +11), padded stride
+  constexpr int CW = 12, CWS = 14;               // chroma window 12 x 12 (chroma integer position -4 .. +7)
+  constexpr int WIN_N = YW * YWS + 2 * CW * CWS;
+  constexpr int WIN_BYTES = ((WIN_N * (int)sizeof(ES) + 127) / 128) * 128 + 16;
+  constexpr int IM_N = 15 * 8 + 8;               // luma intermediate 15 x 8 (chroma 2 x 11 x 4 fits inside)
+  constexpr int T_N = ((8 * 12 + 31) / 32) * 32 + 8;
+  __shared__ __attribute__((aligned(16))) unsigned char winb[GPW * WIN_BYTES];
+  __shared__ __attribute__((aligned(16))) int16_t imb[GPW * IM_N];
+  __shared__ __attribute__((aligned(16))) int32_t tb[GPW * T_N];
+
+  const int grp = threadIdx.x >> 3, lane = threadIdx.x & 7;
+  const int bw = L.w / 8, bh = L.h / 8;
+  const long long blk_all = (long long)blockIdx.x * GPW + grp;
+  if (blk_all >= (long long)L.nframes * bw * bh) return;
+  const int f = (int)(blk_all / (bw * bh)), blk = (int)(blk_all % (bw * bh)), by = blk / bw, bx = blk % bw;
+  const int x = bx * 8, y = by * 8;
+  ES *wy = reinterpret_cast<ES *>(winb + grp * WIN_BYTES);
+  int16_t *im = imb + grp * IM_N;
+  int32_t *T = tb + grp * T_N;
+
+  const Pix *src_y = reinterpret_cast<const Pix *>(L.src[0]) + (size_t)f * L.h * L.stride_y;
+  const Pix *ref_y = reinterpret_cast<const Pix *>(L.ref[0]) + (size_t)f * L.h * L.stride_y;
+  Pix *rec_y = reinterpret_cast<Pix *>(L.rec[0]) + (size_t)f * L.h * L.stride_y;
+  int16_t *mvs = L.mvs + ((size_t)f * bw * bh + blk) * 2;
+  const int imx = mvs[0] >> 3, imy = mvs[1] >> 3;   // integer vector from k_me_int (multiples of 8)
+
+  // luma window: samples (x + imx - 4 .. +11, y + imy - 4 .. +11), clamped into the plane
+#pragma unroll
+  for (int it = 0; it < 2; it++) {
+    const int r = lane + it * 8;
+    const int fy = min(max(y + imy - 4 + r, 0), L.h - 1);
+    const Pix *row = ref_y + (size_t)fy * L.stride_y;
+#pragma unroll
+    for (int c = 0; c < YW; c++) wy[r * YWS + c] = row[min(max(x + imx - 4 + c, 0), L.w - 1)];
+  }
+  int s[8], bp[8], out[8];
+  load_row<8>(src_y + (size_t)(y + lane) * L.stride_y + x, s);
+  AV1MI_GROUP_SYNC();
+  auto sad_of = [&](const int *o) {
+    int v = 0;
+#pragma unroll
+    for (int c = 0; c < 8; c++) v += abs(s[c] - o[c]);
+#pragma unroll
+    for (int off = 4; off >= 1; off >>= 1) v += __shfl_xor(v, off, 8);
+    return v;
+  };
+  // candidate 0: the integer vector itself
+  mc_row<8, ES>(wy, YWS, im, lane, 0, 0, kRegular8, bd, bp);
+  int best = sad_of(bp), bfx = 0, bfy = 0;     // fractional part in 1/8 samples relative to the integer vector
+  for (int step = 4; step >= 2; step >>= 1) {
+    const int cx = bfx, cy = bfy;
+#pragma unroll 1
+    for (int k = 0; k < 9; k++) {
+      if (k == 4) continue;
+      const int fx = cx + (k % 3 - 1) * step, fy = cy + (k / 3 - 1) * step;
+      mc_row<8, ES>(wy, YWS, im, lane, fx * 2, fy * 2, kRegular8, bd, out);
+      const int sd = sad_of(out);
+      const bool better = sd < best;
+      best = better ? sd : best; bfx = better ? fx : bfx; bfy = better ? fy : bfy;
+#pragma unroll
+      for (int c = 0; c < 8; c++) bp[c] = better ? out[c] : bp[c];
+    }
+  }
+  const int mvx = imx * 8 + bfx, mvy = imy * 8 + bfy;   // final vector, 1/8 luma samples
+  if (lane == 0) { mvs[0] = (int16_t)mvx; mvs[1] = (int16_t)mvy; }
+  int rec[8];
+  int nz = code_residual<8, Pix>(T, lane, s, bp, L.dc_q, L.ac_q, L.lev[0] + (size_t)f * L.w * L.h + (size_t)blk * 64 + lane * 8, rec);
+  store_row<8>(rec_y + (size_t)(y + lane) * L.stride_y + x, rec);
+
+  // chroma: lanes 0-3 code the U block, lanes 4-7 the V block (4x4 each, 4-tap regular filter rows)
+  {
+    const int pl = lane >> 2, cl = lane & 3;
+    const int cw = L.w / 2, chh = L.h / 2, cx0 = x / 2, cy0 = y / 2;
+    const Pix *src_c = reinterpret_cast<const Pix *>(L.src[1 + pl]) + (size_t)f * chh * L.stride_uv;
+    const Pix *ref_c = reinterpret_cast<const Pix *>(L.ref[1 + pl]) + (size_t)f * chh * L.stride_uv;
+    Pix *rec_c = reinterpret_cast<Pix *>(L.rec[1 + pl]) + (size_t)f * chh * L.stride_uv;
+    // the vector in 1/16 chroma samples is the luma vector in 1/8 luma samples
+    const int cix = mvx >> 4, ciy = mvy >> 4;         // integer chroma displacement (floor)
+    ES *wc = wy + YW * YWS + pl * CW * CWS;
+#pragma unroll
+    for (int it = 0; it < 3; it++) {
+      const int r = cl + it * 4;
+      const int fy = min(max(cy0 + ciy - 4 + r, 0), chh - 1);
+      const Pix *row = ref_c + (size_t)fy * L.stride_uv;
+#pragma unroll
+      for (int c = 0; c < CW; c++) wc[r * CWS + c] = row[min(max(cx0 + cix - 4 + c, 0), cw - 1)];
+    }
+    int sc[4], pc[4], rc[4];
+    load_row<4>(src_c + (size_t)(cy0 + cl) * L.stride_uv + cx0, sc);
+    AV1MI_GROUP_SYNC();
+    mc_row<4, ES>(wc, CWS, im + pl * (11 * 4 + 4), cl, mvx & 15, mvy & 15, kRegular4, bd, pc);
+    nz |= code_residual<4, Pix>(T + pl * 32, cl, sc, pc, L.dc_q, L.ac_q,
+                                L.lev[1 + pl] + (size_t)f * cw * chh + (size_t)blk * 16 + cl * 4, rc);
+    store_row<4>(rec_c + (size_t)(cy0 + cl) * L.stride_uv + cx0, rc);
+  }
+#pragma unroll
+  for (int off = 4; off >= 1; off >>= 1) nz |= __shfl_xor(nz, off, 8);
+  if (lane == 0) L.skip[(size_t)f * bw * bh + blk] = nz == 0;
+}
+
+hipError_t launch_inter(const InterLaunch &L, hipStream_t s) {
+  if (L.nframes <= 0) return hipSuccess;
+  const int sbs = ((L.w + 63) / 64) * ((L.h + 63) / 64);
+  const long long blocks = (long long)L.nframes * (L.w / 8) * (L.h / 8);
+  const dim3 g1(sbs, L.nframes), g2((unsigned)((blocks + 31) / 32));
+  if (L.bd == 8) {
+    hipLaunchKernelGGL(k_me_int<uint8_t>, g1, dim3(256), 0, s, L);
+    hipLaunchKernelGGL(k_inter_pipe<uint8_t>, g2, dim3(256), 0, s, L);
+  } else {
+    hipLaunchKernelGGL(k_me_int<uint16_t>, g1, dim3(256), 0, s, L);
+    hipLaunchKernelGGL(k_inter_pipe<uint16_t>, g2, dim3(256), 0, s, L);
+  }
+  return hipGetLastError();
+}
+
+}  // namespace av1mi

@@ -21,7 +21,7 @@
 // (internal/ffmpeg/transcode.go:120 hands the whole job to an external encoder).
 #include <type_traits>
 #include "intra_fast.hpp"
-#include "txfm_cfg.hpp"
+#include "block_code.hpp"
 #include "av1mi_internal.hpp"
 
 namespace av1mi {
@@ -34,35 +34,6 @@ __device__ __forceinline__ unsigned morton2(unsigned x, unsigned y) {
 #pragma unroll
   for (int i = 0; i < 4; i++) m |= ((x >> i) & 1u) << (2 * i) | ((y >> i) & 1u) << (2 * i + 1);
   return m;
-}
-
-template <int N, typename Pix> __device__ __forceinline__ void load_row(const Pix *p, int *v) {
-  if constexpr (sizeof(Pix) == 1) {
-#pragma unroll
-    for (int c = 0; c < N; c += 4) {
-      const uint32_t u = *reinterpret_cast<const uint32_t *>(p + c);
-      v[c] = u & 255; v[c + 1] = (u >> 8) & 255; v[c + 2] = (u >> 16) & 255; v[c + 3] = u >> 24;
-    }
-  } else {
-#pragma unroll
-    for (int c = 0; c < N; c += 4) {
-      const uint2 u = *reinterpret_cast<const uint2 *>(p + c);
-      v[c] = u.x & 0xffff; v[c + 1] = u.x >> 16; v[c + 2] = u.y & 0xffff; v[c + 3] = u.y >> 16;
-    }
-  }
-}
-template <int N, typename Pix> __device__ __forceinline__ void store_row(Pix *p, const int *v) {
-  if constexpr (sizeof(Pix) == 1) {
-#pragma unroll
-    for (int c = 0; c < N; c += 4)
-      *reinterpret_cast<uint32_t *>(p + c) = (uint32_t)v[c] | ((uint32_t)v[c + 1] << 8) | ((uint32_t)v[c + 2] << 16) | ((uint32_t)v[c + 3] << 24);
-  } else {
-#pragma unroll
-    for (int c = 0; c < N; c += 4) {
-      uint2 u; u.x = (uint32_t)v[c] | ((uint32_t)v[c + 1] << 16); u.y = (uint32_t)v[c + 2] | ((uint32_t)v[c + 3] << 16);
-      *reinterpret_cast<uint2 *>(p + c) = u;
-    }
-  }
 }
 
 // per-plane, per-tile neighbour context in LDS (indices in samples / blocks of that plane); ES = sample type
@@ -114,78 +85,8 @@ __device__ __forceinline__ int code_block(const TileCtx<Pix> &C, int lane, int b
   eval(std::integral_constant<int, D67_PRED>{});  eval(std::integral_constant<int, SMOOTH_PRED>{});
   eval(std::integral_constant<int, PAETH_PRED>{});
   AV1MI_GROUP_SYNC();
-  // forward transform (libaom fwd_txfm2d_c: columns, then rows), DCT_DCT
-  int32_t *T = C.tbuf;
-  {
-    int4 *row = reinterpret_cast<int4 *>(T + lane * RS);
-#pragma unroll
-    for (int c = 0; c < B; c += 4) row[c / 4] = make_int4(s[c] - bp[c], s[c + 1] - bp[c + 1], s[c + 2] - bp[c + 2], s[c + 3] - bp[c + 3]);
-  }
-  AV1MI_GROUP_SYNC();
-  int32_t xv[B];
-#pragma unroll
-  for (int r = 0; r < B; r++) xv[r] = T[r * RS + lane] << fwd_shift(B, B, 0);
-  fdct<B, fwd_cos_bit_col(B, B)>(xv);
-  AV1MI_GROUP_SYNC();
-#pragma unroll
-  for (int r = 0; r < B; r++) T[r * RS + lane] = round2(xv[r], -fwd_shift(B, B, 1));
-  AV1MI_GROUP_SYNC();
-#pragma unroll
-  for (int c = 0; c < B; c += 4) {
-    const int4 v = *reinterpret_cast<const int4 *>(T + lane * RS + c);
-    xv[c] = v.x; xv[c + 1] = v.y; xv[c + 2] = v.z; xv[c + 3] = v.w;
-  }
-  fdct<B, fwd_cos_bit_row(B, B)>(xv);
-  // quantise / dequantise this row (libaom quantize_fp; spec 7.12.3), log_scale 0 for B <= 16
-  const int dc_quant = (1 << 16) / dc_q, ac_quant = (1 << 16) / ac_q, dc_rnd = (64 * dc_q) >> 7, ac_rnd = (64 * ac_q) >> 7;
-  const int maxv = (1 << (7 + bd)) - 1, minv = -(1 << (7 + bd));
-  int lv[B];
-#pragma unroll
-  for (int c = 0; c < B; c++) {
-    const bool dc = lane == 0 && c == 0;
-    const int q = dc ? dc_q : ac_q, quant = dc ? dc_quant : ac_quant, rnd = dc ? dc_rnd : ac_rnd;
-    const int v = round2(xv[c], -fwd_shift(B, B, 2));
-    const bool neg = v < 0;
-    int a = min(neg ? -v : v, 1 << 20), l = 0;
-    if ((a << 1) >= q) { a = min(a + rnd, 32767); l = (a * quant) >> 16; }
-    l = min(l, 32767);
-    lv[c] = neg ? -l : l;
-    const int d = (l * q) & 0xFFFFFF;
-    xv[c] = min(max(neg ? -d : d, minv), maxv);
-  }
-#pragma unroll
-  for (int c = 0; c < B; c += 4) {
-    uint2 o;
-    o.x = (uint32_t)(lv[c] & 0xffff) | ((uint32_t)lv[c + 1] << 16);
-    o.y = (uint32_t)(lv[c + 2] & 0xffff) | ((uint32_t)lv[c + 3] << 16);
-    *reinterpret_cast<uint2 *>(lev_row + c) = o;
-  }
-  // inverse transform (spec 7.13.3: rows, then columns) + reconstruction
-  constexpr int ROW_RANGE = bd + 8;
-#pragma unroll
-  for (int c = 0; c < B; c++) xv[c] = clampr<ROW_RANGE>(xv[c]);
-  idct<B, ROW_RANGE>(xv);
-  AV1MI_GROUP_SYNC();
-#pragma unroll
-  for (int c = 0; c < B; c += 4)
-    *reinterpret_cast<int4 *>(T + lane * RS + c) = make_int4(round2(xv[c], inv_row_shift(B, B)), round2(xv[c + 1], inv_row_shift(B, B)),
-                                                             round2(xv[c + 2], inv_row_shift(B, B)), round2(xv[c + 3], inv_row_shift(B, B)));
-  AV1MI_GROUP_SYNC();
-#pragma unroll
-  for (int r = 0; r < B; r++) xv[r] = min(max(T[r * RS + lane], -32768), 32767);   // max(bd+6,16) = 16 bits for bd <= 10
-  idct<B, 16>(xv);
-  AV1MI_GROUP_SYNC();
-#pragma unroll
-  for (int r = 0; r < B; r++) T[r * RS + lane] = round2(xv[r], 4);
-  AV1MI_GROUP_SYNC();
   int rec[B];
-  const int maxpix = (1 << bd) - 1;
-#pragma unroll
-  for (int c = 0; c < B; c += 4) {
-    const int4 v = *reinterpret_cast<const int4 *>(T + lane * RS + c);
-    rec[c] = min(max(bp[c] + v.x, 0), maxpix); rec[c + 1] = min(max(bp[c + 1] + v.y, 0), maxpix);
-    rec[c + 2] = min(max(bp[c + 2] + v.z, 0), maxpix); rec[c + 3] = min(max(bp[c + 3] + v.w, 0), maxpix);
-  }
+  code_residual<B, Pix>(C.tbuf, lane, s, bp, dc_q, ac_q, lev_row, rec);
   store_row<B>(rec_row, rec);
   // neighbour context for the blocks to come
   C.left[y + lane] = (ES)rec[B - 1];

@@ -208,6 +208,24 @@ typedef struct av1mi_intra_job {
 } av1mi_intra_job;
 int av1mi_intra_encode(av1mi_ctx *ctx, const av1mi_intra_job *job);
 
+/* ---- the inter (P-frame) pipeline (BASELINE config 3): every 8x8 block predicted from ONE reference frame
+ * (the previous reconstructed, loop-filtered frame): integer full search +-search_range (0..15) by SAD, half- and
+ * quarter-pel refinement with the regular 8-tap filter, luma + chroma motion compensation (spec §7.11.3.4), then the
+ * same DCT_DCT residual coding as the intra pipeline.  nframes independent frames are stacked like in av1mi_intra_job
+ * (typically the t-th frames of many closed-GOP segments).  Outputs additionally: one vector per block (int16 x, y in
+ * 1/8 luma samples) and one skip byte per block (1 = no non-zero level in Y, U and V). */
+typedef struct av1mi_inter_job {
+  int width, height, bit_depth, nframes, qindex, search_range;
+  int stride_y, stride_uv;
+  const void *d_src_y, *d_src_u, *d_src_v;
+  const void *d_ref_y, *d_ref_u, *d_ref_v;
+  void *d_rec_y, *d_rec_u, *d_rec_v;
+  int16_t *d_lev_y, *d_lev_u, *d_lev_v;
+  int16_t *d_mvs;       /* nframes * (w/8)*(h/8) * 2 */
+  uint8_t *d_skip;      /* nframes * (w/8)*(h/8) */
+} av1mi_inter_job;
+int av1mi_inter_encode(av1mi_ctx *ctx, const av1mi_inter_job *job);
+
 /* ---- host-pointer single-block forms (SURVEY.md §8b "per-stage test entry points"): copy in, run the
  * same kernels, copy out, synchronous. */
 int av1mi_inv_txfm2d_add(av1mi_ctx *ctx, const int32_t *coef, void *dst, int stride, int tx_size, int tx_type, int bd);

@@ -147,3 +147,87 @@ int av1o_intra_encode_frame(const void *src_y, const void *src_u, const void *sr
       }
   return 0;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Inter (P) frame encoder loop (BASELINE config 3), the checker of k_me_int + k_inter_pipe.
+ * Encoder policy (ours, non-normative): every block bs x bs (8) is inter-predicted from ONE reference frame
+ * (the previous reconstructed, loop-filtered frame); integer full search +-range around the co-located block
+ * by SAD ((0,0) first, then raster order, strict improvement), then one half-pel and one quarter-pel refinement
+ * round (8 neighbours each, fixed order, strict improvement) with the regular 8-tap filter; chroma uses the same
+ * vector; DCT_DCT residual coding as in the intra loop.  The prediction arithmetic is av1o_mc_block (spec 7.11.3.4).
+ * mvs: int16 pairs (x, y) in 1/8 luma sample units, one per block, raster.  skip: 1 = all levels of the block zero.
+ */
+int av1o_mc_block(const void *ref, int stride, int plane_w, int plane_h, int bd, int x, int y, int w, int h, int mvx,
+                  int mvy, int filt_x, int filt_y, uint16_t *pred);
+
+static long block_sad(const void *src, int stride, int bd, int x, int y, int bs, const uint16_t *pred) {
+  long s = 0;
+  for (int r = 0; r < bs; r++)
+    for (int c = 0; c < bs; c++) s += labs((long)px_get(src, bd, (size_t)(y + r) * stride + x + c) - pred[r * bs + c]);
+  return s;
+}
+static void code_inter_plane(const void *src, void *rec, int stride, int bd, int bs, int x, int y, const uint16_t *pred, int dc_q,
+                             int ac_q, int16_t *levels) {
+  int16_t resid[64 * 64];
+  int32_t coef[1024], dq[1024];
+  const int tx_size = bs == 4 ? TX_4X4 : bs == 8 ? TX_8X8 : TX_16X16;
+  const int bps = bd == 8 ? 1 : 2, n = bs * bs;
+  for (int r = 0; r < bs; r++)
+    for (int c = 0; c < bs; c++) {
+      resid[r * bs + c] = (int16_t)(px_get(src, bd, (size_t)(y + r) * stride + x + c) - pred[r * bs + c]);
+      px_set(rec, bd, (size_t)(y + r) * stride + x + c, pred[r * bs + c]);
+    }
+  av1o_fwd_txfm2d(resid, bs, coef, tx_size, DCT_DCT, bd);
+  av1o_quantize(coef, n, dc_q, ac_q, 0, levels, NULL);
+  av1o_dequantize(levels, n, dc_q, ac_q, 0, bd, dq);
+  av1o_inv_txfm2d_add(dq, (char *)rec + ((size_t)y * stride + x) * bps, stride, tx_size, DCT_DCT, bd, 1);
+}
+
+int av1o_inter_encode_frame(const void *src_y, const void *src_u, const void *src_v, const void *ref_y, const void *ref_u,
+                            const void *ref_v, void *rec_y, void *rec_u, void *rec_v, int w, int h, int stride_y, int stride_uv,
+                            int bd, int bs, int qindex, int range, int16_t *lev_y, int16_t *lev_u, int16_t *lev_v, int16_t *mvs,
+                            uint8_t *skip) {
+  if (bs != 8 || (w % bs) || (h % bs) || (bd != 8 && bd != 10) || range < 0 || range > 15) return -1;
+  const int dc_q = av1o_dc_q(qindex, 0, bd), ac_q = av1o_ac_q(qindex, 0, bd);
+  const int bw = w / bs, bh = h / bs, cs = bs / 2;
+  uint16_t pred[64], best_pred[64], pu[16], pv[16];
+  for (int by = 0; by < bh; by++)
+    for (int bx = 0; bx < bw; bx++) {
+      const int x = bx * bs, y = by * bs;
+      const size_t blk = (size_t)by * bw + bx;
+      /* integer search */
+      av1o_mc_block(ref_y, stride_y, w, h, bd, x, y, bs, bs, 0, 0, 0, 0, pred);
+      long best = block_sad(src_y, stride_y, bd, x, y, bs, pred);
+      int bmx = 0, bmy = 0;   /* 1/8 units */
+      for (int dy = -range; dy <= range; dy++)
+        for (int dx = -range; dx <= range; dx++) {
+          if (!dx && !dy) continue;
+          av1o_mc_block(ref_y, stride_y, w, h, bd, x, y, bs, bs, dx * 16, dy * 16, 0, 0, pred);
+          const long s = block_sad(src_y, stride_y, bd, x, y, bs, pred);
+          if (s < best) { best = s; bmx = dx * 8; bmy = dy * 8; }
+        }
+      /* half-pel then quarter-pel refinement */
+      for (int step = 4; step >= 2; step >>= 1) {
+        const int cx = bmx, cy = bmy;
+        for (int k = 0; k < 9; k++) {
+          if (k == 4) continue;
+          const int mx = cx + (k % 3 - 1) * step, my = cy + (k / 3 - 1) * step;
+          av1o_mc_block(ref_y, stride_y, w, h, bd, x, y, bs, bs, mx * 2, my * 2, 0, 0, pred);
+          const long s = block_sad(src_y, stride_y, bd, x, y, bs, pred);
+          if (s < best) { best = s; bmx = mx; bmy = my; }
+        }
+      }
+      mvs[blk * 2] = (int16_t)bmx; mvs[blk * 2 + 1] = (int16_t)bmy;
+      av1o_mc_block(ref_y, stride_y, w, h, bd, x, y, bs, bs, bmx * 2, bmy * 2, 0, 0, best_pred);
+      av1o_mc_block(ref_u, stride_uv, w / 2, h / 2, bd, x / 2, y / 2, cs, cs, bmx, bmy, 0, 0, pu);
+      av1o_mc_block(ref_v, stride_uv, w / 2, h / 2, bd, x / 2, y / 2, cs, cs, bmx, bmy, 0, 0, pv);
+      code_inter_plane(src_y, rec_y, stride_y, bd, bs, x, y, best_pred, dc_q, ac_q, lev_y + blk * bs * bs);
+      code_inter_plane(src_u, rec_u, stride_uv, bd, cs, x / 2, y / 2, pu, dc_q, ac_q, lev_u + blk * cs * cs);
+      code_inter_plane(src_v, rec_v, stride_uv, bd, cs, x / 2, y / 2, pv, dc_q, ac_q, lev_v + blk * cs * cs);
+      int nz = 0;
+      for (int i = 0; i < bs * bs; i++) nz |= lev_y[blk * bs * bs + i];
+      for (int i = 0; i < cs * cs; i++) nz |= lev_u[blk * cs * cs + i] | lev_v[blk * cs * cs + i];
+      skip[blk] = nz == 0;
+    }
+  return 0;
+}

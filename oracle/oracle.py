@@ -285,3 +285,23 @@ def lr_plane(cdef, dbl, bd, ss, unit_size, units):
     if rc:
         raise ValueError("av1o_lr_plane rc=%d" % rc)
     return out
+
+
+def inter_encode_frame(src, ref, bd, qindex, search_range=8, bs=8):
+    """src, ref: (Y, U, V) tuples; returns dict(rec_y/u/v, lev_y/u/v, mvs [nb,2], skip [nb])"""
+    dt = np.uint8 if bd == 8 else np.uint16
+    S = [np.ascontiguousarray(a, dt) for a in src]
+    R = [np.ascontiguousarray(a, dt) for a in ref]
+    h, w = S[0].shape
+    nb = (h // bs) * (w // bs)
+    cs = bs // 2
+    out = dict(rec_y=np.zeros_like(S[0]), rec_u=np.zeros_like(S[1]), rec_v=np.zeros_like(S[2]),
+               lev_y=np.zeros((nb, bs, bs), np.int16), lev_u=np.zeros((nb, cs, cs), np.int16), lev_v=np.zeros((nb, cs, cs), np.int16),
+               mvs=np.zeros((nb, 2), np.int16), skip=np.zeros(nb, np.uint8))
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    rc = lib().av1o_inter_encode_frame(vp(S[0]), vp(S[1]), vp(S[2]), vp(R[0]), vp(R[1]), vp(R[2]), vp(out["rec_y"]), vp(out["rec_u"]),
+                                       vp(out["rec_v"]), w, h, w, w // 2, bd, bs, qindex, search_range, vp(out["lev_y"]), vp(out["lev_u"]),
+                                       vp(out["lev_v"]), vp(out["mvs"]), vp(out["skip"]))
+    if rc:
+        raise ValueError("av1o_inter_encode_frame rc=%d" % rc)
+    return out

@@ -36,3 +36,16 @@ def test_segment_pipeline_matches_oracle_chain(ctx, O, w, h, bd, bs):
     g = pipe.download(0)
     assert psnr(g["out_y"]) > 28 and psnr(g["out_y"]) > psnr(g["rec_y"]) - 1.0   # the filter chain must not wreck the picture
     pipe.close()
+
+
+def test_4k_10bit_full_chain_one_frame(ctx, O):
+    """BASELINE config 4 size (3840x2160 10-bit): the whole chain on one frame equals the oracle chain bit for bit."""
+    import pipeline
+    pipe = pipeline.IntraPipeline(ctx, 3840, 2160, 10, 1, 128, first_frame=1, block_size=8)
+    pipe.step()
+    got = pipe.download(0)
+    r, dbl, cdef, out = _oracle_chain(O, pipe, 0)
+    for i, p in enumerate("yuv"):
+        assert (got["rec_" + p] == r["rec_" + p]).all() and (got["dbl_" + p] == dbl[i]).all()
+        assert (got["cdef_" + p] == cdef[i]).all() and (got["out_" + p] == out[i]).all()
+    pipe.close()
