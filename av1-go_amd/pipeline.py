@@ -124,3 +124,79 @@ class IntraPipeline:
     def close(self):
         for b in self.d.values():
             b.free()
+
+
+class GopPipeline:
+    """BASELINE config 3: closed GOPs of `gop` frames (1 key frame + gop-1 P frames, single reference = the previous
+    reconstructed, loop-filtered frame).  Frames inside a GOP are serially dependent, so the batch dimension is the
+    SEGMENT: `segments` independent GOPs are coded in lockstep, the t-th frames of all of them stacked in one launch.
+    Per step: gop x (coding launch(es) + 3 deblock + 1 CDEF + 3 LR)."""
+
+    def __init__(self, ctx, width, height, bd, segments, gop, qindex, first_frame=0, search_range=8):
+        self.ctx, self.bd, self.segments, self.gop, self.qindex, self.range = ctx, bd, segments, gop, qindex, search_range
+        self.width, self.height, self.frames = width, height, segments * gop
+        self.key = IntraPipeline(ctx, width, height, bd, segments, qindex, first_frame=first_frame)   # buffers + filter params
+        # source: segment s holds frames first + s*gop .. ; re-stack as [t][s]
+        Y, U, V = synth.frames(width, height, segments * gop, bd, first_frame)
+        pick = lambda a, t: np.ascontiguousarray(a.reshape(segments, gop, *a.shape[1:])[:, t])
+        self.src = [[pick(a, t) for a in (Y, U, V)] for t in range(gop)]
+        k, d = self.key, self.key.d
+        self.d_src = [[ctx.to_device(p) for p in self.src[t]] for t in range(gop)]
+        nb = (height // 8) * (width // 8)
+        self.d_mvs, self.d_skip = ctx.alloc(segments * nb * 4), ctx.alloc(segments * nb)
+        self.d_ref = [ctx.alloc(self.src[0][i].nbytes) for i in range(3)]      # loop-filtered previous frame
+        self.zero_skip = ctx.to_device(np.zeros(segments * nb, np.uint8))
+        self.samples = sum(a.size for a in self.src[0]) * gop
+        self.bps = k.bps
+
+    def describe(self):
+        return ("%dx%d %d-bit 4:2:0, %d closed GOPs of %d frames in lockstep (1 key + %d P frames, single reference, +-%d full "
+                "search + half/quarter-pel refinement, 8x8 blocks), deblock + CDEF + Wiener LR on every frame; entropy coding "
+                "not built" % (self.width, self.height, self.bd, self.segments, self.gop, self.gop - 1, self.range))
+
+    def _filters(self, skip_buf, skip_stride):
+        c, k, d = self.ctx, self.key, self.key.d
+        w, h, f = self.width, self.height, self.segments
+        c.deblock_frames(d["rec_y"], w, d["dbl_y"], w, w, h, self.bd, 0, d["mi_y"], w // 4, 0, 0, f)
+        c.deblock_frames(d["rec_u"], w // 2, d["dbl_u"], w // 2, w // 2, h // 2, self.bd, 1, d["mi_c"], w // 8, 0, 0, f)
+        c.deblock_frames(d["rec_v"], w // 2, d["dbl_v"], w // 2, w // 2, h // 2, self.bd, 1, d["mi_c"], w // 8, 0, 0, f)
+        job = av1mi.CdefJob(w, h, self.bd, f, k.cdef_damping, w, w // 2, d["dbl_y"].ptr, d["dbl_u"].ptr, d["dbl_v"].ptr,
+                            d["cdef_y"].ptr, d["cdef_u"].ptr, d["cdef_v"].ptr, d["cdef_sb"].ptr, 0, skip_buf.ptr, skip_stride)
+        c.cdef_frames(job)
+        c.lr_frames(d["cdef_y"], d["dbl_y"], self.d_ref[0], w, w, h, self.bd, 0, k.lr_unit, d["lr_y"], 0, f)
+        c.lr_frames(d["cdef_u"], d["dbl_u"], self.d_ref[1], w // 2, w // 2, h // 2, self.bd, 1, k.lr_unit, d["lr_c"], 0, f)
+        c.lr_frames(d["cdef_v"], d["dbl_v"], self.d_ref[2], w // 2, w // 2, h // 2, self.bd, 1, k.lr_unit, d["lr_c"], 0, f)
+
+    def step(self, on_frame=None):
+        c, k, d = self.ctx, self.key, self.key.d
+        w, h, f = self.width, self.height, self.segments
+        nb = (h // 8) * (w // 8)
+        for t in range(self.gop):
+            s = self.d_src[t]
+            if t == 0:
+                job = av1mi.IntraJob(w, h, self.bd, f, self.qindex, 8, w, w // 2, s[0].ptr, s[1].ptr, s[2].ptr, d["rec_y"].ptr,
+                                     d["rec_u"].ptr, d["rec_v"].ptr, d["lev_y"].ptr, d["lev_u"].ptr, d["lev_v"].ptr, d["modes_y"].ptr,
+                                     d["modes_uv"].ptr)
+                c.intra_encode(job)
+                self._filters(self.zero_skip, 0)
+            else:
+                job = av1mi.InterJob(w, h, self.bd, f, self.qindex, self.range, w, w // 2, s[0].ptr, s[1].ptr, s[2].ptr,
+                                     self.d_ref[0].ptr, self.d_ref[1].ptr, self.d_ref[2].ptr, d["rec_y"].ptr, d["rec_u"].ptr,
+                                     d["rec_v"].ptr, d["lev_y"].ptr, d["lev_u"].ptr, d["lev_v"].ptr, self.d_mvs.ptr, self.d_skip.ptr)
+                c.inter_encode(job)
+                self._filters(self.d_skip, nb)
+            if on_frame:
+                on_frame(t)
+
+    def algorithmic_bytes(self):
+        b, per_frame = self.bps, self.samples / self.gop
+        return {"intra_pipeline": (2 * b + 2) * per_frame, "inter_pipeline": (3 * b + 2) * per_frame, "deblock": 2 * b * per_frame / 3.0,
+                "cdef": 2 * b * per_frame, "loop_restoration": 2 * b * per_frame / 3.0}
+
+    def close(self):
+        for t in self.d_src:
+            for b in t:
+                b.free()
+        for b in [self.d_mvs, self.d_skip, self.zero_skip] + self.d_ref:
+            b.free()
+        self.key.close()

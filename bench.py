@@ -27,7 +27,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="1080p8", choices=["1080p8", "4k10"])
+    ap.add_argument("--workload", default="1080p8", choices=["1080p8", "4k10", "1080p8-gop", "4k10-gop"],
+                    help="1080p8 = BASELINE config 2 (intra-only, the default); 4k10 = 4K 10-bit intra-only; *-gop = closed GOPs of 30 "
+                         "frames, 1 key + 29 P (configs 3/4)")
     ap.add_argument("--frames", type=int, default=0, help="frames per step (segment length); 0 = default")
     ap.add_argument("--qindex", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -123,14 +125,20 @@ def main():
     import av1mi
     import pipeline
 
-    if args.workload == "1080p8":
+    if args.workload.startswith("1080p8"):
         W, H, bd = 1920, 1080, 8
         frames = args.frames or 32
     else:
         W, H, bd = 3840, 2160, 10
         frames = args.frames or 8
     ctx = av1mi.Context(local_rank)
-    pipe = pipeline.IntraPipeline(ctx, W, H, bd, frames, args.qindex, first_frame=segment_of_rank(rank, frames))
+    if args.workload.endswith("-gop"):
+        gop = 30
+        segs = max(1, frames // 2)               # GOPs coded in lockstep per step
+        frames = segs * gop
+        pipe = pipeline.GopPipeline(ctx, W, H, bd, segs, gop, args.qindex, first_frame=segment_of_rank(rank, frames))
+    else:
+        pipe = pipeline.IntraPipeline(ctx, W, H, bd, frames, args.qindex, first_frame=segment_of_rank(rank, frames))
 
     def barrier():
         ctx.sync()
@@ -176,7 +184,7 @@ def main():
                            "avg_launch_ms": ms / n, "launches": n}
         out["kernels"] = {k: {"launches": v[0], "avg_ms": v[1] / v[0], "algorithmic_GBps": alg[k] / (v[1] / v[0] * 1e-3) / 1e9}
                           for k, v in prof.items()}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.workload.endswith("-gop"):
             out["cpu_baseline"] = cpu_baseline(pipe)
         else:
             out["cpu_baseline"] = None

@@ -49,3 +49,32 @@ def test_4k_10bit_full_chain_one_frame(ctx, O):
         assert (got["rec_" + p] == r["rec_" + p]).all() and (got["dbl_" + p] == dbl[i]).all()
         assert (got["cdef_" + p] == cdef[i]).all() and (got["out_" + p] == out[i]).all()
     pipe.close()
+
+
+def test_closed_gop_chain_matches_oracle(ctx, O):
+    """BASELINE config 3 end to end: 2 segments x (1 key + 3 P frames); every P frame predicts from the loop-filtered
+    previous frame.  Reconstruction after the whole filter chain equals the oracle chain for every frame."""
+    import pipeline
+    w, h, bd, q = 192, 128, 8, 90
+    gp = pipeline.GopPipeline(ctx, w, h, bd, segments=2, gop=4, qindex=q, first_frame=1, search_range=6)
+    got = []
+    dl = lambda bufs, shapes: [b.download(s.shape, s.dtype) for b, s in zip(bufs, shapes)]
+    gp.step(on_frame=lambda t: got.append(dl(gp.d_ref, gp.src[t])))
+    k = gp.key
+    for s in range(2):
+        ref = None
+        for t in range(4):
+            src = [gp.src[t][i][s] for i in range(3)]
+            if t == 0:
+                r = O.intra_encode_frame(src[0], src[1], src[2], bd, 8, q)
+                skip8 = np.zeros((h // 8, w // 8), np.uint8)
+            else:
+                r = O.inter_encode_frame(src, ref, bd, q, 6)
+                skip8 = r["skip"].reshape(h // 8, w // 8)
+            dbl = [O.deblock_plane(r["rec_y"], bd, 0, k.mi_y), O.deblock_plane(r["rec_u"], bd, 1, k.mi_c), O.deblock_plane(r["rec_v"], bd, 1, k.mi_c)]
+            cdef = O.cdef_frame(dbl[0], dbl[1], dbl[2], bd, k.cdef_damping, k.cdef_sb, skip8)
+            ref = [O.lr_plane(cdef[0], dbl[0], bd, 0, k.lr_unit, k.lr_units_y), O.lr_plane(cdef[1], dbl[1], bd, 1, k.lr_unit, k.lr_units_c),
+                   O.lr_plane(cdef[2], dbl[2], bd, 1, k.lr_unit, k.lr_units_c)]
+            for i in range(3):
+                assert (got[t][i][s] == ref[i]).all(), (s, t, i)
+    gp.close()
