@@ -173,9 +173,7 @@ __global__ __launch_bounds__(256) void k_inter_pipe(InterLaunch L) {
     int v = 0;
 #pragma unroll
     for (int c = 0; c < 8; c++) v += abs(s[c] - o[c]);
-#pragma unroll
-    for (int off = 4; off >= 1; off >>= 1) v += __shfl_xor(v, off, 8);
-    return v;
+    return group_sum<8>(v);
   };
   // candidate 0: the integer vector itself
   mc_row<8, ES>(wy, YWS, im, lane, 0, 0, kRegular8, bd, bp);
@@ -226,8 +224,7 @@ __global__ __launch_bounds__(256) void k_inter_pipe(InterLaunch L) {
                                 L.lev[1 + pl] + (size_t)f * cw * chh + (size_t)blk * 16 + cl * 4, rc);
     store_row<4>(rec_c + (size_t)(cy0 + cl) * L.stride_uv + cx0, rc);
   }
-#pragma unroll
-  for (int off = 4; off >= 1; off >>= 1) nz |= __shfl_xor(nz, off, 8);
+  nz = group_or<8>(nz);
   if (lane == 0) L.skip[(size_t)f * bw * bh + blk] = nz == 0;
 }
 

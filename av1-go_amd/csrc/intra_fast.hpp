@@ -49,20 +49,23 @@ template <int B, int DELTA> __device__ __forceinline__ int ct_upsample(int type)
   return type ? u1 : u0;
 }
 
-// p-space entry i (0 = top-left) of one edge after corner + 5-tap edge filter, computed from the raw array; branch-free
-template <typename T>
-__device__ __forceinline__ int filt_entry(const T *raw, int tl, int i, int sz, int strength) {
-  const int i0 = max(i - 2, 0), i1 = max(i - 1, 0), i3 = min(i + 1, sz - 1), i4 = min(i + 2, sz - 1);
-  // raw[-1] holds the unfiltered top-left; p-index 0 must read `tl` (corner-filtered in zone 2)
-  const int p0 = i0 ? (int)raw[i0 - 1] : tl, p1 = i1 ? (int)raw[i1 - 1] : tl, p2 = i ? (int)raw[i - 1] : tl;
-  const int p3 = i3 ? (int)raw[i3 - 1] : tl, p4 = i4 ? (int)raw[i4 - 1] : tl;
-  const int k0 = strength == 3 ? 2 : 0, k1 = strength == 2 ? 5 : 4, k2 = strength == 1 ? 8 : strength == 2 ? 6 : 4;
-  const int f = (k0 * (p0 + p4) + k1 * (p1 + p3) + k2 * p2 + 8) >> 4;
-  return (strength && i >= 1 && i < sz) ? f : p2;
+// A lane's view of one raw edge: for each of its (up to 3) entries i = lane + it*B (p-space: 0 = top-left, k = sample k-1)
+// the five raw values P(i-2) .. P(i+2), loaded ONCE from LDS (indices clamped into the array, never read out of range).
+struct EdgeWin { int v[3][5]; };
+template <int B, typename T>
+__device__ __forceinline__ EdgeWin load_edge_win(const T *raw, int lane) {
+  EdgeWin W;
+#pragma unroll
+  for (int it = 0; it < 3; it++)
+#pragma unroll
+    for (int d = -2; d <= 2; d++) W.v[it][d + 2] = raw[min(max(lane + it * B + d, 0), 2 * B) - 1];
+  return W;
 }
 
+// one derived array (slot S) from the register windows; no LDS reads, no branches on per-lane state
 template <int B, int S, typename T>
-__device__ __forceinline__ void fast_build_slot(T *edge, int lane, int bd, int n_top, int n_left, int filter_type, int tl_raw, int tl_corner) {
+__device__ __forceinline__ void fast_build_slot(T *edge, int lane, int bd, int n_top, int n_left, int filter_type, int tl_raw, int tl_corner,
+                                                const EdgeWin &WA, const EdgeWin &WL) {
   constexpr int RL = raw_len(B), VL = var_len(B);
   constexpr int angles[kNumVariants] = { 45, 67, 113, 135, 157, 113, 135, 157, 203 };
   constexpr int a = angles[S];
@@ -70,27 +73,31 @@ __device__ __forceinline__ void fast_build_slot(T *edge, int lane, int bd, int n
   constexpr int n = B + (ext ? B : 0), delta = is_above ? a - 90 : a - 180;
   const int navail = is_above ? n_top : n_left;
   const int strength = navail > 0 ? ct_strength<B, delta>(filter_type) : 0;
-  const int up = ct_upsample<B, delta>(filter_type);
+  const int up = ct_upsample<B, delta>(filter_type);   // up != 0 implies strength == 0 (spec: d < 40 and small blocks only)
   const int sz = navail + 1 + (ext ? B : 0);
-  const T *raw = edge + (is_above ? 0 : RL) + kRawPad;
   const int tl = both ? tl_corner : tl_raw;
+  const EdgeWin &W = is_above ? WA : WL;
   T *out = edge + 2 * RL + S * VL + kRawPad;
   const int maxv = (1 << bd) - 1;
-  // every lane produces entries lane, lane + B, ... of BOTH layouts' index ranges and stores the one that applies:
-  // plain layout: out[j] for j = -1 .. n-1; upsampled layout: out[2j-1], out[2j] for j = 0 .. n-1 and out[-2]
+  const int k0 = strength == 3 ? 2 : 0, k1 = strength == 2 ? 5 : 4, k2 = strength == 1 ? 8 : strength == 2 ? 6 : 4;
 #pragma unroll
   for (int it = 0; it < (n + B) / B; it++) {
-    const int j = lane + it * B - 1;               // -1 .. n + B - 2
-    const int v = filt_entry(raw, tl, min(j, n - 1) + 1, sz, strength);   // value of edge entry min(j, n-1)
-    if (!up) {
-      if (j < n) out[j] = (T)v;
-    } else {
-      // entry j plays the role of "c" (edge index j) for j >= 0; j == -1 writes the duplicated top-left
-      const int va = filt_entry(raw, tl, max(j - 2, -1) + 1, sz, strength), vb = filt_entry(raw, tl, max(j - 1, -1) + 1, sz, strength);
-      const int vd = filt_entry(raw, tl, min(j + 1, n - 1) + 1, sz, strength);
-      const int h = min(max((-va + 9 * vb + 9 * v - vd + 8) >> 4, 0), maxv);
-      if (j >= 0 && j < n) { out[2 * j - 1] = (T)h; out[2 * j] = (T)v; }
-      if (j == -1) out[-2] = (T)v;
+    const int i = lane + it * B;                    // p-space index of this lane's entry; edge index j = i - 1
+    // P(i + d) with the top-left substituted at p-index 0
+    const int pm2 = i - 2 <= 0 ? tl : W.v[it][0], pm1 = i - 1 <= 0 ? tl : W.v[it][1], p0 = i <= 0 ? tl : W.v[it][2];
+    const int pp1 = W.v[it][3], pp2 = W.v[it][4];
+    // 5-tap filter with taps clamped to [0, sz-1] (i < sz wherever the result is used)
+    const int t1 = i + 1 <= sz - 1 ? pp1 : p0, t2 = i + 2 <= sz - 1 ? pp2 : t1;
+    const int f = (k0 * (pm2 + t2) + k1 * (pm1 + t1) + k2 * p0 + 8) >> 4;
+    const int v = (strength && i >= 1 && i < sz) ? f : p0;
+    // upsampling taps (unfiltered there): entries j-2, j-1, j, j+1 clamped to [-1, n-1]  <=>  p-indices i-2.., max 0, min n
+    const int u3 = i + 1 <= n ? pp1 : p0;
+    const int h = min(max((-pm2 + 9 * pm1 + 9 * p0 - u3 + 8) >> 4, 0), maxv);
+    const int j = i - 1;
+    if (j < n) {
+      if (!up) out[j] = (T)v;
+      else if (j >= 0) { out[2 * j - 1] = (T)h; out[2 * j] = (T)p0; }
+      else out[-2] = (T)p0;
     }
   }
 }
@@ -120,18 +127,19 @@ __device__ __forceinline__ void fast_build(T *edge, int lane, int bd, int n_top,
     }
   }
   AV1MI_GROUP_SYNC();
-  // phase 2: the nine derived arrays
+  // phase 2: the nine derived arrays from two register windows
+  const EdgeWin WA = load_edge_win<B>(ra, lane), WL = load_edge_win<B>(rl, lane);
   const int tl_raw = ra[-1];
   const int tl_corner = (2 * B >= 24) ? (rl[0] * 5 + tl_raw * 6 + ra[0] * 5 + 8) >> 4 : tl_raw;
-  fast_build_slot<B, 0>(edge, lane, bd, n_top, n_left, filter_type, tl_raw, tl_corner);
-  fast_build_slot<B, 1>(edge, lane, bd, n_top, n_left, filter_type, tl_raw, tl_corner);
-  fast_build_slot<B, 2>(edge, lane, bd, n_top, n_left, filter_type, tl_raw, tl_corner);
-  fast_build_slot<B, 3>(edge, lane, bd, n_top, n_left, filter_type, tl_raw, tl_corner);
-  fast_build_slot<B, 4>(edge, lane, bd, n_top, n_left, filter_type, tl_raw, tl_corner);
-  fast_build_slot<B, 5>(edge, lane, bd, n_top, n_left, filter_type, tl_raw, tl_corner);
-  fast_build_slot<B, 6>(edge, lane, bd, n_top, n_left, filter_type, tl_raw, tl_corner);
-  fast_build_slot<B, 7>(edge, lane, bd, n_top, n_left, filter_type, tl_raw, tl_corner);
-  fast_build_slot<B, 8>(edge, lane, bd, n_top, n_left, filter_type, tl_raw, tl_corner);
+  fast_build_slot<B, 0>(edge, lane, bd, n_top, n_left, filter_type, tl_raw, tl_corner, WA, WL);
+  fast_build_slot<B, 1>(edge, lane, bd, n_top, n_left, filter_type, tl_raw, tl_corner, WA, WL);
+  fast_build_slot<B, 2>(edge, lane, bd, n_top, n_left, filter_type, tl_raw, tl_corner, WA, WL);
+  fast_build_slot<B, 3>(edge, lane, bd, n_top, n_left, filter_type, tl_raw, tl_corner, WA, WL);
+  fast_build_slot<B, 4>(edge, lane, bd, n_top, n_left, filter_type, tl_raw, tl_corner, WA, WL);
+  fast_build_slot<B, 5>(edge, lane, bd, n_top, n_left, filter_type, tl_raw, tl_corner, WA, WL);
+  fast_build_slot<B, 6>(edge, lane, bd, n_top, n_left, filter_type, tl_raw, tl_corner, WA, WL);
+  fast_build_slot<B, 7>(edge, lane, bd, n_top, n_left, filter_type, tl_raw, tl_corner, WA, WL);
+  fast_build_slot<B, 8>(edge, lane, bd, n_top, n_left, filter_type, tl_raw, tl_corner, WA, WL);
   AV1MI_GROUP_SYNC();
 }
 
@@ -191,9 +199,7 @@ __device__ __forceinline__ void fast_pred_row(const T *edge, int r, int bd, int 
     }
   } else if constexpr (MODE == DC_PRED) {
     // lane r contributes above[r] + left[r]; the B lanes of the block sum by xor-shuffles
-    int sa_ = above[r], sl_ = left[r];
-#pragma unroll
-    for (int o = B / 2; o >= 1; o >>= 1) { sa_ += __shfl_xor(sa_, o, B); sl_ += __shfl_xor(sl_, o, B); }
+    const int sa_ = group_sum<B>(above[r]), sl_ = group_sum<B>(left[r]);
     constexpr int lg = B == 4 ? 2 : B == 8 ? 3 : B == 16 ? 4 : B == 32 ? 5 : 6;
     const bool ht = n_top > 0, hl = n_left > 0;
     const int both = (sa_ + sl_ + B) >> (lg + 1), one = ((ht ? sa_ : sl_) + B / 2) >> lg;

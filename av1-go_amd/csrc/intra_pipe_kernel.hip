@@ -24,7 +24,26 @@
 #include "block_code.hpp"
 #include "av1mi_internal.hpp"
 
+// Diagnostic build only (-DAV1MI_STAMPS, never shipped): per-phase s_memtime sums of lane 0 of every wave, written to a
+// debug buffer no other code reads (cdna_hip_programming.md §7 "In-kernel stamps").
+#ifdef AV1MI_STAMPS
+#define STAMP(i)                                                                                   \
+  do {                                                                                             \
+    unsigned long long t_;                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                     \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+    av1mi_stamp_acc[i] += t_ - av1mi_stamp_last; av1mi_stamp_last = t_;                            \
+  } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
+
 namespace av1mi {
+
+#ifdef AV1MI_STAMPS
+__device__ unsigned long long av1mi_stamp_out[8];
+#endif
 
 __device__ constexpr int kCand[11] = { DC_PRED, V_PRED, H_PRED, D45_PRED, D135_PRED, D113_PRED, D157_PRED, D203_PRED,
                                        D67_PRED, SMOOTH_PRED, PAETH_PRED };
@@ -47,10 +66,17 @@ template <typename ES> struct TileCtx {
 
 // Code one B x B block with L = B lanes (`lane` in [0,B)); `gw` = lanes that share the mode decision (the whole
 // group: B for luma, 2B for the U+V pair).  Returns the chosen mode (identical in all gw lanes).
+#ifdef AV1MI_STAMPS
+#define STAMP_ARGS , unsigned long long *av1mi_stamp_acc, unsigned long long &av1mi_stamp_last
+#define STAMP_PASS , av1mi_stamp_acc, av1mi_stamp_last
+#else
+#define STAMP_ARGS
+#define STAMP_PASS
+#endif
 template <int B, int GW, typename Pix>
 __device__ __forceinline__ int code_block(const TileCtx<Pix> &C, int lane, int bx, int by, int n, int n_top, int n_topright, int n_left,
                                           int n_bottomleft, int filter_type, int dc_q, int ac_q, const Pix *src_row,
-                                          Pix *rec_row, int16_t *lev_row) {
+                                          Pix *rec_row, int16_t *lev_row STAMP_ARGS) {
   constexpr int RS = B + 4, bd = sizeof(Pix) == 1 ? 8 : 10;
   using ES = Pix;
   const int x = bx * B, y = by * B;
@@ -60,8 +86,10 @@ __device__ __forceinline__ int code_block(const TileCtx<Pix> &C, int lane, int b
   };
   int s[B], bp[B];
   load_row<B>(src_row, s);
+  STAMP(0);
   // all edge variants of the block in two LDS phases, then 11 compile-time-specialised predictions, no hand-offs
   fast_build<B>(C.edge, lane, bd, n_top, n_topright, n_left, n_bottomleft, filter_type, fetch);
+  STAMP(1);
   int best = 0x7fffffff, best_mode = 0;
   auto eval = [&](auto mode_tag) {
     constexpr int MODE = decltype(mode_tag)::value;
@@ -70,8 +98,7 @@ __device__ __forceinline__ int code_block(const TileCtx<Pix> &C, int lane, int b
     int sad = 0;
 #pragma unroll
     for (int c = 0; c < B; c++) sad += abs(s[c] - out[c]);
-#pragma unroll
-    for (int o = GW / 2; o >= 1; o >>= 1) sad += __shfl_xor(sad, o, GW);
+    sad = group_sum<GW>(sad);
     const bool better = sad < best;
     best = better ? sad : best; best_mode = better ? MODE : best_mode;
 #pragma unroll
@@ -85,8 +112,10 @@ __device__ __forceinline__ int code_block(const TileCtx<Pix> &C, int lane, int b
   eval(std::integral_constant<int, D67_PRED>{});  eval(std::integral_constant<int, SMOOTH_PRED>{});
   eval(std::integral_constant<int, PAETH_PRED>{});
   AV1MI_GROUP_SYNC();
+  STAMP(2);
   int rec[B];
   code_residual<B, Pix>(C.tbuf, lane, s, bp, dc_q, ac_q, lev_row, rec);
+  STAMP(3);
   store_row<B>(rec_row, rec);
   // neighbour context for the blocks to come
   C.left[y + lane] = (ES)rec[B - 1];
@@ -96,6 +125,7 @@ __device__ __forceinline__ int code_block(const TileCtx<Pix> &C, int lane, int b
     C.br[by * n + bx] = (ES)rec[B - 1];
   }
   AV1MI_GROUP_SYNC();
+  STAMP(4);
   return best_mode;
 }
 
@@ -141,6 +171,10 @@ __global__ __launch_bounds__(256) void k_intra_pipe(IntraPipeLaunch L) {
   int16_t *lev_c = L.lev[1 + pl] + (size_t)f * (L.w / 2) * (L.h / 2);
   uint8_t *modes_y = L.modes_y + (size_t)f * bw * bh, *modes_uv = L.modes_uv + (size_t)f * bw * bh;
 
+#ifdef AV1MI_STAMPS
+  unsigned long long av1mi_stamp_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, av1mi_stamp_last;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(av1mi_stamp_last)::"memory");
+#endif
   for (unsigned k = 0; k < (unsigned)(N * N); k++) {
     unsigned bx = 0, by = 0;
 #pragma unroll
@@ -158,19 +192,30 @@ __global__ __launch_bounds__(256) void k_intra_pipe(IntraPipeLaunch L) {
       const size_t off = ((size_t)fy * BS + lane) * L.stride_y + (size_t)fx * BS;
       const int m = code_block<BS, BS, Pix>(Y, lane, bx, by, N, have_top ? BS : 0, have_tr ? BS : 0, have_left ? BS : 0,
                                              have_bl ? BS : 0, ft, L.dc_q, L.ac_q, src_y + off, rec_y + off,
-                                             lev_y + blk * BS * BS + lane * BS);
+                                             lev_y + blk * BS * BS + lane * BS STAMP_PASS);
       if (lane == 0) { modes_y[blk] = (uint8_t)m; mode_y[by * N + bx] = (uint8_t)m; }
     }
     {
       const size_t off = ((size_t)fy * CS + cl) * L.stride_uv + (size_t)fx * CS;
       const int m = code_block<CS, BS, Pix>(Cp, cl, bx, by, N, have_top ? CS : 0, have_tr ? CS : 0, have_left ? CS : 0,
                                              have_bl ? CS : 0, ftc, L.dc_q, L.ac_q, src_c + off, rec_c + off,
-                                             lev_c + blk * CS * CS + cl * CS);
+                                             lev_c + blk * CS * CS + cl * CS STAMP_PASS);
       if (lane == 0) { modes_uv[blk] = (uint8_t)m; mode_c[by * N + bx] = (uint8_t)m; }
     }
     AV1MI_GROUP_SYNC();
+    STAMP(5);
   }
+#ifdef AV1MI_STAMPS
+  if (threadIdx.x == 0 && blockIdx.x == 7)
+    for (int i = 0; i < 8; i++) av1mi_stamp_out[i] = av1mi_stamp_acc[i];
+#endif
 }
+
+#ifdef AV1MI_STAMPS
+extern "C" int av1mi_debug_read_stamps(unsigned long long *out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(av1mi_stamp_out), sizeof(av1mi_stamp_out));
+}
+#endif
 
 hipError_t launch_intra_pipe(const IntraPipeLaunch &L, int bs, hipStream_t s) {
   const long long tiles = (long long)L.nframes * ((L.w + 63) / 64) * ((L.h + 63) / 64);
