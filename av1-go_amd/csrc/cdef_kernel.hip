@@ -51,11 +51,57 @@ __device__ __forceinline__ int cdef_sample(const uint16_t *p, int pri, int sec, 
   return min(max(x + ((8 + sum - (sum < 0)) >> 4), mn), mx);
 }
 
+// Four horizontally adjacent samples at once with packed 16-bit VALU (v_pk_*_i16: two samples per lane-op); used where
+// every tap is inside the picture (no 0xFFFF sentinels in the tile), i.e. for all but the picture-border superblocks.
+// p: 4-byte aligned centre pointer (first of the four samples) in an LDS tile with even row stride LS.
+typedef short v2s __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2s pk_constrain(v2s diff, int thr, int shift) {
+  const v2s mag = __builtin_elementwise_max(diff, -diff);
+  v2s t = (v2s){ (short)thr, (short)thr } - (mag >> (v2s){ (short)shift, (short)shift });
+  t = __builtin_elementwise_max(t, (v2s){ 0, 0 });
+  const v2s m = __builtin_elementwise_min(mag, t), sgn = diff >> (v2s){ 15, 15 };
+  return (m ^ sgn) - sgn;
+}
+template <int LS>
+__device__ __forceinline__ void cdef_quad_packed(const uint16_t *p, int pri, int sec, int damping, int dir, int cs, v2s *out) {
+  const uint32_t *c32 = reinterpret_cast<const uint32_t *>(p);
+  const v2s x0 = __builtin_bit_cast(v2s, c32[0]), x1 = __builtin_bit_cast(v2s, c32[1]);
+  v2s s0 = { 0, 0 }, s1 = { 0, 0 }, mx0 = x0, mx1 = x1, mn0 = x0, mn1 = x1;
+  const int pshift = pri ? max(0, damping - msb(pri)) : 0, sshift = sec ? max(0, damping - msb(sec)) : 0;
+  const int pt0 = ((pri >> cs) & 1) ? 3 : 4, pt1 = ((pri >> cs) & 1) ? 3 : 2;
+  auto tap = [&](int off, int thr, int shift, int w) {
+    // the four samples at p + off .. p + off + 3 as two packed pairs; off may be odd: funnel-shift three aligned dwords
+    const int odd = off & 1;
+    const uint32_t *q = reinterpret_cast<const uint32_t *>(p + off - odd);
+    const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
+    const v2s a0 = __builtin_bit_cast(v2s, __builtin_amdgcn_alignbit(d1, d0, odd * 16));
+    const v2s a1 = __builtin_bit_cast(v2s, __builtin_amdgcn_alignbit(d2, d1, odd * 16));
+    const v2s ww = { (short)w, (short)w };
+    s0 += ww * pk_constrain(a0 - x0, thr, shift); s1 += ww * pk_constrain(a1 - x1, thr, shift);
+    mx0 = __builtin_elementwise_max(mx0, a0); mx1 = __builtin_elementwise_max(mx1, a1);
+    mn0 = __builtin_elementwise_min(mn0, a0); mn1 = __builtin_elementwise_min(mn1, a1);
+  };
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const int o0 = kCdefDir[dir][k][0] * LS + kCdefDir[dir][k][1];
+    const int o1 = kCdefDir[(dir + 2) & 7][k][0] * LS + kCdefDir[(dir + 2) & 7][k][1];
+    const int o2 = kCdefDir[(dir + 6) & 7][k][0] * LS + kCdefDir[(dir + 6) & 7][k][1];
+    const int ptap = k ? pt1 : pt0, stap = k ? 1 : 2;
+    tap(o0, pri, pshift, ptap); tap(-o0, pri, pshift, ptap);
+    tap(o1, sec, sshift, stap); tap(-o1, sec, sshift, stap);
+    tap(o2, sec, sshift, stap); tap(-o2, sec, sshift, stap);
+  }
+  const v2s eight = { 8, 8 }, four = { 4, 4 }, fifteen = { 15, 15 };
+  const v2s y0 = x0 + ((s0 + (s0 >> fifteen) + eight) >> four), y1 = x1 + ((s1 + (s1 >> fifteen) + eight) >> four);
+  out[0] = __builtin_elementwise_min(__builtin_elementwise_max(y0, mn0), mx0);
+  out[1] = __builtin_elementwise_min(__builtin_elementwise_max(y1, mn1), mx1);
+}
+
 template <typename Pix>
 __global__ __launch_bounds__(256) void k_cdef(CdefLaunch L) {
   constexpr int YS = 64 + 4 + 2, CSZ = 32 + 4 + 2;   // LDS row strides (halo 2 each side, +2 pad)
-  __shared__ uint16_t ty[(64 + 4) * YS];
-  __shared__ uint16_t tc[2][(32 + 4) * CSZ];
+  __shared__ __attribute__((aligned(16))) uint16_t ty[(64 + 4) * YS + 8];
+  __shared__ __attribute__((aligned(16))) uint16_t tc[2][(32 + 4) * CSZ + 8];
   __shared__ uint8_t bdir[64];
   __shared__ int bvar[64];
   const int tid = threadIdx.x;
@@ -80,6 +126,8 @@ __global__ __launch_bounds__(256) void k_cdef(CdefLaunch L) {
   const int sbw = (L.w + 63) / 64;
   const uint8_t *st = L.sb_strength + ((size_t)f * L.sb_frame_stride + (size_t)sby * sbw + sbx) * 4;
   const bool enabled = st[0] != 255;
+  // every tap of this superblock inside the picture?  (then the tile holds no sentinel and the packed path applies)
+  const bool interior = sbx > 0 && sby > 0 && sbx * 64 + 66 <= L.w && sby * 64 + 66 <= L.h;
   // direction search: lane b of wave 0 owns 8x8 block b (raster within the superblock)
   if (tid < 64 && enabled) {
     const int by = tid >> 3, bx = tid & 7;
@@ -147,8 +195,14 @@ __global__ __launch_bounds__(256) void k_cdef(CdefLaunch L) {
       const int vs = (var >> 6) ? min(msb((unsigned)(var >> 6)), 12) : 0;
       const int pri = var ? (ypri0 * (4 + vs) + 8) >> 4 : 0;
       const int dir = ypri0 == 0 ? 0 : bdir[b];
+      if (interior) {
+        v2s r[2];
+        cdef_quad_packed<YS>(p, pri, ysec, L.damping + cs, dir, cs, r);
+        o[0] = r[0].x; o[1] = r[0].y; o[2] = r[1].x; o[3] = r[1].y;
+      } else {
 #pragma unroll
-      for (int k = 0; k < 4; k++) o[k] = cdef_sample<YS>(p + k, pri, ysec, L.damping + cs, dir, cs);
+        for (int k = 0; k < 4; k++) o[k] = cdef_sample<YS>(p + k, pri, ysec, L.damping + cs, dir, cs);
+      }
     }
     Pix *d = dy + (size_t)fy * L.stride_y + fx;
     if constexpr (sizeof(Pix) == 1) *reinterpret_cast<uint32_t *>(d) = (uint32_t)o[0] | ((uint32_t)o[1] << 8) | ((uint32_t)o[2] << 16) | ((uint32_t)o[3] << 24);
@@ -165,8 +219,14 @@ __global__ __launch_bounds__(256) void k_cdef(CdefLaunch L) {
     if (skip) { o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; o[3] = p[3]; }
     else {
       const int dir = upri == 0 ? 0 : bdir[b];
+      if (interior) {
+        v2s r[2];
+        cdef_quad_packed<CSZ>(p, upri, usec, L.damping + cs - 1, dir, cs, r);
+        o[0] = r[0].x; o[1] = r[0].y; o[2] = r[1].x; o[3] = r[1].y;
+      } else {
 #pragma unroll
-      for (int k = 0; k < 4; k++) o[k] = cdef_sample<CSZ>(p + k, upri, usec, L.damping + cs - 1, dir, cs);
+        for (int k = 0; k < 4; k++) o[k] = cdef_sample<CSZ>(p + k, upri, usec, L.damping + cs - 1, dir, cs);
+      }
     }
     Pix *d = reinterpret_cast<Pix *>(L.dst[1 + pl]) + (size_t)f * chh * L.stride_uv + (size_t)fy * L.stride_uv + fx;
     if constexpr (sizeof(Pix) == 1) *reinterpret_cast<uint32_t *>(d) = (uint32_t)o[0] | ((uint32_t)o[1] << 8) | ((uint32_t)o[2] << 16) | ((uint32_t)o[3] << 24);
