@@ -110,24 +110,47 @@ __global__ __launch_bounds__(256) void k_cdef(CdefLaunch L) {
   const Pix *sy = reinterpret_cast<const Pix *>(L.src[0]) + (size_t)f * L.h * L.stride_y;
   Pix *dy = reinterpret_cast<Pix *>(L.dst[0]) + (size_t)f * L.h * L.stride_y;
   const int cw = L.w / 2, chh = L.h / 2;
-  // stage luma 68x68 and chroma 36x36 x2
-  for (int i = tid; i < 68 * 68; i += 256) {
-    const int r = i / 68, c = i - r * 68;
-    const int fy = sby * 64 - 2 + r, fx = sbx * 64 - 2 + c;
-    ty[r * YS + c] = (fy >= 0 && fy < L.h && fx >= 0 && fx < L.w) ? (uint16_t)sy[(size_t)fy * L.stride_y + fx] : (uint16_t)0xFFFF;
-  }
-  for (int i = tid; i < 2 * 36 * 36; i += 256) {
-    const int pl = i / (36 * 36), j = i - pl * 36 * 36, r = j / 36, c = j - r * 36;
-    const int fy = sby * 32 - 2 + r, fx = sbx * 32 - 2 + c;
-    const Pix *sc = reinterpret_cast<const Pix *>(L.src[1 + pl]) + (size_t)f * chh * L.stride_uv;
-    tc[pl][r * CSZ + c] = (fy >= 0 && fy < chh && fx >= 0 && fx < cw) ? (uint16_t)sc[(size_t)fy * L.stride_uv + fx] : (uint16_t)0xFFFF;
+  // every tap of this superblock inside the picture?  (then the tile holds no sentinel and the packed path applies)
+  const bool interior = sbx > 0 && sby > 0 && sbx * 64 + 66 <= L.w && sby * 64 + 66 <= L.h;
+  // stage luma 68x68 and chroma 36x36 x2 (local (0,0) = picture (sb*64-2, sb*64-2))
+  if (interior) {
+    // no bounds to check: 4-sample aligned loads starting 4 samples left of the block (18 per row), the tile keeps only
+    // the 2-sample halo, so local column = aligned column - 2
+    for (int i = tid; i < 68 * 18; i += 256) {
+      const int r = i / 18, g = i - r * 18;
+      const Pix *q = sy + (size_t)(sby * 64 - 2 + r) * L.stride_y + sbx * 64 - 4 + g * 4;
+      int v[4];
+      if constexpr (sizeof(Pix) == 1) { const uint32_t u = *reinterpret_cast<const uint32_t *>(q); v[0] = u & 255; v[1] = (u >> 8) & 255; v[2] = (u >> 16) & 255; v[3] = u >> 24; }
+      else { const uint2 u = *reinterpret_cast<const uint2 *>(q); v[0] = u.x & 0xffff; v[1] = u.x >> 16; v[2] = u.y & 0xffff; v[3] = u.y >> 16; }
+#pragma unroll
+      for (int k = 0; k < 4; k++) { const int c = g * 4 + k - 2; if (c >= 0 && c < 68) ty[r * YS + c] = (uint16_t)v[k]; }
+    }
+    for (int i = tid; i < 2 * 36 * 10; i += 256) {
+      const int pl = i / 360, j = i - pl * 360, r = j / 10, g = j - r * 10;
+      const Pix *q = reinterpret_cast<const Pix *>(L.src[1 + pl]) + (size_t)f * chh * L.stride_uv + (size_t)(sby * 32 - 2 + r) * L.stride_uv + sbx * 32 - 4 + g * 4;
+      int v[4];
+      if constexpr (sizeof(Pix) == 1) { const uint32_t u = *reinterpret_cast<const uint32_t *>(q); v[0] = u & 255; v[1] = (u >> 8) & 255; v[2] = (u >> 16) & 255; v[3] = u >> 24; }
+      else { const uint2 u = *reinterpret_cast<const uint2 *>(q); v[0] = u.x & 0xffff; v[1] = u.x >> 16; v[2] = u.y & 0xffff; v[3] = u.y >> 16; }
+#pragma unroll
+      for (int k = 0; k < 4; k++) { const int c = g * 4 + k - 2; if (c >= 0 && c < 36) tc[pl][r * CSZ + c] = (uint16_t)v[k]; }
+    }
+  } else {
+    for (int i = tid; i < 68 * 68; i += 256) {
+      const int r = i / 68, c = i - r * 68;
+      const int fy = sby * 64 - 2 + r, fx = sbx * 64 - 2 + c;
+      ty[r * YS + c] = (fy >= 0 && fy < L.h && fx >= 0 && fx < L.w) ? (uint16_t)sy[(size_t)fy * L.stride_y + fx] : (uint16_t)0xFFFF;
+    }
+    for (int i = tid; i < 2 * 36 * 36; i += 256) {
+      const int pl = i / (36 * 36), j = i - pl * 36 * 36, r = j / 36, c = j - r * 36;
+      const int fy = sby * 32 - 2 + r, fx = sbx * 32 - 2 + c;
+      const Pix *sc = reinterpret_cast<const Pix *>(L.src[1 + pl]) + (size_t)f * chh * L.stride_uv;
+      tc[pl][r * CSZ + c] = (fy >= 0 && fy < chh && fx >= 0 && fx < cw) ? (uint16_t)sc[(size_t)fy * L.stride_uv + fx] : (uint16_t)0xFFFF;
+    }
   }
   __syncthreads();
   const int sbw = (L.w + 63) / 64;
   const uint8_t *st = L.sb_strength + ((size_t)f * L.sb_frame_stride + (size_t)sby * sbw + sbx) * 4;
   const bool enabled = st[0] != 255;
-  // every tap of this superblock inside the picture?  (then the tile holds no sentinel and the packed path applies)
-  const bool interior = sbx > 0 && sby > 0 && sbx * 64 + 66 <= L.w && sby * 64 + 66 <= L.h;
   // direction search: lane b of wave 0 owns 8x8 block b (raster within the superblock)
   if (tid < 64 && enabled) {
     const int by = tid >> 3, bx = tid & 7;
