@@ -45,8 +45,6 @@ namespace av1mi {
 __device__ unsigned long long av1mi_stamp_out[8];
 #endif
 
-__device__ constexpr int kCand[11] = { DC_PRED, V_PRED, H_PRED, D45_PRED, D135_PRED, D113_PRED, D157_PRED, D203_PRED,
-                                       D67_PRED, SMOOTH_PRED, PAETH_PRED };
 
 __device__ __forceinline__ unsigned morton2(unsigned x, unsigned y) {
   unsigned m = 0;
@@ -77,7 +75,7 @@ template <int B, int GW, typename Pix>
 __device__ __forceinline__ int code_block(const TileCtx<Pix> &C, int lane, int bx, int by, int n, int n_top, int n_topright, int n_left,
                                           int n_bottomleft, int filter_type, int dc_q, int ac_q, const Pix *src_row,
                                           Pix *rec_row, int16_t *lev_row STAMP_ARGS) {
-  constexpr int RS = B + 4, bd = sizeof(Pix) == 1 ? 8 : 10;
+  constexpr int bd = sizeof(Pix) == 1 ? 8 : 10;
   using ES = Pix;
   const int x = bx * B, y = by * B;
   auto fetch = [&](int yy, int xx) -> int {
@@ -103,8 +101,10 @@ __device__ __forceinline__ int code_block(const TileCtx<Pix> &C, int lane, int b
     best = better ? sad : best; best_mode = better ? MODE : best_mode;
 #pragma unroll
     for (int c = 0; c < B; c++) bp[c] = better ? out[c] : bp[c];
+    // keep the scheduler from hoisting the next candidates' LDS reads above this one: that costs ~100 VGPRs and a wave per SIMD
+    __builtin_amdgcn_sched_barrier(0);
   };
-  // candidate order == kCand == oracle/av1o_pipeline.c:intra_candidates (first minimum wins)
+  // candidate order == oracle/av1o_pipeline.c:intra_candidates (first minimum wins)
   eval(std::integral_constant<int, DC_PRED>{});   eval(std::integral_constant<int, V_PRED>{});
   eval(std::integral_constant<int, H_PRED>{});    eval(std::integral_constant<int, D45_PRED>{});
   eval(std::integral_constant<int, D135_PRED>{}); eval(std::integral_constant<int, D113_PRED>{});
@@ -130,7 +130,7 @@ __device__ __forceinline__ int code_block(const TileCtx<Pix> &C, int lane, int b
 }
 
 template <int BS, typename Pix>
-__global__ __launch_bounds__(256) void k_intra_pipe(IntraPipeLaunch L) {
+__global__ __launch_bounds__(256, BS == 8 ? 3 : 1) void k_intra_pipe(IntraPipeLaunch L) {
   constexpr int CS = BS / 2, N = 64 / BS, TPW = 256 / BS;
   using ES = Pix;                                      // LDS sample type: 1 byte for 8-bit content, 2 for 10-bit
   constexpr int ELY = fast_edge_len(BS), ELC = fast_edge_len(CS);

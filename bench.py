@@ -127,7 +127,7 @@ def main():
 
     if args.workload.startswith("1080p8"):
         W, H, bd = 1920, 1080, 8
-        frames = args.frames or 32
+        frames = args.frames or 48   # 48 frames x 510 tiles / 8 tiles per wave = 12 waves per CU: one full generation
     else:
         W, H, bd = 3840, 2160, 10
         frames = args.frames or 8
