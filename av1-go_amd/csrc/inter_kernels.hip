@@ -33,49 +33,68 @@ __constant__ int16_t kRegular4[16][8] = {
   { 0, 0, -8, 38, 110, -12, 0, 0 }, { 0, 0, -6, 28, 116, -10, 0, 0 }, { 0, 0, -4, 18, 122, -8, 0, 0 }, { 0, 0, -2, 8, 126, -4, 0, 0 } };
 
 // ------------------------------------------------------------------------------------------ integer search
+// The search runs on the 8 most significant bits of the samples (10-bit content is shifted down by 2: encoder policy,
+// mirrored by the oracle), which lets one v_qsad_pk_u16_u8 score FOUR horizontally adjacent candidate vectors against
+// four source samples at once.  A lane owns (dy, group of 4 dx): per block row it reads 12 reference bytes (three
+// aligned dwords) and issues two QSADs with the row's two source dwords, which all lanes read from the same LDS address.
 template <typename Pix>
 __global__ __launch_bounds__(256) void k_me_int(InterLaunch L) {
-  constexpr int MAXR = 15, WS = 64 + 2 * MAXR + 2;   // window row stride
-  __shared__ Pix win[(64 + 2 * MAXR) * WS];
-  __shared__ Pix srct[64 * 64];
-  const int tid = threadIdx.x, R = L.range, WD = 64 + 2 * R, NC = 2 * R + 1;
+  constexpr int MAXR = 16, WS = 64 + 2 * MAXR + 16;   // window row stride in bytes (multiple of 4)
+  __shared__ __attribute__((aligned(16))) uint8_t win[(64 + 2 * MAXR) * WS];
+  __shared__ __attribute__((aligned(16))) uint8_t srct[64 * 64];
+  constexpr int sh = sizeof(Pix) == 1 ? 0 : 2;
+  const int tid = threadIdx.x, R = L.range, R4 = (R + 3) & ~3, NC = 2 * R + 1;
+  const int WDX = 64 + 2 * R4 + 4, WDY = 64 + 2 * R;        // window columns start at x - R4 (4-aligned), rows at y - R
   const int sbw = (L.w + 63) / 64;
   const int f = blockIdx.y, sb = blockIdx.x, sby = sb / sbw, sbx = sb % sbw;
   const Pix *src = reinterpret_cast<const Pix *>(L.src[0]) + (size_t)f * L.h * L.stride_y;
   const Pix *ref = reinterpret_cast<const Pix *>(L.ref[0]) + (size_t)f * L.h * L.stride_y;
-  for (int i = tid; i < WD * WD; i += 256) {
-    const int r = i / WD, c = i - r * WD;
-    const int fy = min(max(sby * 64 - R + r, 0), L.h - 1), fx = min(max(sbx * 64 - R + c, 0), L.w - 1);
-    win[r * WS + c] = ref[(size_t)fy * L.stride_y + fx];
+  for (int i = tid; i < WDY * WDX; i += 256) {
+    const int r = i / WDX, c = i - r * WDX;
+    const int fy = min(max(sby * 64 - R + r, 0), L.h - 1), fx = min(max(sbx * 64 - R4 + c, 0), L.w - 1);
+    win[r * WS + c] = (uint8_t)(ref[(size_t)fy * L.stride_y + fx] >> sh);
   }
   for (int i = tid; i < 64 * 64; i += 256) {
     const int r = i >> 6, c = i & 63;
     const int fy = min(sby * 64 + r, L.h - 1), fx = min(sbx * 64 + c, L.w - 1);
-    srct[i] = src[(size_t)fy * L.stride_y + fx];
+    srct[i] = (uint8_t)(src[(size_t)fy * L.stride_y + fx] >> sh);
   }
   __syncthreads();
   const int wave = tid >> 6, lane = tid & 63;
   const int bw = L.w / 8, bh = L.h / 8;
+  const int NG = (2 * R4) / 4 + 1;                 // groups of four dx starting at -R4
   int16_t *mvs = L.mvs + (size_t)f * bw * bh * 2;
-  for (int b = wave; b < 64; b += 4) {   // 16 blocks per wave
+  for (int b = wave; b < 64; b += 4) {             // 16 blocks per wave
     const int by = b >> 3, bx = b & 7;
     const int fbx = sbx * 8 + bx, fby = sby * 8 + by;
     if (fbx >= bw || fby >= bh) continue;
     unsigned best = 0xFFFFFFFFu;
-    for (int c0 = 0; c0 < NC * NC; c0 += 64) {
-      const int cand = c0 + lane;
-      if (cand < NC * NC) {
-        const int dy = cand / NC - R, dx = cand - (cand / NC) * NC - R;
-        const Pix *p = win + (by * 8 + dy + R) * WS + bx * 8 + dx + R;
-        const Pix *s = srct + (by * 8) * 64 + bx * 8;
-        int sad = 0;
+    for (int t0 = 0; t0 < NC * NG; t0 += 64) {
+      const int t = t0 + lane;
+      if (t < NC * NG) {
+        const int dyi = t / NG, g = t - dyi * NG;  // dy = dyi - R, dx0 = -R4 + 4 g
+        const uint8_t *p = win + (by * 8 + dyi) * WS + bx * 8 + 4 * g;
+        const uint8_t *s = srct + (by * 8) * 64 + bx * 8;
+        unsigned long long acc = 0;
 #pragma unroll
-        for (int r = 0; r < 8; r++)
+        for (int r = 0; r < 8; r++) {
+          const uint32_t *q = reinterpret_cast<const uint32_t *>(p + r * WS);
+          const uint2 sr = *reinterpret_cast<const uint2 *>(s + r * 64);
+          const unsigned long long w01 = (unsigned long long)q[0] | ((unsigned long long)q[1] << 32);
+          const unsigned long long w12 = (unsigned long long)q[1] | ((unsigned long long)q[2] << 32);
+          acc = __builtin_amdgcn_qsad_pk_u16_u8(w01, sr.x, acc);
+          acc = __builtin_amdgcn_qsad_pk_u16_u8(w12, sr.y, acc);
+        }
 #pragma unroll
-          for (int c = 0; c < 8; c++) sad += abs((int)s[r * 64 + c] - (int)p[r * WS + c]);
-        // (0,0) ranks first, the others in raster order; ties keep the lower rank
-        const unsigned key = (unsigned)sad * 1024u + ((dx | dy) ? (unsigned)cand + 1u : 0u);
-        best = min(best, key);
+        for (int i = 0; i < 4; i++) {
+          const int dx = -R4 + 4 * g + i, dy = dyi - R;
+          if (dx >= -R && dx <= R) {
+            const unsigned sad = (unsigned)(acc >> (16 * i)) & 0xFFFFu;
+            // (0,0) ranks first, the others in raster order; ties keep the lower rank
+            const unsigned key = sad * 1024u + ((dx | dy) ? (unsigned)((dy + R) * NC + dx + R) + 1u : 0u);
+            best = min(best, key);
+          }
+        }
       }
     }
 #pragma unroll
@@ -126,6 +145,43 @@ __device__ __forceinline__ void mc_row(const ES *win, int ws, int16_t *im, int l
   AV1MI_GROUP_SYNC();
 }
 
+// The same filter split in two, so that the candidates of a refinement round that share a horizontal phase share its
+// (more expensive) horizontal pass: mc_h16 filters all 16 rows of the luma window for one horizontal displacement,
+// mc_v8 produces row `lane` of the prediction for one vertical displacement from that intermediate.
+template <typename ES>
+__device__ __forceinline__ void mc_h16(const ES *win, int ws, int16_t *im, int lane, int posx, const int16_t (*filt)[8]) {
+  const int ox = 4 + (posx >> 4) - 3;
+  int fx[8];
+#pragma unroll
+  for (int t = 0; t < 8; t++) fx[t] = filt[posx & 15][t];
+#pragma unroll
+  for (int it = 0; it < 2; it++) {
+    const int j = lane + it * 8;
+    const ES *p = win + j * ws + ox;
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+      int s = 0;
+#pragma unroll
+      for (int t = 0; t < 8; t++) s += fx[t] * (int)p[c + t];
+      im[j * 8 + c] = (int16_t)((s + 4) >> 3);
+    }
+  }
+}
+__device__ __forceinline__ void mc_v8(const int16_t *im, int lane, int posy, const int16_t (*filt)[8], int bd, int *out) {
+  const int oy = 4 + (posy >> 4) - 3;
+  int fy[8];
+#pragma unroll
+  for (int t = 0; t < 8; t++) fy[t] = filt[posy & 15][t];
+  const int maxpix = (1 << bd) - 1;
+#pragma unroll
+  for (int c = 0; c < 8; c++) {
+    int s = 0;
+#pragma unroll
+    for (int t = 0; t < 8; t++) s += fy[t] * (int)im[(oy + lane + t) * 8 + c];
+    out[c] = min(max((s + 1024) >> 11, 0), maxpix);
+  }
+}
+
 template <typename Pix>
 __global__ __launch_bounds__(256) void k_inter_pipe(InterLaunch L) {
   using ES = Pix;
@@ -135,7 +191,7 @@ __global__ __launch_bounds__(256) void k_inter_pipe(InterLaunch L) {
   constexpr int CW = 12, CWS = 14;               // chroma window 12 x 12 (chroma integer position -4 .. +7)
   constexpr int WIN_N = YW * YWS + 2 * CW * CWS;
   constexpr int WIN_BYTES = ((WIN_N * (int)sizeof(ES) + 127) / 128) * 128 + 16;
-  constexpr int IM_N = 15 * 8 + 8;               // luma intermediate 15 x 8 (chroma 2 x 11 x 4 fits inside)
+  constexpr int IM_N = 16 * 8 + 8;               // luma intermediate 16 x 8 (chroma 2 x 11 x 4 fits inside)
   constexpr int T_N = ((8 * 12 + 31) / 32) * 32 + 8;
   __shared__ __attribute__((aligned(16))) unsigned char winb[GPW * WIN_BYTES];
   __shared__ __attribute__((aligned(16))) int16_t imb[GPW * IM_N];
@@ -179,17 +235,28 @@ __global__ __launch_bounds__(256) void k_inter_pipe(InterLaunch L) {
   mc_row<8, ES>(wy, YWS, im, lane, 0, 0, kRegular8, bd, bp);
   int best = sad_of(bp), bfx = 0, bfy = 0;     // fractional part in 1/8 samples relative to the integer vector
   for (int step = 4; step >= 2; step >>= 1) {
+    // the 8 neighbours of (cx, cy): column by column, one horizontal pass per column of candidates.  The oracle visits
+    // them in raster order k = 0..8 with strict improvement, i.e. the winner is the minimum of (SAD, k) and the centre
+    // keeps ties; that order is reproduced with an explicit rank.
     const int cx = bfx, cy = bfy;
+    int rbest = -1;                                  // rank of the current best inside this round (-1: the centre)
 #pragma unroll 1
-    for (int k = 0; k < 9; k++) {
-      if (k == 4) continue;
-      const int fx = cx + (k % 3 - 1) * step, fy = cy + (k / 3 - 1) * step;
-      mc_row<8, ES>(wy, YWS, im, lane, fx * 2, fy * 2, kRegular8, bd, out);
-      const int sd = sad_of(out);
-      const bool better = sd < best;
-      best = better ? sd : best; bfx = better ? fx : bfx; bfy = better ? fy : bfy;
+    for (int ix = 0; ix < 3; ix++) {
+      const int fx = cx + (ix - 1) * step;
+      mc_h16<ES>(wy, YWS, im, lane, fx * 2, kRegular8);
+      AV1MI_GROUP_SYNC();
+#pragma unroll 1
+      for (int iy = 0; iy < 3; iy++) {
+        if (ix == 1 && iy == 1) continue;
+        const int fy = cy + (iy - 1) * step, k = iy * 3 + ix;
+        mc_v8(im, lane, fy * 2, kRegular8, bd, out);
+        const int sd = sad_of(out);
+        const bool better = sd < best || (sd == best && rbest >= 0 && k < rbest);
+        best = better ? sd : best; bfx = better ? fx : bfx; bfy = better ? fy : bfy; rbest = better ? k : rbest;
 #pragma unroll
-      for (int c = 0; c < 8; c++) bp[c] = better ? out[c] : bp[c];
+        for (int c = 0; c < 8; c++) bp[c] = better ? out[c] : bp[c];
+      }
+      AV1MI_GROUP_SYNC();
     }
   }
   const int mvx = imx * 8 + bfx, mvy = imy * 8 + bfy;   // final vector, 1/8 luma samples

@@ -152,7 +152,7 @@ int av1o_intra_encode_frame(const void *src_y, const void *src_u, const void *sr
  * Inter (P) frame encoder loop (BASELINE config 3), the checker of k_me_int + k_inter_pipe.
  * Encoder policy (ours, non-normative): every block bs x bs (8) is inter-predicted from ONE reference frame
  * (the previous reconstructed, loop-filtered frame); integer full search +-range around the co-located block
- * by SAD ((0,0) first, then raster order, strict improvement), then one half-pel and one quarter-pel refinement
+ * by SAD of the 8 most significant bits ((0,0) first, then raster order, strict improvement), then one half-pel and one quarter-pel refinement
  * round (8 neighbours each, fixed order, strict improvement) with the regular 8-tap filter; chroma uses the same
  * vector; DCT_DCT residual coding as in the intra loop.  The prediction arithmetic is av1o_mc_block (spec 7.11.3.4).
  * mvs: int16 pairs (x, y) in 1/8 luma sample units, one per block, raster.  skip: 1 = all levels of the block zero.
@@ -160,6 +160,14 @@ int av1o_intra_encode_frame(const void *src_y, const void *src_u, const void *sr
 int av1o_mc_block(const void *ref, int stride, int plane_w, int plane_h, int bd, int x, int y, int w, int h, int mvx,
                   int mvy, int filt_x, int filt_y, uint16_t *pred);
 
+/* integer-search cost: SAD on the 8 most significant bits of source and prediction (policy of k_me_int) */
+static long block_sad8(const void *src, int stride, int bd, int x, int y, int bs, const uint16_t *pred) {
+  long s = 0;
+  for (int r = 0; r < bs; r++)
+    for (int c = 0; c < bs; c++)
+      s += labs((long)(px_get(src, bd, (size_t)(y + r) * stride + x + c) >> (bd - 8)) - (pred[r * bs + c] >> (bd - 8)));
+  return s;
+}
 static long block_sad(const void *src, int stride, int bd, int x, int y, int bs, const uint16_t *pred) {
   long s = 0;
   for (int r = 0; r < bs; r++)
@@ -197,15 +205,18 @@ int av1o_inter_encode_frame(const void *src_y, const void *src_u, const void *sr
       const size_t blk = (size_t)by * bw + bx;
       /* integer search */
       av1o_mc_block(ref_y, stride_y, w, h, bd, x, y, bs, bs, 0, 0, 0, 0, pred);
-      long best = block_sad(src_y, stride_y, bd, x, y, bs, pred);
+      long best = block_sad8(src_y, stride_y, bd, x, y, bs, pred);
       int bmx = 0, bmy = 0;   /* 1/8 units */
       for (int dy = -range; dy <= range; dy++)
         for (int dx = -range; dx <= range; dx++) {
           if (!dx && !dy) continue;
           av1o_mc_block(ref_y, stride_y, w, h, bd, x, y, bs, bs, dx * 16, dy * 16, 0, 0, pred);
-          const long s = block_sad(src_y, stride_y, bd, x, y, bs, pred);
+          const long s = block_sad8(src_y, stride_y, bd, x, y, bs, pred);
           if (s < best) { best = s; bmx = dx * 8; bmy = dy * 8; }
         }
+      /* the refinement compares full-precision SADs, starting from the integer winner's */
+      av1o_mc_block(ref_y, stride_y, w, h, bd, x, y, bs, bs, bmx * 2, bmy * 2, 0, 0, pred);
+      best = block_sad(src_y, stride_y, bd, x, y, bs, pred);
       /* half-pel then quarter-pel refinement */
       for (int step = 4; step >= 2; step >>= 1) {
         const int cx = bmx, cy = bmy;
