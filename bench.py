@@ -68,6 +68,30 @@ def cpu_baseline(pipe, seconds=12.0):
                       "restoration (same stages as the GPU step) in %.1f s" % (done, dt)}
 
 
+PMC_KERNEL = {"intra_pipeline": "k_intra_pipe", "deblock": "k_deblock", "cdef": "k_cdef", "loop_restoration": "k_lr",
+              "inter_pipeline": "k_inter_pipe"}
+
+
+def pmc_traffic(kind, workload, frames):
+    """HBM bytes per launch of the kernel behind `kind` from the committed rocprofv3 PMC passes (profiles/, made by
+    tools/prof_pmc.sh + tools/pmc_to_json.py on the same command): reads = 2 x FETCH_SIZE (gfx950 tallies a 128-B read
+    request as 64 B; confirmed on this box for 8- and 16-byte-per-lane streams, see "calibration" in the file) + WRITE_SIZE,
+    scaled to this run's frames per step.  None when no matching profile is committed (PMC cannot be read live)."""
+    tag = {"1080p8": "1080p8_intra"}.get(workload)
+    if tag is None:
+        return None
+    path = os.path.join(ROOT, "profiles", "pmc_%s_latest.json" % tag)
+    try:
+        prof = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    for name, d in prof["kernels"].items():
+        if name.startswith(PMC_KERNEL.get(kind, "?")):
+            corr = (prof.get("calibration") or {}).get("read_correction_8B_per_lane") or 2.0
+            return (d["fetch_bytes_uncorrected"] * corr + d["write_bytes"]) * frames / prof["frames_per_step"]
+    return None
+
+
 def segment_of_rank(rank, frames_per_step):
     """closed-GOP sharding: rank r codes the r-th run of frames_per_step frames (no data exchanged between ranks)"""
     return rank * frames_per_step
@@ -180,7 +204,7 @@ def main():
         n, ms = prof[dom]
         ach = alg[dom] / (ms / n * 1e-3) / 1e9
         out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                           "frac": ach / HBM_PEAK_GBPS, "traffic": None, "algorithmic_bytes_per_launch": alg[dom],
+                           "frac": ach / HBM_PEAK_GBPS, "traffic": pmc_traffic(dom, args.workload, frames), "algorithmic_bytes_per_launch": alg[dom],
                            "avg_launch_ms": ms / n, "launches": n}
         out["kernels"] = {k: {"launches": v[0], "avg_ms": v[1] / v[0], "algorithmic_GBps": alg[k] / (v[1] / v[0] * 1e-3) / 1e9}
                           for k, v in prof.items()}

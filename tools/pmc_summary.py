@@ -9,7 +9,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 acc = defaultdict(lambda: defaultdict(list))
 for f in glob.glob("gpurun_out/pmc_%s/pass*/**/*counter_collection.csv" % tag, recursive=True):
     for row in csv.DictReader(open(f)):
-        k = row["Kernel_Name"].split("(")[0].replace("void av1mi::", "")
+        k = row["Kernel_Name"].split("(")[0].replace("void ", "").replace("av1mi::", "")
         acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k in sorted(acc):
     print(k)
