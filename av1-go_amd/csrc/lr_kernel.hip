@@ -25,9 +25,9 @@ __device__ constexpr int kSgrParams[16][4] = {
 
 template <typename Pix>
 __global__ __launch_bounds__(256) void k_lr(LrLaunch L) {
-  constexpr int MAXH = 64, MAXW = 64, SS = MAXW + 6 + 2;   // source tile row stride (u16)
+  constexpr int MAXH = 64, MAXW = 64, SS = MAXW + 16;      // source tile row stride (u16): tile column 0 = X0 - 4
   constexpr int AS = MAXW + 2 + 2;                         // A/B row stride
-  __shared__ uint16_t src[(MAXH + 6) * SS];
+  __shared__ __attribute__((aligned(16))) uint16_t src[(MAXH + 6) * SS];
   __shared__ __attribute__((aligned(16))) unsigned char scratch[(MAXH + 2) * AS * 2 + (MAXH + 2) * AS * 4];
   int16_t *inter = reinterpret_cast<int16_t *>(scratch);                       // Wiener: (SH+6) x tw
   uint16_t *Abuf = reinterpret_cast<uint16_t *>(scratch);                      // self-guided: (SH+2) x (tw+2)
@@ -56,15 +56,36 @@ __global__ __launch_bounds__(256) void k_lr(LrLaunch L) {
     }
     return;
   }
-  // stage (bh + 6) x (bw + 6) source samples, local (0,0) == (y0 - 3, X0 - 3)
-  for (int i = tid; i < (bh + 6) * (bw + 6); i += 256) {
-    const int r = i / (bw + 6), c = i - r * (bw + 6);
-    const int x = min(max(X0 - 3 + c, 0), L.w - 1);
-    int y = min(max(y0 - 3 + r, 0), L.h - 1);
-    const Pix *p = cdef;
-    if (y < sstart) { y = max(sstart - 2, y); p = dbl; }
-    else if (y > send) { y = min(send + 2, y); p = dbl; }
-    src[r * SS + c] = p[(size_t)y * L.stride + x];
+  // stage (bh + 6) rows x (bw + 8) columns of source samples: local row 0 == y0 - 3, local column 0 == X0 - 4 (4-aligned)
+  const bool xin = X0 >= 4 && X0 + bw + 4 <= L.w && !(bw & 3);   // no horizontal clamping, whole 4-sample groups
+  if (xin) {
+    const int ng = (bw + 8) / 4;
+    for (int i = tid; i < (bh + 6) * ng; i += 256) {
+      const int r = i / ng, g = i - r * ng;
+      int y = min(max(y0 - 3 + r, 0), L.h - 1);
+      const Pix *p = cdef;
+      if (y < sstart) { y = max(sstart - 2, y); p = dbl; }
+      else if (y > send) { y = min(send + 2, y); p = dbl; }
+      const Pix *q = p + (size_t)y * L.stride + X0 - 4 + 4 * g;
+      uint2 o;
+      if (((uintptr_t)q & (4 * sizeof(Pix) - 1)) == 0) {
+        if constexpr (sizeof(Pix) == 1) {
+          const uint32_t u = *reinterpret_cast<const uint32_t *>(q);
+          o.x = (u & 255) | ((u & 0xff00) << 8); o.y = ((u >> 16) & 255) | ((u >> 8) & 0xff0000);
+        } else o = *reinterpret_cast<const uint2 *>(q);
+      } else { o.x = (uint32_t)q[0] | ((uint32_t)q[1] << 16); o.y = (uint32_t)q[2] | ((uint32_t)q[3] << 16); }
+      *reinterpret_cast<uint2 *>(src + r * SS + 4 * g) = o;
+    }
+  } else {
+    for (int i = tid; i < (bh + 6) * (bw + 6); i += 256) {
+      const int r = i / (bw + 6), c = i - r * (bw + 6);
+      const int x = min(max(X0 - 3 + c, 0), L.w - 1);
+      int y = min(max(y0 - 3 + r, 0), L.h - 1);
+      const Pix *p = cdef;
+      if (y < sstart) { y = max(sstart - 2, y); p = dbl; }
+      else if (y > send) { y = min(send + 2, y); p = dbl; }
+      src[r * SS + c + 1] = p[(size_t)y * L.stride + x];
+    }
   }
   __syncthreads();
   const int maxpix = (1 << bd) - 1;
@@ -75,21 +96,65 @@ __global__ __launch_bounds__(256) void k_lr(LrLaunch L) {
     vf[3] = 128 - 2 * (U[1] + U[2] + U[3]);
     hf[3] = 128 - 2 * (U[4] + U[5] + U[6]);
     const int offset = 1 << (bd + 3), limit = (1 << (bd + 5)) - 1;
+    if (!(bw & 3)) {
+      // four outputs per lane: ten source samples read once; the vertical pass reads four int16 per tap as one 8-byte word
+      const int q4 = bw / 4;
+      for (int i = tid; i < (bh + 6) * q4; i += 256) {
+        const int r = i / q4, c = (i - r * q4) * 4;
+        const uint16_t *p = src + r * SS + c + 1;
+        int v[10];
+#pragma unroll
+        for (int t = 0; t < 10; t++) v[t] = p[t];
+        int o[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          int sum = 0;
+#pragma unroll
+          for (int t = 0; t < 7; t++) sum += hf[t] * v[k + t];
+          o[k] = min(max((sum + 4) >> 3, -offset), limit - offset);
+        }
+        uint2 w; w.x = (uint32_t)(o[0] & 0xffff) | ((uint32_t)o[1] << 16); w.y = (uint32_t)(o[2] & 0xffff) | ((uint32_t)o[3] << 16);
+        *reinterpret_cast<uint2 *>(inter + r * MAXW + c) = w;
+      }
+      __syncthreads();
+      for (int i = tid; i < bh * q4; i += 256) {
+        const int r = i / q4, c = (i - r * q4) * 4;
+        int sum[4] = { 0, 0, 0, 0 };
+#pragma unroll
+        for (int t = 0; t < 7; t++) {
+          const uint2 w = *reinterpret_cast<const uint2 *>(inter + (r + t) * MAXW + c);
+          sum[0] += vf[t] * (int16_t)(w.x & 0xffff); sum[1] += vf[t] * (int16_t)(w.x >> 16);
+          sum[2] += vf[t] * (int16_t)(w.y & 0xffff); sum[3] += vf[t] * (int16_t)(w.y >> 16);
+        }
+        int o[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) o[k] = min(max((sum[k] + 1024) >> 11, 0), maxpix);
+        Pix *d = out + (size_t)(y0 + r) * L.stride + X0 + c;
+        if (((uintptr_t)d & (4 * sizeof(Pix) - 1)) == 0) {
+          if constexpr (sizeof(Pix) == 1) *reinterpret_cast<uint32_t *>(d) = (uint32_t)o[0] | ((uint32_t)o[1] << 8) | ((uint32_t)o[2] << 16) | ((uint32_t)o[3] << 24);
+          else { uint2 u; u.x = (uint32_t)o[0] | ((uint32_t)o[1] << 16); u.y = (uint32_t)o[2] | ((uint32_t)o[3] << 16); *reinterpret_cast<uint2 *>(d) = u; }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; k++) d[k] = (Pix)o[k];
+        }
+      }
+      return;
+    }
     for (int i = tid; i < (bh + 6) * bw; i += 256) {
       const int r = i / bw, c = i - r * bw;
-      const uint16_t *p = src + r * SS + c;
-      int s = 0;
+      const uint16_t *p = src + r * SS + c + 1;
+      int sum = 0;
 #pragma unroll
-      for (int t = 0; t < 7; t++) s += hf[t] * p[t];
-      inter[r * MAXW + c] = (int16_t)min(max((s + 4) >> 3, -offset), limit - offset);
+      for (int t = 0; t < 7; t++) sum += hf[t] * p[t];
+      inter[r * MAXW + c] = (int16_t)min(max((sum + 4) >> 3, -offset), limit - offset);
     }
     __syncthreads();
     for (int i = tid; i < bh * bw; i += 256) {
       const int r = i / bw, c = i - r * bw;
-      int s = 0;
+      int sum = 0;
 #pragma unroll
-      for (int t = 0; t < 7; t++) s += vf[t] * inter[(r + t) * MAXW + c];
-      out[(size_t)(y0 + r) * L.stride + X0 + c] = (Pix)min(max((s + 1024) >> 11, 0), maxpix);
+      for (int t = 0; t < 7; t++) sum += vf[t] * inter[(r + t) * MAXW + c];
+      out[(size_t)(y0 + r) * L.stride + X0 + c] = (Pix)min(max((sum + 1024) >> 11, 0), maxpix);
     }
     return;
   }
@@ -106,7 +171,7 @@ __global__ __launch_bounds__(256) void k_lr(LrLaunch L) {
     for (int q = tid; q < (bh + 2) * (bw + 2); q += 256) {
       const int i = q / (bw + 2) - 1, j = q % (bw + 2) - 1;
       if (pass == 0 && !((y0 + i) & 1)) continue;            // the r = 2 pass only ever reads odd rows
-      const uint16_t *p = src + (i + 3) * SS + (j + 3);
+      const uint16_t *p = src + (i + 3) * SS + (j + 4);
       unsigned a = 0, b = 0;
       for (int dy = -r; dy <= r; dy++)
         for (int dx = -r; dx <= r; dx++) { const unsigned v = p[dy * SS + dx]; a += v * v; b += v; }
@@ -137,7 +202,7 @@ __global__ __launch_bounds__(256) void k_lr(LrLaunch L) {
         a = 4 * (pa[0] + pa[-1] + pa[1] + pa[-AS] + pa[AS]) + 3 * (pa[-AS - 1] + pa[-AS + 1] + pa[AS - 1] + pa[AS + 1]);
         b = 4 * (pb[0] + pb[-1] + pb[1] + pb[-AS] + pb[AS]) + 3 * (pb[-AS - 1] + pb[-AS + 1] + pb[AS - 1] + pb[AS + 1]);
       }
-      const int v = a * (int)src[(i + 3) * SS + j + 3] + b;
+      const int v = a * (int)src[(i + 3) * SS + j + 4] + b;
       flt[pass][k] = (v + (1 << (shift + 3))) >> (shift + 4);   // Round2(v, SGR_BITS 8 + shift - RST_BITS 4)
     }
     __syncthreads();
@@ -148,7 +213,7 @@ __global__ __launch_bounds__(256) void k_lr(LrLaunch L) {
     const int q = tid + 256 * k;
     if (q >= bh * bw) continue;
     const int i = q / bw, j = q - i * bw;
-    const int u = (int)src[(i + 3) * SS + j + 3] << 4;
+    const int u = (int)src[(i + 3) * SS + j + 4] << 4;
     int v = w1 * u;
     v += w0 * (r0 ? flt[0][k] : u);
     v += w2 * (r1 ? flt[1][k] : u);
