@@ -2,8 +2,9 @@
 //
 // Input is raw video because demux / H.264 decode stay FFmpeg's job (SURVEY.md §8b "Gap to flag"); the output is NOT an
 // AV1 bitstream: entropy coding and OBU packing are not built, so the container written here
-// ("AV1MI1") holds, per segment, the mode bytes and the quantised levels run-length/varint packed on the host.  It exists
-// so that the job contract (output file present, size gate, atomic replace) can be exercised end to end.
+// ("AV1MI1") holds, per closed-GOP segment and frame: the frame type, the mode bytes (key frames) or the vectors + skip
+// flags (P frames), and the quantised levels run-length/varint packed on the host.  It exists so that the job contract
+// (output file present, size gate, atomic replace) can be exercised end to end through every kernel K1-K8.
 #include "backend.hpp"
 #include <cstdio>
 #include <cstring>
@@ -58,58 +59,134 @@ void pack_levels(const int16_t *lv, size_t n, std::vector<unsigned char> &o) {
 
 }  // namespace
 
+// encoder policies shared with av1-go_amd/pipeline.py (non-normative): deblock level / CDEF strengths from the AC step
+static int lf_level_from_q(int ac_q, int bd, bool key) {
+  long g;
+  if (bd == 8) g = key ? ((long)ac_q * 17563 - 421574 + (1 << 17)) >> 18 : ((long)ac_q * 6017 + 650707 + (1 << 17)) >> 18;
+  else g = ((long)ac_q * 20723 + 4060632 + (1 << 19)) >> 20;
+  return (int)(g < 0 ? 0 : g > 63 ? 63 : g);
+}
+static void cdef_strength_from_q(int ac_q, int bd, uint8_t st[4]) {
+  const int q = ac_q >> (bd - 8);
+  int y = q < 700 ? (q * q * 3 + 32768) >> 16 : 15;
+  y = y > 15 ? 15 : y;
+  st[0] = (uint8_t)(y + 2 > 15 ? 15 : (y + 2 < 1 ? 1 : y + 2)); st[1] = 1; st[2] = (uint8_t)(y < 1 ? 1 : y); st[3] = 1;
+}
+
 int RunBackend(const BackendJob &job, std::string *err) {
   av1mi_ctx *ctx = nullptr;
   if (av1mi_device_count() <= 0 || av1mi_open(job.device, &ctx) != AV1MI_OK) {
     *err = "Error: no usable HIP device for the av1mi backend (device " + std::to_string(job.device) + ")";
     return -1;
   }
+  // One closed GOP (segment) at a time: frame 0 is a key frame, frames 1.. are P frames predicted from the previous
+  // reconstructed frame after deblocking + CDEF + loop restoration.  Frames of a segment are uploaded once.
   Y4m y;
   int code = 0;
   FILE *out = nullptr;
-  std::vector<unsigned char> hY, hU, hV, packed, modes;
-  std::vector<int16_t> lev;
-  void *d[11] = { nullptr };
-  size_t ny = 0, nc = 0, nb = 0;
+  std::vector<unsigned char> hY, hU, hV, packed, bytes;
+  std::vector<int16_t> lev, mvh;
+  enum { SY, SU, SV, RY, RU, RV, DY, DU, DV, CY, CU, CV, OY, OU, OV, LY, LU, LV, MY, MUV, MVS, SKIP, ZSKIP, MIY, MIC, CSB, LRY, LRC, NBUF };
+  void *d[NBUF] = { nullptr };
   long frames_total = 0;
   if (!y4m_open(job.input, &y, err)) { code = 1; goto done; }
   {
     const size_t bps = y.bd == 8 ? 1 : 2;
-    const int G = job.gop;
-    ny = (size_t)y.w * y.h; nc = ny / 4; nb = ny / 64;
+    const int G = job.gop, w = y.w, h = y.h;
+    const size_t ny = (size_t)w * h, nc = ny / 4, nb = ny / 64;
+    const int ac_q = av1mi_ac_q(job.quality, y.bd);
+    const int nsb = ((w + 63) / 64) * ((h + 63) / 64);
+    const int ury = (h + 32) / 64 > 1 ? (h + 32) / 64 : 1, ucy = (w + 32) / 64 > 1 ? (w + 32) / 64 : 1;
+    const int urc = (h / 2 + 32) / 64 > 1 ? (h / 2 + 32) / 64 : 1, ucc = (w / 2 + 32) / 64 > 1 ? (w / 2 + 32) / 64 : 1;
     hY.resize(ny * bps * G); hU.resize(nc * bps * G); hV.resize(nc * bps * G);
-    lev.resize(ny * G); modes.resize(nb * G);
-    const size_t sizes[11] = { ny * bps * G, nc * bps * G, nc * bps * G, ny * bps * G, nc * bps * G, nc * bps * G,
-                               ny * 2 * G, nc * 2 * G, nc * 2 * G, nb * G, nb * G };
-    for (int i = 0; i < 11; i++) CHK(av1mi_malloc(ctx, &d[i], sizes[i]));
+    lev.resize(ny); bytes.resize(nb); mvh.resize(nb * 2);
+    size_t sizes[NBUF];
+    for (int i = SY; i <= SV; i++) sizes[i] = (i == SY ? ny : nc) * bps * G;
+    for (int i = RY; i <= OV; i++) sizes[i] = ((i - RY) % 3 == 0 ? ny : nc) * bps;
+    sizes[LY] = ny * 2; sizes[LU] = sizes[LV] = nc * 2; sizes[MY] = sizes[MUV] = sizes[SKIP] = sizes[ZSKIP] = nb; sizes[MVS] = nb * 4;
+    sizes[MIY] = (ny / 16) * 4; sizes[MIC] = (nc / 16) * 4; sizes[CSB] = (size_t)nsb * 4; sizes[LRY] = (size_t)ury * ucy * 8; sizes[LRC] = (size_t)urc * ucc * 8;
+    for (int i = 0; i < NBUF; i++) CHK(av1mi_malloc(ctx, &d[i], sizes[i]));
+    CHK(av1mi_memset(ctx, d[ZSKIP], 0, nb));
+    {  // constant side information of this job
+      std::vector<uint32_t> mi(ny / 16);
+      std::vector<uint8_t> sb((size_t)nsb * 4);
+      std::vector<int8_t> lr((size_t)(ury * ucy > urc * ucc ? ury * ucy : urc * ucc) * 8);
+      uint8_t st[4];
+      cdef_strength_from_q(ac_q, y.bd, st);
+      for (int i = 0; i < nsb; i++) memcpy(&sb[(size_t)i * 4], st, 4);
+      CHK(av1mi_upload(ctx, d[CSB], sb.data(), sb.size()));
+      const int8_t wy[8] = { 1, 3, -7, 15, 3, -7, 15, 0 }, wc[8] = { 1, 0, -7, 15, 0, -7, 15, 0 };
+      for (int i = 0; i < ury * ucy; i++) memcpy(&lr[(size_t)i * 8], wy, 8);
+      CHK(av1mi_upload(ctx, d[LRY], lr.data(), (size_t)ury * ucy * 8));
+      for (int i = 0; i < urc * ucc; i++) memcpy(&lr[(size_t)i * 8], wc, 8);
+      CHK(av1mi_upload(ctx, d[LRC], lr.data(), (size_t)urc * ucc * 8));
+    }
     out = fopen(job.output.c_str(), "wb");
     if (!out) { *err = job.output + ": Permission denied"; code = 1; goto done; }
-    fprintf(out, "AV1MI1 W%d H%d B%d F%d:%d Q%d G%d\n", y.w, y.h, y.bd, y.fps_n, y.fps_d, job.quality, G);
+    fprintf(out, "AV1MI1 W%d H%d B%d F%d:%d Q%d G%d\n", w, h, y.bd, y.fps_n, y.fps_d, job.quality, G);
+    const int damping = 3 + ((ac_q >> (y.bd - 8)) > 100) + ((ac_q >> (y.bd - 8)) > 300);
     for (;;) {
       int n = 0, r = 1;
       while (n < G && (r = y4m_frame(&y, hY.data() + ny * bps * n, hU.data() + nc * bps * n, hV.data() + nc * bps * n)) == 1) n++;
       if (r < 0) { *err = job.input + ": Invalid data found when processing input (truncated frame)"; code = 1; goto done; }
       if (n == 0) break;
-      CHK(av1mi_upload(ctx, d[0], hY.data(), ny * bps * n));
-      CHK(av1mi_upload(ctx, d[1], hU.data(), nc * bps * n));
-      CHK(av1mi_upload(ctx, d[2], hV.data(), nc * bps * n));
-      av1mi_intra_job ij;
-      memset(&ij, 0, sizeof(ij));
-      ij.width = y.w; ij.height = y.h; ij.bit_depth = y.bd; ij.nframes = n; ij.qindex = job.quality; ij.block_size = 8;
-      ij.stride_y = y.w; ij.stride_uv = y.w / 2;
-      ij.d_src_y = d[0]; ij.d_src_u = d[1]; ij.d_src_v = d[2]; ij.d_rec_y = d[3]; ij.d_rec_u = d[4]; ij.d_rec_v = d[5];
-      ij.d_lev_y = (int16_t *)d[6]; ij.d_lev_u = (int16_t *)d[7]; ij.d_lev_v = (int16_t *)d[8];
-      ij.d_modes_y = (uint8_t *)d[9]; ij.d_modes_uv = (uint8_t *)d[10];
-      CHK(av1mi_intra_encode(ctx, &ij));   // every frame a key frame until the inter path is wired into the host
+      CHK(av1mi_upload(ctx, d[SY], hY.data(), ny * bps * n));
+      CHK(av1mi_upload(ctx, d[SU], hU.data(), nc * bps * n));
+      CHK(av1mi_upload(ctx, d[SV], hV.data(), nc * bps * n));
       packed.clear();
-      const size_t lev_n[3] = { ny * n, nc * n, nc * n };
-      for (int p = 0; p < 3; p++) {
-        CHK(av1mi_download(ctx, lev.data(), d[6 + p], lev_n[p] * 2));
-        pack_levels(lev.data(), lev_n[p], packed);
-      }
-      for (int p = 0; p < 2; p++) {
-        CHK(av1mi_download(ctx, modes.data(), d[9 + p], nb * n));
-        packed.insert(packed.end(), modes.begin(), modes.begin() + nb * n);
+      for (int t = 0; t < n; t++) {
+        const bool key = t == 0;
+        const char *sy = (const char *)d[SY] + ny * bps * t, *su = (const char *)d[SU] + nc * bps * t, *sv = (const char *)d[SV] + nc * bps * t;
+        if (key) {
+          av1mi_intra_job ij;
+          memset(&ij, 0, sizeof(ij));
+          ij.width = w; ij.height = h; ij.bit_depth = y.bd; ij.nframes = 1; ij.qindex = job.quality; ij.block_size = 8;
+          ij.stride_y = w; ij.stride_uv = w / 2;
+          ij.d_src_y = sy; ij.d_src_u = su; ij.d_src_v = sv; ij.d_rec_y = d[RY]; ij.d_rec_u = d[RU]; ij.d_rec_v = d[RV];
+          ij.d_lev_y = (int16_t *)d[LY]; ij.d_lev_u = (int16_t *)d[LU]; ij.d_lev_v = (int16_t *)d[LV];
+          ij.d_modes_y = (uint8_t *)d[MY]; ij.d_modes_uv = (uint8_t *)d[MUV];
+          CHK(av1mi_intra_encode(ctx, &ij));
+        } else {
+          av1mi_inter_job pj;
+          memset(&pj, 0, sizeof(pj));
+          pj.width = w; pj.height = h; pj.bit_depth = y.bd; pj.nframes = 1; pj.qindex = job.quality; pj.search_range = 8;
+          pj.stride_y = w; pj.stride_uv = w / 2;
+          pj.d_src_y = sy; pj.d_src_u = su; pj.d_src_v = sv; pj.d_ref_y = d[OY]; pj.d_ref_u = d[OU]; pj.d_ref_v = d[OV];
+          pj.d_rec_y = d[RY]; pj.d_rec_u = d[RU]; pj.d_rec_v = d[RV];
+          pj.d_lev_y = (int16_t *)d[LY]; pj.d_lev_u = (int16_t *)d[LU]; pj.d_lev_v = (int16_t *)d[LV];
+          pj.d_mvs = (int16_t *)d[MVS]; pj.d_skip = (uint8_t *)d[SKIP];
+          CHK(av1mi_inter_encode(ctx, &pj));
+        }
+        if (t + 1 < n) {   // the next frame needs this one as its reference: deblock -> CDEF -> loop restoration
+          const int lvl = lf_level_from_q(ac_q, y.bd, key);
+          std::vector<uint32_t> mi(ny / 16, 3u | (3u << 4) | ((uint32_t)lvl << 8) | ((uint32_t)lvl << 16) | (3u << 25));
+          CHK(av1mi_upload(ctx, d[MIY], mi.data(), mi.size() * 4));
+          std::vector<uint32_t> mic(nc / 16, 2u | (2u << 4) | ((uint32_t)lvl << 8) | ((uint32_t)lvl << 16) | (3u << 25));
+          CHK(av1mi_upload(ctx, d[MIC], mic.data(), mic.size() * 4));
+          CHK(av1mi_deblock_plane(ctx, d[RY], w, d[DY], w, w, h, y.bd, 0, (const uint32_t *)d[MIY], w / 4, 0));
+          CHK(av1mi_deblock_plane(ctx, d[RU], w / 2, d[DU], w / 2, w / 2, h / 2, y.bd, 1, (const uint32_t *)d[MIC], w / 8, 0));
+          CHK(av1mi_deblock_plane(ctx, d[RV], w / 2, d[DV], w / 2, w / 2, h / 2, y.bd, 1, (const uint32_t *)d[MIC], w / 8, 0));
+          av1mi_cdef_job cj;
+          memset(&cj, 0, sizeof(cj));
+          cj.width = w; cj.height = h; cj.bit_depth = y.bd; cj.nframes = 1; cj.damping = damping; cj.stride_y = w; cj.stride_uv = w / 2;
+          cj.d_src_y = d[DY]; cj.d_src_u = d[DU]; cj.d_src_v = d[DV]; cj.d_dst_y = d[CY]; cj.d_dst_u = d[CU]; cj.d_dst_v = d[CV];
+          cj.d_sb_strength = (const uint8_t *)d[CSB]; cj.d_skip8 = (const uint8_t *)(key ? d[ZSKIP] : d[SKIP]);
+          CHK(av1mi_cdef_frames(ctx, &cj));
+          CHK(av1mi_lr_frames(ctx, d[CY], d[DY], d[OY], w, w, h, y.bd, 0, 64, (const int8_t *)d[LRY], 0, 1));
+          CHK(av1mi_lr_frames(ctx, d[CU], d[DU], d[OU], w / 2, w / 2, h / 2, y.bd, 1, 64, (const int8_t *)d[LRC], 0, 1));
+          CHK(av1mi_lr_frames(ctx, d[CV], d[DV], d[OV], w / 2, w / 2, h / 2, y.bd, 1, 64, (const int8_t *)d[LRC], 0, 1));
+        }
+        // side information + levels of this frame -> host, packed
+        packed.push_back(key ? 'K' : 'P');
+        if (key) {
+          for (int p = 0; p < 2; p++) { CHK(av1mi_download(ctx, bytes.data(), d[MY + p], nb)); packed.insert(packed.end(), bytes.begin(), bytes.end()); }
+        } else {
+          CHK(av1mi_download(ctx, mvh.data(), d[MVS], nb * 4));
+          for (size_t i = 0; i < nb * 2; i++) put_varint(packed, (unsigned)((mvh[i] << 1) ^ (mvh[i] >> 15)) & 0xFFFFu);
+          CHK(av1mi_download(ctx, bytes.data(), d[SKIP], nb)); packed.insert(packed.end(), bytes.begin(), bytes.end());
+        }
+        const size_t lev_n[3] = { ny, nc, nc };
+        for (int p = 0; p < 3; p++) { CHK(av1mi_download(ctx, lev.data(), d[LY + p], lev_n[p] * 2)); pack_levels(lev.data(), lev_n[p], packed); }
       }
       fprintf(out, "SEG %d %zu\n", n, packed.size());
       if (fwrite(packed.data(), 1, packed.size(), out) != packed.size()) { *err = job.output + ": No space left on device"; code = 1; goto done; }
@@ -119,7 +196,7 @@ int RunBackend(const BackendJob &job, std::string *err) {
     if (frames_total == 0) { *err = job.input + ": Invalid data found when processing input (no frames)"; code = 1; }
   }
 done:
-  for (int i = 0; i < 11; i++) if (d[i]) av1mi_free(ctx, d[i]);
+  for (int i = 0; i < NBUF; i++) if (d[i]) av1mi_free(ctx, d[i]);
   if (out) fclose(out);
   if (y.f) fclose(y.f);
   av1mi_close(ctx);

@@ -96,6 +96,9 @@ def test_run_transcode_and_process_job_on_gpu(host, tmp_path):
     assert host.av1mi_host_run_transcode(args.encode(), buf, 1024) == 0 and buf.value == b""
     data = out.read_bytes()
     assert data.startswith(b"AV1MI1 W192 H128 B8 F30:1 Q120 G3\n") and data.count(b"SEG 3 ") == 2 and data.count(b"SEG 1 ") == 1
+    # every segment starts with a key frame ('K' right after its header line), later frames are P frames
+    first = data.index(b"SEG 3 ")
+    assert data[data.index(b"\n", first) + 1:data.index(b"\n", first) + 2] == b"K"
     assert len(data) < src.stat().st_size            # coarse quantiser: packed levels are smaller than the raw input
     out.unlink()
     # lifecycle: generous ratio -> the source is replaced by the coded file; tight ratio -> skipped with markers
