@@ -1,15 +1,19 @@
 // backend.cpp — drives libav1mi.so over closed-GOP segments of a Y4M file (4:2:0, 8- or 10-bit).
 //
 // Input is raw video because demux / H.264 decode stay FFmpeg's job (SURVEY.md §8b "Gap to flag"); the output is NOT an
-// AV1 bitstream: entropy coding and OBU packing are not built, so the container written here
-// ("AV1MI1") holds, per closed-GOP segment and frame: the frame type, the mode bytes (key frames) or the vectors + skip
-// flags (P frames), and the quantised levels run-length/varint packed on the host.  It exists so that the job contract
-// (output file present, size gate, atomic replace) can be exercised end to end through every kernel K1-K8.
+// AV1 bitstream: the container written here ("AV1MI2") holds, per closed-GOP segment, one record per frame: the frame type
+// and the frame's symbols (modes or vectors + skip flags, quantised levels) coded by the host entropy coder of entropy.hpp
+// (AV1's range-coder arithmetic and CDF adaptation over this project's own syntax, one coder state
+// per frame, the frames of a segment coded in parallel on the host cores while the next segment is on the GPU queue).
+// It exists so that the job contract (output file present, size gate, atomic replace) can be exercised end to end through
+// every kernel K1-K8 and H1; OBU packing and AV1's default CDFs are not built.
 #include "backend.hpp"
 #include <cstdio>
 #include <cstring>
+#include <thread>
 #include <vector>
 #include "../../include/av1mi.h"
+#include "entropy.hpp"
 
 namespace av1mi_host {
 namespace {
@@ -44,16 +48,6 @@ int y4m_frame(Y4m *y, unsigned char *Y, unsigned char *U, unsigned char *V) {
   return 1;
 }
 void put_varint(std::vector<unsigned char> &o, unsigned v) { while (v >= 128) { o.push_back((unsigned char)(v | 128)); v >>= 7; } o.push_back((unsigned char)v); }
-// zero-run + zigzag varint packing of levels (host-side stand-in for entropy coding; not AV1)
-void pack_levels(const int16_t *lv, size_t n, std::vector<unsigned char> &o) {
-  unsigned run = 0;
-  for (size_t i = 0; i < n; i++) {
-    if (lv[i] == 0) { run++; continue; }
-    put_varint(o, run << 1); run = 0;
-    put_varint(o, ((unsigned)(lv[i] < 0 ? -lv[i] : lv[i]) << 1 | (lv[i] < 0)) << 1 | 1);
-  }
-  put_varint(o, run << 1);
-}
 #define CHK(call)                                                                        \
   do { int rc_ = (call); if (rc_ != AV1MI_OK) { *err = std::string(#call) + ": " + av1mi_last_error(ctx); code = 2; goto done; } } while (0)
 
@@ -85,7 +79,10 @@ int RunBackend(const BackendJob &job, std::string *err) {
   int code = 0;
   FILE *out = nullptr;
   std::vector<unsigned char> hY, hU, hV, packed, bytes;
-  std::vector<int16_t> lev, mvh;
+  std::vector<int16_t> levY, levU, levV, mvh;
+  std::vector<FrameSyms> syms;
+  std::vector<std::vector<uint8_t>> coded;
+  const int host_threads = (int)std::thread::hardware_concurrency() > 0 ? (int)std::thread::hardware_concurrency() : 1;
   enum { SY, SU, SV, RY, RU, RV, DY, DU, DV, CY, CU, CV, OY, OU, OV, LY, LU, LV, MY, MUV, MVS, SKIP, ZSKIP, MIY, MIC, CSB, LRY, LRC, NBUF };
   void *d[NBUF] = { nullptr };
   long frames_total = 0;
@@ -99,7 +96,7 @@ int RunBackend(const BackendJob &job, std::string *err) {
     const int ury = (h + 32) / 64 > 1 ? (h + 32) / 64 : 1, ucy = (w + 32) / 64 > 1 ? (w + 32) / 64 : 1;
     const int urc = (h / 2 + 32) / 64 > 1 ? (h / 2 + 32) / 64 : 1, ucc = (w / 2 + 32) / 64 > 1 ? (w / 2 + 32) / 64 : 1;
     hY.resize(ny * bps * G); hU.resize(nc * bps * G); hV.resize(nc * bps * G);
-    lev.resize(ny); bytes.resize(nb); mvh.resize(nb * 2);
+    levY.resize(ny * G); levU.resize(nc * G); levV.resize(nc * G); bytes.resize(nb * 2 * G); mvh.resize(nb * 2 * G);
     size_t sizes[NBUF];
     for (int i = SY; i <= SV; i++) sizes[i] = (i == SY ? ny : nc) * bps * G;
     for (int i = RY; i <= OV; i++) sizes[i] = ((i - RY) % 3 == 0 ? ny : nc) * bps;
@@ -123,7 +120,7 @@ int RunBackend(const BackendJob &job, std::string *err) {
     }
     out = fopen(job.output.c_str(), "wb");
     if (!out) { *err = job.output + ": Permission denied"; code = 1; goto done; }
-    fprintf(out, "AV1MI1 W%d H%d B%d F%d:%d Q%d G%d\n", w, h, y.bd, y.fps_n, y.fps_d, job.quality, G);
+    fprintf(out, "AV1MI2 W%d H%d B%d F%d:%d Q%d G%d\n", w, h, y.bd, y.fps_n, y.fps_d, job.quality, G);
     const int damping = 3 + ((ac_q >> (y.bd - 8)) > 100) + ((ac_q >> (y.bd - 8)) > 300);
     for (;;) {
       int n = 0, r = 1;
@@ -133,7 +130,7 @@ int RunBackend(const BackendJob &job, std::string *err) {
       CHK(av1mi_upload(ctx, d[SY], hY.data(), ny * bps * n));
       CHK(av1mi_upload(ctx, d[SU], hU.data(), nc * bps * n));
       CHK(av1mi_upload(ctx, d[SV], hV.data(), nc * bps * n));
-      packed.clear();
+      packed.clear(); syms.clear();
       for (int t = 0; t < n; t++) {
         const bool key = t == 0;
         const char *sy = (const char *)d[SY] + ny * bps * t, *su = (const char *)d[SU] + nc * bps * t, *sv = (const char *)d[SV] + nc * bps * t;
@@ -176,17 +173,26 @@ int RunBackend(const BackendJob &job, std::string *err) {
           CHK(av1mi_lr_frames(ctx, d[CU], d[DU], d[OU], w / 2, w / 2, h / 2, y.bd, 1, 64, (const int8_t *)d[LRC], 0, 1));
           CHK(av1mi_lr_frames(ctx, d[CV], d[DV], d[OV], w / 2, w / 2, h / 2, y.bd, 1, 64, (const int8_t *)d[LRC], 0, 1));
         }
-        // side information + levels of this frame -> host, packed
-        packed.push_back(key ? 'K' : 'P');
+        // symbols of this frame -> host (coded after the segment's last launch has been queued)
+        FrameSyms fs; fs.width = w; fs.height = h; fs.key = key;
+        unsigned char *by = bytes.data() + nb * 2 * t;
         if (key) {
-          for (int p = 0; p < 2; p++) { CHK(av1mi_download(ctx, bytes.data(), d[MY + p], nb)); packed.insert(packed.end(), bytes.begin(), bytes.end()); }
+          CHK(av1mi_download(ctx, by, d[MY], nb)); CHK(av1mi_download(ctx, by + nb, d[MUV], nb));
+          fs.modes_y = by; fs.modes_uv = by + nb;
         } else {
-          CHK(av1mi_download(ctx, mvh.data(), d[MVS], nb * 4));
-          for (size_t i = 0; i < nb * 2; i++) put_varint(packed, (unsigned)((mvh[i] << 1) ^ (mvh[i] >> 15)) & 0xFFFFu);
-          CHK(av1mi_download(ctx, bytes.data(), d[SKIP], nb)); packed.insert(packed.end(), bytes.begin(), bytes.end());
+          CHK(av1mi_download(ctx, mvh.data() + nb * 2 * t, d[MVS], nb * 4)); CHK(av1mi_download(ctx, by, d[SKIP], nb));
+          fs.mvs = mvh.data() + nb * 2 * t; fs.skip = by;
         }
-        const size_t lev_n[3] = { ny, nc, nc };
-        for (int p = 0; p < 3; p++) { CHK(av1mi_download(ctx, lev.data(), d[LY + p], lev_n[p] * 2)); pack_levels(lev.data(), lev_n[p], packed); }
+        CHK(av1mi_download(ctx, levY.data() + ny * t, d[LY], ny * 2)); fs.lev_y = levY.data() + ny * t;
+        CHK(av1mi_download(ctx, levU.data() + nc * t, d[LU], nc * 2)); fs.lev_u = levU.data() + nc * t;
+        CHK(av1mi_download(ctx, levV.data() + nc * t, d[LV], nc * 2)); fs.lev_v = levV.data() + nc * t;
+        syms.push_back(fs);
+      }
+      entropy_encode_frames(syms, host_threads, &coded);
+      for (int t = 0; t < n; t++) {
+        packed.push_back(t == 0 ? 'K' : 'P');
+        put_varint(packed, (unsigned)coded[(size_t)t].size());
+        packed.insert(packed.end(), coded[(size_t)t].begin(), coded[(size_t)t].end());
       }
       fprintf(out, "SEG %d %zu\n", n, packed.size());
       if (fwrite(packed.data(), 1, packed.size(), out) != packed.size()) { *err = job.output + ": No space left on device"; code = 1; goto done; }

@@ -1,0 +1,130 @@
+"""Host entropy coder (av1-go_amd/host/entropy.cpp): decode(encode(x)) == x on the encoder loop's real
+outputs and on adversarial symbol streams, CDF adaptation per AV1 spec §8.2.6, and the coded size against the zeroth-order
+entropy of the levels (a coder that silently wastes bits is a bug too)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+HOST = os.path.join(ROOT, "av1-go_amd", "host", "libav1mi_host.so")
+
+
+@pytest.fixture(scope="module")
+def host():
+    if not os.path.exists(HOST):
+        import subprocess
+        subprocess.check_call(["make", "-s", "-C", os.path.dirname(HOST)])
+    lib = C.CDLL(HOST)
+    P = C.c_void_p
+    lib.av1mi_host_entropy_encode.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, P, P, P, P, P, P, P, P, C.c_longlong]
+    lib.av1mi_host_entropy_encode.restype = C.c_longlong
+    lib.av1mi_host_entropy_decode.argtypes = [P, C.c_longlong, C.c_int, C.c_int, C.c_int, P, P, P, P, P, P, P]
+    lib.av1mi_host_entropy_encode_stack.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P, P, P, P, P]
+    lib.av1mi_host_entropy_encode_stack.restype = C.c_longlong
+    return lib
+
+
+def _vp(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _roundtrip(host, w, h, key, ly, lu, lv, my=None, muv=None, mvs=None, skip=None, tile=64):
+    nb = (w // 8) * (h // 8)
+    arrs = [np.ascontiguousarray(a) if a is not None else None for a in (ly, lu, lv, my, muv, mvs, skip)]
+    cap = 64 + w * h * 8
+    out = np.zeros(cap, np.uint8)
+    n = host.av1mi_host_entropy_encode(w, h, key, tile, *[_vp(a) for a in arrs], _vp(out), cap)
+    assert n > 0
+    d = [np.full((nb, 8, 8), 77, np.int16), np.full((nb, 4, 4), 77, np.int16), np.full((nb, 4, 4), 77, np.int16),
+         np.full(nb, 99, np.uint8), np.full(nb, 99, np.uint8), np.full((nb, 2), 99, np.int16), np.full(nb, 99, np.uint8)]
+    assert host.av1mi_host_entropy_decode(_vp(out), n, w, h, key, *[_vp(a) for a in d]) == 0
+    for i in range(3):
+        assert np.array_equal(d[i].reshape(-1), arrs[i].reshape(-1)), "plane %d levels differ" % i
+    if key:
+        assert np.array_equal(d[3], arrs[3]) and np.array_equal(d[4], arrs[4])
+    else:
+        assert np.array_equal(d[5].reshape(-1), arrs[5].reshape(-1)) and np.array_equal(d[6], arrs[6])
+    # truncating the stream must not crash the decoder (zeros are read past the end); result is simply wrong or rejected
+    host.av1mi_host_entropy_decode(_vp(out), max(1, n // 2), w, h, key, *[_vp(a) for a in d])
+    return n
+
+
+def _h0(levels):
+    v, c = np.unique(levels, return_counts=True)
+    p = c / c.sum()
+    return float(-(p * np.log2(p)).sum() * levels.size / 8)
+
+
+@pytest.mark.parametrize("bd,q,tile", [(8, 40, 64), (8, 120, 128), (10, 200, 4096), (8, 200, 64)])
+def test_key_frame_roundtrip_on_encoder_output(host, O, bd, q, tile):
+    Y, U, V = synth.frames(200, 136, 1, bd)          # ragged: 3.125 x 2.125 tiles of 64
+    o = O.intra_encode_frame(Y[0], U[0], V[0], bd, 8, q)
+    n = _roundtrip(host, 200, 136, 1, o["lev_y"], o["lev_u"], o["lev_v"], o["modes_y"], o["modes_uv"], tile=tile)
+    # adaptive contexts must beat the memoryless entropy of the level alphabet + 1 byte per mode pair
+    bound = _h0(o["lev_y"]) + _h0(o["lev_u"]) + _h0(o["lev_v"]) + o["modes_y"].size
+    assert n < bound, (n, bound)
+
+
+def test_p_frame_roundtrip_on_encoder_output(host, O):
+    Y, U, V = synth.frames(128, 64, 2, 8)
+    o = O.inter_encode_frame((Y[1], U[1], V[1]), (Y[0], U[0], V[0]), 8, 100)
+    assert o["mvs"].any()
+    for tile in (64, 128):
+        _roundtrip(host, 128, 64, 0, o["lev_y"], o["lev_u"], o["lev_v"], None, None, o["mvs"], o["skip"], tile=tile)
+
+
+def test_adversarial_symbols_roundtrip(host):
+    rng = np.random.default_rng(11)
+    w, h = 64, 48
+    nb = (w // 8) * (h // 8)
+    # dense full-range levels (carry chains, 15-bit Golomb classes), all-zero blocks, single trailing coefficient
+    ly = rng.integers(-32767, 32768, (nb, 8, 8)).astype(np.int16)
+    ly[::3] = 0
+    ly[1::3, :, :] = 0
+    ly[1::3, 7, 7] = -1
+    lu = rng.integers(-3, 4, (nb, 4, 4)).astype(np.int16)
+    lv = np.zeros((nb, 4, 4), np.int16)
+    lv[:, 0, 0] = 32767
+    my = rng.integers(0, 13, nb).astype(np.uint8)
+    muv = np.full(nb, 12, np.uint8)
+    _roundtrip(host, w, h, 1, ly, lu, lv, my, muv)
+    mvs = rng.integers(-32768, 32768, (nb, 2)).astype(np.int16)
+    mvs[:4] = 0
+    skip = (rng.random(nb) < 0.5).astype(np.uint8)
+    ly[skip == 1] = 0
+    lu[skip == 1] = 0
+    lv[skip == 1] = 0
+    _roundtrip(host, w, h, 0, ly, lu, lv, None, None, mvs, skip)
+
+
+def test_highly_skewed_stream_hits_carry_propagation(host):
+    # long runs of the most probable symbol drive `low` to 0xFF.. byte runs; a wrong carry shows as a decode mismatch
+    w, h = 256, 256
+    nb = (w // 8) * (h // 8)
+    ly = np.zeros((nb, 8, 8), np.int16)
+    ly[:, 0, 0] = 1
+    ly[5::7, 0, 1] = -2
+    lu = np.zeros((nb, 4, 4), np.int16)
+    lv = np.zeros((nb, 4, 4), np.int16)
+    my = np.zeros(nb, np.uint8)
+    n = _roundtrip(host, w, h, 1, ly, lu, lv, my, my)
+    assert n < 1.5 * nb      # about a byte per block even with the CDFs restarting in every 64x64 tile
+
+
+def test_threaded_stack_matches_single_frames(host):
+    w, h, nf = 64, 64, 5
+    rng = np.random.default_rng(2)
+    nb = (w // 8) * (h // 8)
+    ly = (rng.laplace(0, 1.5, (nf, nb, 8, 8))).astype(np.int16)
+    lu = (rng.laplace(0, 0.7, (nf, nb, 4, 4))).astype(np.int16)
+    lv = (rng.laplace(0, 0.7, (nf, nb, 4, 4))).astype(np.int16)
+    my = rng.integers(0, 13, (nf, nb)).astype(np.uint8)
+    muv = rng.integers(0, 13, (nf, nb)).astype(np.uint8)
+    tot = host.av1mi_host_entropy_encode_stack(w, h, nf, 3, 64, _vp(ly), _vp(lu), _vp(lv), _vp(my), _vp(muv))
+    single = sum(_roundtrip(host, w, h, 1, ly[i], lu[i], lv[i], my[i], muv[i]) for i in range(nf))
+    assert tot == single

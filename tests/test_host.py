@@ -73,6 +73,45 @@ def _write_y4m(path, w, h, n, bd=8):
                 f.write(p.astype("<u2" if bd == 10 else np.uint8).tobytes())
 
 
+def _varint(data, pos):
+    v = sh = 0
+    while True:
+        b = data[pos]
+        pos += 1
+        v |= (b & 127) << sh
+        sh += 7
+        if b < 128:
+            return v, pos
+
+
+def _check_first_segment_against_oracle(host, data, w, h, q):
+    """the coded file, decoded by the host entropy decoder, carries exactly the symbols the oracle's encoder loop produces"""
+    from oracle import oracle
+    import synth
+    oracle.build()
+    P = C.c_void_p
+    host.av1mi_host_entropy_decode.argtypes = [P, C.c_longlong, C.c_int, C.c_int, C.c_int, P, P, P, P, P, P, P]
+    Y, U, V = synth.frames(w, h, 1, 8)
+    ok = oracle.intra_encode_frame(Y[0], U[0], V[0], 8, 8, q)
+    nb = (w // 8) * (h // 8)
+    pos = data.index(b"\n", data.index(b"SEG 3 ")) + 1
+    vp = lambda a: a.ctypes.data_as(P)
+    for t, key in ((0, 1), (1, 0)):
+        assert data[pos:pos + 1] == (b"K" if key else b"P")
+        n, pos = _varint(data, pos + 1)
+        payload = np.frombuffer(data[pos:pos + n], np.uint8).copy()
+        pos += n
+        ly, lu, lv = np.zeros((nb, 8, 8), np.int16), np.zeros((nb, 4, 4), np.int16), np.zeros((nb, 4, 4), np.int16)
+        my, muv, mvs, skip = np.zeros(nb, np.uint8), np.zeros(nb, np.uint8), np.zeros((nb, 2), np.int16), np.zeros(nb, np.uint8)
+        assert host.av1mi_host_entropy_decode(vp(payload), n, w, h, key, vp(ly), vp(lu), vp(lv), vp(my), vp(muv), vp(mvs), vp(skip)) == 0
+        if key:
+            assert np.array_equal(ly, ok["lev_y"]) and np.array_equal(lu, ok["lev_u"]) and np.array_equal(lv, ok["lev_v"])
+            assert np.array_equal(my, ok["modes_y"]) and np.array_equal(muv, ok["modes_uv"])
+        else:
+            assert skip.max() <= 1 and np.abs(mvs).max() <= 8 * 8 + 7     # +-8 integer search + sub-pel, 1/8 units
+            assert (ly[skip == 1] == 0).all()
+
+
 def test_run_transcode_fails_cleanly_without_gpu_or_input(host, tmp_path, av1mi):
     buf = C.create_string_buffer(1024)
     args = "\n".join(["-i", str(tmp_path / "missing.y4m"), "-global_quality:v:0", "25", str(tmp_path / "o.mkv")])
@@ -95,11 +134,12 @@ def test_run_transcode_and_process_job_on_gpu(host, tmp_path):
     args = "\n".join(["-hide_banner", "-i", str(src), "-global_quality:v:0", "120", "-g", "3", str(out)])
     assert host.av1mi_host_run_transcode(args.encode(), buf, 1024) == 0 and buf.value == b""
     data = out.read_bytes()
-    assert data.startswith(b"AV1MI1 W192 H128 B8 F30:1 Q120 G3\n") and data.count(b"SEG 3 ") == 2 and data.count(b"SEG 1 ") == 1
+    assert data.startswith(b"AV1MI2 W192 H128 B8 F30:1 Q120 G3\n") and data.count(b"SEG 3 ") == 2 and data.count(b"SEG 1 ") == 1
     # every segment starts with a key frame ('K' right after its header line), later frames are P frames
     first = data.index(b"SEG 3 ")
     assert data[data.index(b"\n", first) + 1:data.index(b"\n", first) + 2] == b"K"
     assert len(data) < src.stat().st_size            # coarse quantiser: packed levels are smaller than the raw input
+    _check_first_segment_against_oracle(host, data, 192, 128, 120)
     out.unlink()
     # lifecycle: generous ratio -> the source is replaced by the coded file; tight ratio -> skipped with markers
     status, reason = C.create_string_buffer(256), C.create_string_buffer(1024)
@@ -110,4 +150,4 @@ def test_run_transcode_and_process_job_on_gpu(host, tmp_path):
     assert status.value == b"skipped" and reason.value.startswith(b"size gate: new ") and (tmp_path / "other.av1qsvd-skip").exists()
     assert (tmp_path / "other.av1qsvd-why.txt").exists() and not (tmp_path / "other.av1-tmp.mkv").exists() and src2.stat().st_size == orig
     assert host.av1mi_host_process_job(str(src).encode(), orig, 5.0, str(tmp_path).encode(), 0, status, reason, 256) == 0
-    assert status.value == b"success" and src.read_bytes().startswith(b"AV1MI1 ") and (tmp_path / "test.json").exists()
+    assert status.value == b"success" and src.read_bytes().startswith(b"AV1MI2 ") and (tmp_path / "test.json").exists()
