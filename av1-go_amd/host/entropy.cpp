@@ -159,19 +159,31 @@ unsigned get_golomb(RangeDecoder &d, uint16_t *cdf) {
   if (k >= 15) return d.decode_bits(32) - 1;
   return ((1u << k) | (k ? d.decode_bits(k) : 0)) - 1;
 }
+// one transform block: eob, then ALL tokens, then the remainders of the escaped tokens, then the signs packed 8 per raw
+// symbol — grouped by kind (not interleaved per coefficient) so that a SIMD coder with one tile per lane spends its steps on
+// the common symbol kind and touches the rare ones in short loops (csrc/entropy_kernels.hip)
 void put_block(RangeEncoder &e, Models &m, int pt, const int16_t *lv, int n, const uint8_t *scan) {
   int eob = 0;
   for (int i = 0; i < n; i++) if (lv[scan[i]]) eob = i + 1;
   const int c = eob_class(eob);
   e.encode(c, m.eob[pt], 8);
   if (c >= 3) e.encode_bits((unsigned)(eob - ((1 << (c - 2)) + 1)), c - 2);
-  int prev = 0;
+  int prev = 0, nnz = 0;
+  uint64_t signs = 0;
   for (int i = 0; i < eob; i++) {
     const int l = lv[scan[i]], a = l < 0 ? -l : l, t = a < 3 ? a : 3;
     e.encode(t, m.tok[pt][band_of(i)][prev], 4);
-    if (t == 3) put_golomb(e, m.gol[pt], (unsigned)(a - 3));
-    if (a) e.encode_bits(l < 0, 1);
+    if (a) { signs = (signs << 1) | (uint64_t)(l < 0); nnz++; }
     prev = t < 2 ? t : 2;
+  }
+  for (int i = 0; i < eob; i++) {
+    const int l = lv[scan[i]], a = l < 0 ? -l : l;
+    if (a >= 3) put_golomb(e, m.gol[pt], (unsigned)(a - 3));
+  }
+  while (nnz > 0) {                      // first symbol first, most significant bit of every chunk
+    const int k = nnz > 8 ? 8 : nnz;
+    nnz -= k;
+    e.encode_bits((unsigned)((signs >> nnz) & 0xFF), k);
   }
 }
 bool get_block(RangeDecoder &d, Models &m, int pt, int16_t *lv, int n, const uint8_t *scan) {
@@ -180,14 +192,26 @@ bool get_block(RangeDecoder &d, Models &m, int pt, int16_t *lv, int n, const uin
   int eob = c;
   if (c >= 3) eob = (1 << (c - 2)) + 1 + (int)d.decode_bits(c - 2);
   if (eob > n) return false;
-  int prev = 0;
+  int mag[64], prev = 0, nnz = 0;
   for (int i = 0; i < eob; i++) {
     const int t = d.decode(m.tok[pt][band_of(i)][prev], 4);
-    int a = t;
-    if (t == 3) a = 3 + (int)get_golomb(d, m.gol[pt]);
-    if (a > 32767) return false;
-    if (a) lv[scan[i]] = (int16_t)(d.decode_bits(1) ? -a : a);
+    mag[i] = t;
+    nnz += t != 0;
     prev = t < 2 ? t : 2;
+  }
+  for (int i = 0; i < eob; i++)
+    if (mag[i] == 3) { mag[i] = 3 + (int)get_golomb(d, m.gol[pt]); if (mag[i] > 32768) return false; }
+  int i = 0;
+  while (nnz > 0) {
+    const int k = nnz > 8 ? 8 : nnz;
+    nnz -= k;
+    const unsigned bits = d.decode_bits(k);
+    for (int j = k - 1; j >= 0; i++) {
+      if (i >= eob) return false;
+      if (!mag[i]) continue;
+      lv[scan[i]] = (int16_t)(((bits >> j) & 1) ? -mag[i] : mag[i]);
+      j--;
+    }
   }
   return true;
 }
@@ -267,7 +291,7 @@ std::vector<uint8_t> entropy_encode_frame(const FrameSyms &f) {
 
 bool entropy_decode_frame(const uint8_t *data, size_t n, int width, int height, int key, int16_t *lev_y, int16_t *lev_u, int16_t *lev_v,
                           uint8_t *modes_y, uint8_t *modes_uv, int16_t *mvs, uint8_t *skip) {
-  if (n < 1 || data[0] < 6 || data[0] > 12) return false;
+  if (n < 1 || data[0] < 5 || data[0] > 12) return false;   // tiles of 32..4096 luma samples
   const int tile = 1 << data[0], tc = (width + tile - 1) / tile, tr = (height + tile - 1) / tile;
   size_t pos = 1;
   std::vector<size_t> sizes((size_t)tc * tr);

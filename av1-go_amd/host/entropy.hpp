@@ -51,7 +51,7 @@ struct EntropyModels {
 
 struct FrameSyms {        // what one coded frame carries besides the header (all block-raster order, see include/av1mi.h)
   int width = 0, height = 0, key = 1;
-  int tile = 64;          // entropy tile edge in luma samples (power of two, 64..4096): every tile has its own coder + CDF state
+  int tile = 64;          // entropy tile edge in luma samples (power of two, 32..4096): every tile has its own coder + CDF state
   const int16_t *lev_y = nullptr, *lev_u = nullptr, *lev_v = nullptr;   // 8x8 luma / 4x4 chroma blocks, row-major inside a block
   const uint8_t *modes_y = nullptr, *modes_uv = nullptr;                // key frames
   const int16_t *mvs = nullptr; const uint8_t *skip = nullptr;          // P frames

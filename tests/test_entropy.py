@@ -33,7 +33,7 @@ def _vp(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
-def _roundtrip(host, w, h, key, ly, lu, lv, my=None, muv=None, mvs=None, skip=None, tile=64):
+def _roundtrip(host, w, h, key, ly, lu, lv, my=None, muv=None, mvs=None, skip=None, tile=64, oracle=None):
     nb = (w // 8) * (h // 8)
     arrs = [np.ascontiguousarray(a) if a is not None else None for a in (ly, lu, lv, my, muv, mvs, skip)]
     cap = 64 + w * h * 8
@@ -43,6 +43,9 @@ def _roundtrip(host, w, h, key, ly, lu, lv, my=None, muv=None, mvs=None, skip=No
     d = [np.full((nb, 8, 8), 77, np.int16), np.full((nb, 4, 4), 77, np.int16), np.full((nb, 4, 4), 77, np.int16),
          np.full(nb, 99, np.uint8), np.full(nb, 99, np.uint8), np.full((nb, 2), 99, np.int16), np.full(nb, 99, np.uint8)]
     assert host.av1mi_host_entropy_decode(_vp(out), n, w, h, key, *[_vp(a) for a in d]) == 0
+    if oracle is not None:      # the independent C restatement must produce the same bytes
+        ref = oracle.entropy_encode_frame(w, h, key, tile, *arrs)
+        assert len(ref) == n and ref == out[:n].tobytes(), "host coder and oracle differ"
     for i in range(3):
         assert np.array_equal(d[i].reshape(-1), arrs[i].reshape(-1)), "plane %d levels differ" % i
     if key:
@@ -60,11 +63,11 @@ def _h0(levels):
     return float(-(p * np.log2(p)).sum() * levels.size / 8)
 
 
-@pytest.mark.parametrize("bd,q,tile", [(8, 40, 64), (8, 120, 128), (10, 200, 4096), (8, 200, 64)])
+@pytest.mark.parametrize("bd,q,tile", [(8, 40, 64), (8, 120, 128), (10, 200, 4096), (8, 200, 64), (10, 90, 32)])
 def test_key_frame_roundtrip_on_encoder_output(host, O, bd, q, tile):
     Y, U, V = synth.frames(200, 136, 1, bd)          # ragged: 3.125 x 2.125 tiles of 64
     o = O.intra_encode_frame(Y[0], U[0], V[0], bd, 8, q)
-    n = _roundtrip(host, 200, 136, 1, o["lev_y"], o["lev_u"], o["lev_v"], o["modes_y"], o["modes_uv"], tile=tile)
+    n = _roundtrip(host, 200, 136, 1, o["lev_y"], o["lev_u"], o["lev_v"], o["modes_y"], o["modes_uv"], tile=tile, oracle=O)
     # adaptive contexts must beat the memoryless entropy of the level alphabet + 1 byte per mode pair
     bound = _h0(o["lev_y"]) + _h0(o["lev_u"]) + _h0(o["lev_v"]) + o["modes_y"].size
     assert n < bound, (n, bound)
@@ -75,10 +78,10 @@ def test_p_frame_roundtrip_on_encoder_output(host, O):
     o = O.inter_encode_frame((Y[1], U[1], V[1]), (Y[0], U[0], V[0]), 8, 100)
     assert o["mvs"].any()
     for tile in (64, 128):
-        _roundtrip(host, 128, 64, 0, o["lev_y"], o["lev_u"], o["lev_v"], None, None, o["mvs"], o["skip"], tile=tile)
+        _roundtrip(host, 128, 64, 0, o["lev_y"], o["lev_u"], o["lev_v"], None, None, o["mvs"], o["skip"], tile=tile, oracle=O)
 
 
-def test_adversarial_symbols_roundtrip(host):
+def test_adversarial_symbols_roundtrip(host, O):
     rng = np.random.default_rng(11)
     w, h = 64, 48
     nb = (w // 8) * (h // 8)
@@ -92,17 +95,17 @@ def test_adversarial_symbols_roundtrip(host):
     lv[:, 0, 0] = 32767
     my = rng.integers(0, 13, nb).astype(np.uint8)
     muv = np.full(nb, 12, np.uint8)
-    _roundtrip(host, w, h, 1, ly, lu, lv, my, muv)
+    _roundtrip(host, w, h, 1, ly, lu, lv, my, muv, oracle=O)
     mvs = rng.integers(-32768, 32768, (nb, 2)).astype(np.int16)
     mvs[:4] = 0
     skip = (rng.random(nb) < 0.5).astype(np.uint8)
     ly[skip == 1] = 0
     lu[skip == 1] = 0
     lv[skip == 1] = 0
-    _roundtrip(host, w, h, 0, ly, lu, lv, None, None, mvs, skip)
+    _roundtrip(host, w, h, 0, ly, lu, lv, None, None, mvs, skip, oracle=O)
 
 
-def test_highly_skewed_stream_hits_carry_propagation(host):
+def test_highly_skewed_stream_hits_carry_propagation(host, O):
     # long runs of the most probable symbol drive `low` to 0xFF.. byte runs; a wrong carry shows as a decode mismatch
     w, h = 256, 256
     nb = (w // 8) * (h // 8)
@@ -112,7 +115,7 @@ def test_highly_skewed_stream_hits_carry_propagation(host):
     lu = np.zeros((nb, 4, 4), np.int16)
     lv = np.zeros((nb, 4, 4), np.int16)
     my = np.zeros(nb, np.uint8)
-    n = _roundtrip(host, w, h, 1, ly, lu, lv, my, my)
+    n = _roundtrip(host, w, h, 1, ly, lu, lv, my, my, oracle=O)
     assert n < 1.5 * nb      # about a byte per block even with the CDFs restarting in every 64x64 tile
 
 
