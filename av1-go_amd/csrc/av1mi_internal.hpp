@@ -86,4 +86,18 @@ hipError_t launch_quantize(const int32_t *coef, int16_t *levels, int32_t *dqcoef
 hipError_t launch_dequantize(const int16_t *levels, int32_t *dqcoef, long long n, int coef_per_blk, int dc_q,
                              int ac_q, int log_scale, int bd, hipStream_t s);
 
+// K9: tile entropy coder (entropy_kernels.hip)
+struct EntropyLaunch {
+  const int16_t *lev[3]; const uint8_t *modes_y, *modes_uv; const int16_t *mvs; const uint8_t *skip;
+  int w, h, nframes, key, tile;
+  uint8_t *slots; uint32_t slot_bytes;        // scratch: one payload slot per tile
+  uint32_t *sizes, *hdr_off, *pay_off;        // scratch: per tile
+  uint32_t *frame_hdr; uint64_t *frame_size;  // scratch: per frame
+  uint32_t *status;                           // scratch: bit 0 = out_cap too small, bit 1 = a slot ran over
+  uint8_t *out; uint64_t out_cap; uint64_t *frame_off;
+};
+hipError_t entropy_init_tables();
+hipError_t launch_entropy_code(const EntropyLaunch &L, hipStream_t s);
+hipError_t launch_entropy_pack(const EntropyLaunch &L, hipStream_t s);
+
 }  // namespace av1mi

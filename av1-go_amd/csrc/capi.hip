@@ -17,6 +17,8 @@ struct av1mi_ctx {
   char name[256] = { 0 };
   void *scratch = nullptr;  // staging for the host-pointer single-block forms
   size_t scratch_bytes = 0;
+  void *ent_scratch = nullptr;  // K9: tile slots + layout arrays
+  size_t ent_bytes = 0;
   // per-kernel profile: one event pair per launch while enabled
   bool prof_on = false;
   struct ProfRec { int kind; hipEvent_t e0, e1; };
@@ -127,7 +129,8 @@ int av1mi_open(int device, av1mi_ctx **out) {
   hipDeviceProp_t prop;
   if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess ||
       hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
+      hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
+      av1mi::entropy_init_tables() != hipSuccess) {
     delete ctx;
     return AV1MI_E_NODEV;
   }
@@ -141,6 +144,7 @@ void av1mi_close(av1mi_ctx *ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
+  if (ctx->ent_scratch) (void)hipFree(ctx->ent_scratch);
   for (auto &r : ctx->prof_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   for (auto e : ctx->prof_pool) (void)hipEventDestroy(e);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -225,7 +229,7 @@ int av1mi_prof_get(av1mi_ctx *ctx, int kind, int *launches, double *total_ms) {
 }
 const char *av1mi_kernel_kind_name(int kind) {
   static const char *n[AV1MI_K_KINDS] = { "fwd_txfm", "inv_txfm", "quantize", "dequantize", "intra_pred", "mc", "deblock",
-                                          "cdef", "loop_restoration", "intra_pipeline", "inter_pipeline", "misc" };
+                                          "cdef", "loop_restoration", "intra_pipeline", "inter_pipeline", "misc", "entropy_code", "entropy_pack" };
   return kind < 0 || kind >= AV1MI_K_KINDS ? "?" : n[kind];
 }
 
@@ -412,6 +416,46 @@ int av1mi_inter_encode(av1mi_ctx *ctx, const av1mi_inter_job *j) {
   L.w = j->width; L.h = j->height; L.stride_y = j->stride_y; L.stride_uv = j->stride_uv; L.bd = j->bit_depth; L.nframes = j->nframes;
   L.dc_q = av1mi_dc_q(j->qindex, j->bit_depth); L.ac_q = av1mi_ac_q(j->qindex, j->bit_depth); L.range = j->search_range;
   { ProfScope ps(ctx, AV1MI_K_INTER_PIPE); HIP_TRY(ctx, av1mi::launch_inter(L, ctx->stream)); }
+  return AV1MI_OK;
+}
+
+int av1mi_entropy_encode(av1mi_ctx *ctx, const av1mi_entropy_job *j) {
+  BIND(ctx);
+  if (!j) return fail(ctx, AV1MI_E_INVAL, "null job");
+  if (j->width <= 0 || j->height <= 0 || (j->width & 7) || (j->height & 7) || j->width > 16384 || j->height > 16384)
+    return fail(ctx, AV1MI_E_INVAL, "frame %dx%d must be a multiple of 8", j->width, j->height);
+  if (j->tile != 32 && j->tile != 64 && j->tile != 128) return fail(ctx, AV1MI_E_INVAL, "entropy tile %d not supported (32, 64, 128)", j->tile);
+  if (j->nframes < 0 || j->nframes > 65535) return fail(ctx, AV1MI_E_INVAL, "bad nframes");
+  const void *need[] = { j->d_lev_y, j->d_lev_u, j->d_lev_v, j->key ? (const void *)j->d_modes_y : (const void *)j->d_mvs,
+                         j->key ? (const void *)j->d_modes_uv : (const void *)j->d_skip, j->d_out, j->d_frame_off };
+  for (const void *p : need) if (!p) return fail(ctx, AV1MI_E_INVAL, "null device pointer");
+  if (((uintptr_t)j->d_lev_y | (uintptr_t)j->d_lev_u | (uintptr_t)j->d_lev_v) & 15) return fail(ctx, AV1MI_E_INVAL, "level planes must be 16-byte aligned");
+  if (((uintptr_t)j->d_frame_off & 7) || (!j->key && ((uintptr_t)j->d_mvs & 3))) return fail(ctx, AV1MI_E_INVAL, "misaligned device pointer");
+  if (j->nframes == 0) return AV1MI_OK;
+  const size_t tc = (size_t)(j->width + j->tile - 1) / j->tile, tr = (size_t)(j->height + j->tile - 1) / j->tile, tiles = tc * tr * j->nframes;
+  const size_t slot = (size_t)j->tile * j->tile * 9 + 64;   // 1.5 coefficients per luma sample, 6 bytes each
+  auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const size_t o_sizes = up(tiles * slot), o_hdr = o_sizes + up(tiles * 4), o_pay = o_hdr + up(tiles * 4), o_fh = o_pay + up(tiles * 4),
+               o_fs = o_fh + up((size_t)j->nframes * 4), o_st = o_fs + up((size_t)j->nframes * 8), total = o_st + 256;
+  if (ctx->ent_bytes < total) {
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->ent_scratch) (void)hipFree(ctx->ent_scratch);
+    ctx->ent_scratch = nullptr; ctx->ent_bytes = 0;
+    HIP_TRY(ctx, hipMalloc(&ctx->ent_scratch, total));
+    ctx->ent_bytes = total;
+  }
+  char *sc = (char *)ctx->ent_scratch;
+  av1mi::EntropyLaunch L;
+  L.lev[0] = j->d_lev_y; L.lev[1] = j->d_lev_u; L.lev[2] = j->d_lev_v;
+  L.modes_y = j->d_modes_y; L.modes_uv = j->d_modes_uv; L.mvs = j->d_mvs; L.skip = j->d_skip;
+  L.w = j->width; L.h = j->height; L.nframes = j->nframes; L.key = j->key != 0; L.tile = j->tile;
+  L.slots = (uint8_t *)sc; L.slot_bytes = (uint32_t)slot;
+  L.sizes = (uint32_t *)(sc + o_sizes); L.hdr_off = (uint32_t *)(sc + o_hdr); L.pay_off = (uint32_t *)(sc + o_pay);
+  L.frame_hdr = (uint32_t *)(sc + o_fh); L.frame_size = (uint64_t *)(sc + o_fs); L.status = (uint32_t *)(sc + o_st);
+  L.out = j->d_out; L.out_cap = j->out_cap; L.frame_off = j->d_frame_off;
+  HIP_TRY(ctx, hipMemsetAsync(L.status, 0, 4, ctx->stream));
+  { ProfScope ps(ctx, AV1MI_K_ENTROPY); HIP_TRY(ctx, av1mi::launch_entropy_code(L, ctx->stream)); }
+  { ProfScope ps(ctx, AV1MI_K_ENTROPY_PACK); HIP_TRY(ctx, av1mi::launch_entropy_pack(L, ctx->stream)); }
   return AV1MI_OK;
 }
 

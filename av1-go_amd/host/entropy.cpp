@@ -37,7 +37,7 @@ EntropyModels::EntropyModels() {
 }
 void EntropyModels::set_uniform() {
   for (int p = 0; p < 2; p++) {
-    cdf_init_uniform(eob[p], 8); cdf_init_uniform(gol[p], 16); cdf_init_uniform(mode[p], 13); cdf_init_uniform(mvc[p], 17);
+    cdf_init_uniform(eob[p], 8); cdf_init_uniform(gol[p], 16); cdf_init_uniform(mode[p], 13); cdf_init_uniform(mvc[p], 16);
     for (int b = 0; b < 4; b++) for (int c = 0; c < 3; c++) cdf_init_uniform(tok[p][b][c], 4);
   }
   cdf_init_uniform(skip, 2);
@@ -215,16 +215,21 @@ bool get_block(RangeDecoder &d, Models &m, int pt, int16_t *lv, int n, const uin
   }
   return true;
 }
+// vector difference component: class = bit length of |v| capped at 15 (16-ary: the partition's minimum-probability
+// term 4 * (N - 1) needs N <= 16 to leave symbol 0 a non-empty interval, as in AV1), then the bits below the leading one;
+// class 15 carries |v| - 16384 in 15 bits (|v| <= 32768)
 void put_mv_comp(RangeEncoder &e, uint16_t *cdf, int v) {
-  const unsigned a = (unsigned)(v < 0 ? -v : v); const int k = a ? 32 - __builtin_clz(a) : 0;   // bit length
-  e.encode(k, cdf, 17);                                                                           // |v| <= 32768: k <= 16
-  if (k > 1) e.encode_bits(a & ((1u << (k - 1)) - 1), k - 1);
+  const unsigned a = (unsigned)(v < 0 ? -v : v); int k = a ? 32 - __builtin_clz(a) : 0;
+  if (k > 15) k = 15;
+  e.encode(k, cdf, 16);
+  if (k == 15) e.encode_bits(a - 16384, 15);
+  else if (k > 1) e.encode_bits(a & ((1u << (k - 1)) - 1), k - 1);
   if (a) e.encode_bits(v < 0, 1);
 }
 int get_mv_comp(RangeDecoder &d, uint16_t *cdf) {
-  const int k = d.decode(cdf, 17);
+  const int k = d.decode(cdf, 16);
   if (!k) return 0;
-  const unsigned a = (1u << (k - 1)) | (k > 1 ? d.decode_bits(k - 1) : 0);
+  const unsigned a = k == 15 ? 16384 + d.decode_bits(15) : (1u << (k - 1)) | (k > 1 ? d.decode_bits(k - 1) : 0);
   return d.decode_bits(1) ? -(int)a : (int)a;
 }
 

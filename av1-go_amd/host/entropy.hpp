@@ -44,7 +44,7 @@ void cdf_adapt(uint16_t *cdf, int s, int nsyms);
 // adaptive models of one tile; every CDF is N cumulative 15-bit values followed by the adaptation counter.
 // Initial values: entropy_init.hpp (this project's own constants, tools/train_cdfs.py), NOT AV1's default tables.
 struct EntropyModels {
-  uint16_t eob[2][9], tok[2][4][3][5], gol[2][17], mode[2][14], skip[3], mvc[2][18];   // [plane type][...]
+  uint16_t eob[2][9], tok[2][4][3][5], gol[2][17], mode[2][14], skip[3], mvc[2][17];   // [plane type][...]
   EntropyModels();
   void set_uniform();
 };

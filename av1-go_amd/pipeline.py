@@ -3,7 +3,8 @@
 All frames of a segment are stacked into one tall plane per component so that every stage is ONE launch per
 segment (a 1080p frame is a few tens of microseconds of device work per stage: per-frame launches would be
 launch-bound).  Everything stays resident in HBM between stages; only the int16 levels and the mode bytes are
-meant to leave the device (host entropy coding, SURVEY.md §8a row H1 — not built yet).
+meant to leave the device: either uncoded for the host entropy coder (host/entropy.cpp), or as the
+finished byte stream of the GPU tile entropy coder (K9, `entropy_tile` > 0).
 """
 import numpy as np
 
@@ -41,9 +42,10 @@ class IntraPipeline:
          3 launches k_deblock     deblocking of Y, U, V (both passes fused)         rec -> dbl
          1 launch   k_cdef        CDEF of the three planes                          dbl -> cdef
          3 launches k_lr          loop restoration (Wiener, fixed default taps)     cdef (+ dbl rows) -> out
-    Filter parameters are fixed per segment by simple policies (no RD search); entropy coding is not built."""
+         2 steps    k_ent_code + pack   (entropy_tile > 0 only) tile entropy coder: levels + modes -> one byte stream
+    Filter parameters are fixed per segment by simple policies (no RD search)."""
 
-    def __init__(self, ctx, width, height, bd, frames, qindex, first_frame=0, block_size=8):
+    def __init__(self, ctx, width, height, bd, frames, qindex, first_frame=0, block_size=8, entropy_tile=0):
         self.ctx, self.bd, self.frames, self.bs, self.qindex = ctx, bd, frames, block_size, qindex
         self.width, self.height = width, height
         Y, U, V = synth.frames(width, height, frames, bd, first_frame)
@@ -59,6 +61,16 @@ class IntraPipeline:
                         ("lev_y", Y.size * 2), ("lev_u", U.size * 2), ("lev_v", V.size * 2),
                         ("modes_y", frames * nb), ("modes_uv", frames * nb)):
             self.d[name] = ctx.alloc(n)
+        self.entropy_tile, self.ent_job, self.entropy_in_step = entropy_tile, None, True
+        if entropy_tile:
+            if block_size != 8:
+                raise ValueError("the entropy coder's syntax is defined for 8x8 blocks")
+            self.ent_cap = frames * (width * height * 3 + 65536)      # raw int16 size: the coded stream stays far below
+            self.d["ent_out"], self.d["ent_off"] = ctx.alloc(self.ent_cap), ctx.alloc((frames + 1) * 8)
+            self.ent_job = av1mi.EntropyJob(width, height, frames, 1, entropy_tile)
+            for k in ("lev_y", "lev_u", "lev_v", "modes_y", "modes_uv"):
+                setattr(self.ent_job, "d_" + k, self.d[k].ptr)
+            self.ent_job.d_out, self.ent_job.out_cap, self.ent_job.d_frame_off = self.d["ent_out"].ptr, self.ent_cap, self.d["ent_off"].ptr
         self.job = av1mi.IntraJob(width, height, bd, frames, qindex, block_size, width, width // 2)
         for k in ("src_y", "src_u", "src_v", "rec_y", "rec_u", "rec_v", "lev_y", "lev_u", "lev_v", "modes_y", "modes_uv"):
             setattr(self.job, "d_" + k, self.d[k].ptr)
@@ -89,14 +101,18 @@ class IntraPipeline:
     def describe(self):
         return ("%dx%d %d-bit 4:2:0 intra-only (all key frames), tile = 64x64 superblock, %dx%d blocks: intra prediction "
                 "(11 modes, SAD decision) + fwd DCT + quant + dequant + inv DCT + recon fused, then deblocking (level %d), "
-                "CDEF (strengths %s, damping %d) and Wiener loop restoration (64x64 units, default taps); "
-                "entropy coding / OBU packing not built (levels + modes stay in HBM)"
-                % (self.width, self.height, self.bd, self.bs, self.bs, self.lf_level, self.cdef_sb[0].tolist(), self.cdef_damping))
+                "CDEF (strengths %s, damping %d) and Wiener loop restoration (64x64 units, default taps); %s"
+                % (self.width, self.height, self.bd, self.bs, self.bs, self.lf_level, self.cdef_sb[0].tolist(), self.cdef_damping,
+                   "levels + modes coded on the GPU by the tile entropy coder (%dx%d tiles, own syntax, not an AV1 bitstream)"
+                   % (self.entropy_tile, self.entropy_tile) if self.entropy_tile and self.entropy_in_step else
+                   "levels + modes stay uncoded in HBM (entropy coding not in the timed step)"))
 
     def step(self):
         c, d = self.ctx, self.d
         w, h, f = self.width, self.height, self.frames
         c.intra_encode(self.job)
+        if self.ent_job is not None and self.entropy_in_step:
+            c.entropy_encode(self.ent_job)
         c.deblock_frames(d["rec_y"], w, d["dbl_y"], w, w, h, self.bd, 0, d["mi_y"], w // 4, 0, 0, f)
         c.deblock_frames(d["rec_u"], w // 2, d["dbl_u"], w // 2, w // 2, h // 2, self.bd, 1, d["mi_c"], w // 8, 0, 0, f)
         c.deblock_frames(d["rec_v"], w // 2, d["dbl_v"], w // 2, w // 2, h // 2, self.bd, 1, d["mi_c"], w // 8, 0, 0, f)
@@ -110,7 +126,17 @@ class IntraPipeline:
         reconstruction (b) and the int16 levels (2); deblocking reads and writes a plane (2b)."""
         b = self.bps
         return {"intra_pipeline": (2 * b + 2) * self.samples, "deblock": 2 * b * self.samples / 3.0,
-                "cdef": 2 * b * self.samples, "loop_restoration": 2 * b * self.samples / 3.0}
+                "cdef": 2 * b * self.samples, "loop_restoration": 2 * b * self.samples / 3.0,
+                "entropy_code": 2 * self.samples}      # reads the int16 levels; the coded bytes are < 1 per coefficient
+
+    def coded_records(self):
+        """the frame records written by the last step (entropy_tile > 0)"""
+        off = self.d["ent_off"].download((self.frames + 1,), np.uint64)
+        total = int(off[-1])
+        if total > self.ent_cap:
+            raise RuntimeError("entropy output needs %d bytes, capacity %d" % (total, self.ent_cap))
+        data = self.d["ent_out"].download((max(total, 1),), np.uint8)[:total].tobytes()
+        return [data[int(off[i]):int(off[i + 1])] for i in range(self.frames)]
 
     def download(self, frame=0):
         """outputs of one frame of the segment (tests / PSNR)"""

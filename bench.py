@@ -32,6 +32,11 @@ def parse():
                          "frames, 1 key + 29 P (configs 3/4)")
     ap.add_argument("--frames", type=int, default=0, help="frames per step (segment length); 0 = default")
     ap.add_argument("--qindex", type=int, default=128)
+    ap.add_argument("--entropy", default="none", choices=["none", "gpu"],
+                    help="gpu = the tile entropy coder (K9) runs inside the timed step; none (default) = BASELINE config 2 as "
+                         "written (transform + prediction + filters), with the entropy stage timed in a separate leg and "
+                         "reported under \"entropy\"")
+    ap.add_argument("--entropy-tile", type=int, default=64, choices=[32, 64, 128])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="no GPU: exercise the rank/sharding/timing/aggregation plumbing with a stand-in step (gloo tests)")
@@ -66,6 +71,51 @@ def cpu_baseline(pipe, seconds=12.0):
     return {"value": done / dt, "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": "%d frames of the same segment through the oracle's intra encoder loop + deblock + CDEF + loop "
                       "restoration (same stages as the GPU step) in %.1f s" % (done, dt)}
+
+
+def entropy_leg(ctx, pipe, args, launches=5, host_seconds=6.0):
+    """The stage after the block pipeline, timed on the levels + modes the last step left in HBM: (a) the GPU tile entropy
+    coder (K9), HIP events on the pipeline's stream; (b) the host coder of the same syntax (host/entropy.cpp, the stage
+    BASELINE's north_star keeps on the host cores) on a bounded sample of the same frames, all host threads."""
+    import ctypes as C
+    ctx.entropy_encode(pipe.ent_job)          # warm: grows the context's scratch
+    ctx.sync()
+    ctx.prof_reset()
+    ctx.prof_enable(True)
+    for _ in range(launches):
+        ctx.entropy_encode(pipe.ent_job)
+    ctx.sync()
+    ctx.prof_enable(False)
+    prof = ctx.prof_get()
+    recs = pipe.coded_records()
+    code_ms = prof["entropy_code"][1] / prof["entropy_code"][0]
+    pack_ms = prof["entropy_pack"][1] / prof["entropy_pack"][0]
+    out = {"syntax": "own (AV1 range-coder arithmetic + CDF adaptation, spec 8.2.6); not an AV1 bitstream",
+           "tile": pipe.entropy_tile, "bytes_per_frame": sum(len(r) for r in recs) / len(recs),
+           "gpu": {"code_ms_per_launch": code_ms, "pack_ms_per_launch": pack_ms, "frames_per_launch": pipe.frames,
+                   "frames_per_s": pipe.frames / ((code_ms + pack_ms) * 1e-3),
+                   "levels_GBps": 2 * pipe.samples / (code_ms * 1e-3) / 1e9}}
+    host = os.path.join(ROOT, "av1-go_amd", "host", "libav1mi_host.so")
+    if os.path.exists(host):
+        lib = C.CDLL(host)
+        P = C.c_void_p
+        lib.av1mi_host_entropy_encode_stack.argtypes = [C.c_int] * 5 + [P] * 5
+        lib.av1mi_host_entropy_encode_stack.restype = C.c_longlong
+        threads = min(os.cpu_count() or 1, 16)
+        n = min(pipe.frames, threads)
+        w, h = pipe.width, pipe.height
+        nb = (w // 8) * (h // 8)
+        lv = [pipe.d["lev_" + p].download((pipe.frames, nb * (64 if p == "y" else 16)), np.int16)[:n].copy() for p in "yuv"]
+        md = [pipe.d[k].download((pipe.frames, nb), np.uint8)[:n].copy() for k in ("modes_y", "modes_uv")]
+        vp = lambda a: a.ctypes.data_as(P)
+        done, tot, t0 = 0, 0, time.perf_counter()
+        while time.perf_counter() - t0 < host_seconds:
+            tot = lib.av1mi_host_entropy_encode_stack(w, h, n, threads, pipe.entropy_tile, *[vp(a) for a in lv + md])
+            done += n
+        dt = time.perf_counter() - t0
+        out["host"] = {"frames_per_s": done / dt, "threads": threads, "sample": "%d frames in %.1f s" % (done, dt),
+                       "bytes_match_gpu": tot == sum(len(r) for r in recs[:n])}
+    return out
 
 
 PMC_KERNEL = {"intra_pipeline": "k_intra_pipe", "deblock": "k_deblock", "cdef": "k_cdef", "loop_restoration": "k_lr",
@@ -162,7 +212,9 @@ def main():
         frames = segs * gop
         pipe = pipeline.GopPipeline(ctx, W, H, bd, segs, gop, args.qindex, first_frame=segment_of_rank(rank, frames))
     else:
-        pipe = pipeline.IntraPipeline(ctx, W, H, bd, frames, args.qindex, first_frame=segment_of_rank(rank, frames))
+        pipe = pipeline.IntraPipeline(ctx, W, H, bd, frames, args.qindex, first_frame=segment_of_rank(rank, frames),
+                                      entropy_tile=args.entropy_tile)
+        pipe.entropy_in_step = args.entropy == "gpu"
 
     def barrier():
         ctx.sync()
@@ -206,8 +258,10 @@ def main():
         out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                            "frac": ach / HBM_PEAK_GBPS, "traffic": pmc_traffic(dom, args.workload, frames), "algorithmic_bytes_per_launch": alg[dom],
                            "avg_launch_ms": ms / n, "launches": n}
-        out["kernels"] = {k: {"launches": v[0], "avg_ms": v[1] / v[0], "algorithmic_GBps": alg[k] / (v[1] / v[0] * 1e-3) / 1e9}
-                          for k, v in prof.items()}
+        out["kernels"] = {k: {"launches": v[0], "avg_ms": v[1] / v[0],
+                              "algorithmic_GBps": alg[k] / (v[1] / v[0] * 1e-3) / 1e9 if k in alg else None} for k, v in prof.items()}
+        if world == 1 and not args.workload.endswith("-gop"):
+            out["entropy"] = entropy_leg(ctx, pipe, args)
         if world == 1 and not args.no_cpu_baseline and not args.workload.endswith("-gop"):
             out["cpu_baseline"] = cpu_baseline(pipe)
         else:

@@ -78,7 +78,8 @@ int av1mi_timer_end(av1mi_ctx *ctx, float *elapsed_ms);
  * returns, for one kernel kind, the number of launches and the summed device time since the last reset. */
 enum av1mi_kernel_kind {
   AV1MI_K_FWD_TXFM, AV1MI_K_INV_TXFM, AV1MI_K_QUANT, AV1MI_K_DEQUANT, AV1MI_K_INTRA_PRED, AV1MI_K_MC,
-  AV1MI_K_DEBLOCK, AV1MI_K_CDEF, AV1MI_K_LR, AV1MI_K_INTRA_PIPE, AV1MI_K_INTER_PIPE, AV1MI_K_MISC, AV1MI_K_KINDS
+  AV1MI_K_DEBLOCK, AV1MI_K_CDEF, AV1MI_K_LR, AV1MI_K_INTRA_PIPE, AV1MI_K_INTER_PIPE, AV1MI_K_MISC, AV1MI_K_ENTROPY,
+  AV1MI_K_ENTROPY_PACK, AV1MI_K_KINDS
 };
 int av1mi_prof_enable(av1mi_ctx *ctx, int on);
 int av1mi_prof_reset(av1mi_ctx *ctx);
@@ -225,6 +226,27 @@ typedef struct av1mi_inter_job {
   uint8_t *d_skip;      /* nframes * (w/8)*(h/8) */
 } av1mi_inter_job;
 int av1mi_inter_encode(av1mi_ctx *ctx, const av1mi_inter_job *job);
+
+/* ---- K9: tile entropy coder (the stage that follows the block pipelines: SURVEY.md §8a row H1 keeps it on the host
+ * cores and §8e names it the scaling risk; here the symbols never leave HBM uncoded).  Codes the outputs of
+ * av1mi_intra_encode (key = 1: levels + modes) or av1mi_inter_encode (key = 0: levels + vectors + skip flags), 8x8
+ * blocks, of `nframes` stacked frames into ONE contiguous byte stream of frame records
+ *   [log2(tile)] [varint payload size of every tile, raster order] [tile payloads]
+ * in the syntax of av1-go_amd/host/entropy.hpp (AV1's range-coder arithmetic and CDF adaptation, spec §8.2.6, over
+ * this project's own symbols and initial CDFs — not an AV1 bitstream).  Every tile (tile x tile luma samples, tile =
+ * 32, 64 or 128) has an independent coder state: one GPU lane per tile.  d_frame_off receives nframes + 1 byte
+ * offsets into d_out (the last one = total size).  If the total exceeds out_cap nothing is written to d_out and
+ * d_frame_off[nframes] still holds the size needed (worst case 6 bytes per coefficient + 64 per tile).
+ * Scratch (one slot per tile) is owned by the context and grows on demand. */
+typedef struct av1mi_entropy_job {
+  int width, height, nframes, key, tile;
+  const int16_t *d_lev_y, *d_lev_u, *d_lev_v;
+  const uint8_t *d_modes_y, *d_modes_uv;   /* key = 1 */
+  const int16_t *d_mvs; const uint8_t *d_skip;   /* key = 0 */
+  uint8_t *d_out; size_t out_cap;
+  uint64_t *d_frame_off;                   /* nframes + 1 entries, 8-byte aligned */
+} av1mi_entropy_job;
+int av1mi_entropy_encode(av1mi_ctx *ctx, const av1mi_entropy_job *job);
 
 /* ---- host-pointer single-block forms (SURVEY.md §8b "per-stage test entry points"): copy in, run the
  * same kernels, copy out, synchronous. */

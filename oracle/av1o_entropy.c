@@ -15,7 +15,8 @@
  * Tile payload: blocks in raster order inside the tile; per block
  *   key frame:  mode_y (13-ary), mode_uv (13-ary)
  *   P frame:    skip (binary), mv.x and mv.y as differences to the left block of the same tile (wrapping int16):
- *               bit-length class (17-ary), the bits below the leading one (raw), sign (raw)
+ *               bit-length class capped at 15 (16-ary), the bits below the leading one (class 15: |d| - 16384 in 15 bits),
+ *               sign (raw)
  *   unless skipped, for Y 8x8 then U 4x4 then V 4x4 in zig-zag order:
  *               eob class (8-ary: 0,1,2,3-4,5-8,9-16,17-32,33-64) + offset bits (raw),
  *               then the token min(|l|,3) of every coefficient below eob (4-ary, context = plane type, band of position,
@@ -102,8 +103,8 @@ static size_t finish(enc_t *e) {
   return e->n;
 }
 
-/* model offsets inside kEntropyInit (uint16 words): eob[2][9] tok[2][4][3][5] gol[2][17] mode[2][14] skip[3] mvc[2][18] */
-enum { M_EOB = 0, M_TOK = 18, M_GOL = 138, M_MODE = 172, M_SKIP = 200, M_MVC = 203, M_WORDS = 239 };
+/* model offsets inside kEntropyInit (uint16 words): eob[2][9] tok[2][4][3][5] gol[2][17] mode[2][14] skip[3] mvc[2][17] */
+enum { M_EOB = 0, M_TOK = 18, M_GOL = 138, M_MODE = 172, M_SKIP = 200, M_MVC = 203, M_WORDS = 237 };
 
 static int bitlen(uint32_t v) { int n = 0; while (v) { n++; v >>= 1; } return n; }
 
@@ -148,9 +149,11 @@ static void put_coeffs(enc_t *e, uint16_t *m, int pt, const int16_t *lv, int n, 
 }
 static void put_mvd(enc_t *e, uint16_t *cdf, int v) {
   const uint32_t a = (uint32_t)(v < 0 ? -v : v);
-  const int k = bitlen(a);
-  put_sym(e, cdf, k, 17);
-  if (k > 1) put_raw(e, a & ((1u << (k - 1)) - 1), k - 1);
+  int k = bitlen(a);
+  if (k > 15) k = 15;                 /* N <= 16 keeps 4 * (N - 1) below the smallest interval symbol 0 can be left with */
+  put_sym(e, cdf, k, 16);
+  if (k == 15) put_raw(e, a - 16384, 15);
+  else if (k > 1) put_raw(e, a & ((1u << (k - 1)) - 1), k - 1);
   if (a) put_raw(e, v < 0, 1);
 }
 
@@ -180,7 +183,7 @@ size_t av1o_entropy_encode_tile(int w, int h, int key, int tile, int tx, int ty,
         const int px = bx > bx0 ? mvs[(b - 1) * 2] : 0, py = bx > bx0 ? mvs[(b - 1) * 2 + 1] : 0;
         put_sym(&e, m + M_SKIP, skip[b] != 0, 2);
         put_mvd(&e, m + M_MVC, (int16_t)(mvs[b * 2] - px));
-        put_mvd(&e, m + M_MVC + 18, (int16_t)(mvs[b * 2 + 1] - py));
+        put_mvd(&e, m + M_MVC + 17, (int16_t)(mvs[b * 2 + 1] - py));
         coded = !skip[b];
       }
       if (coded) {

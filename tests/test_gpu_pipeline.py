@@ -78,3 +78,20 @@ def test_closed_gop_chain_matches_oracle(ctx, O):
             for i in range(3):
                 assert (got[t][i][s] == ref[i]).all(), (s, t, i)
     gp.close()
+
+
+def test_pipeline_with_gpu_entropy_stage(ctx, O):
+    """levels + modes never leave HBM uncoded: the records of the fused step equal the oracle coder run on the oracle's
+    encoder-loop outputs (block pipeline parity and entropy parity chained)."""
+    import pipeline
+    w, h, bd, q = 320, 200, 8, 110
+    pipe = pipeline.IntraPipeline(ctx, w, h, bd, 3, q, first_frame=4, entropy_tile=64)
+    pipe.step()
+    recs = pipe.coded_records()
+    Y, U, V = pipe.src
+    for f in range(3):
+        r = O.intra_encode_frame(Y[f], U[f], V[f], bd, 8, q)
+        ref = O.entropy_encode_frame(w, h, 1, 64, r["lev_y"], r["lev_u"], r["lev_v"], r["modes_y"], r["modes_uv"])
+        assert recs[f] == ref, "frame %d: %d vs %d bytes" % (f, len(recs[f]), len(ref))
+        assert len(ref) < Y[f].nbytes           # and it compresses
+    pipe.close()

@@ -84,14 +84,14 @@ def _varint(data, pos):
             return v, pos
 
 
-def _check_first_segment_against_oracle(host, data, w, h, q):
+def _check_first_segment_against_oracle(host, data, w, h, q, nframes):
     """the coded file, decoded by the host entropy decoder, carries exactly the symbols the oracle's encoder loop produces"""
     from oracle import oracle
     import synth
     oracle.build()
     P = C.c_void_p
     host.av1mi_host_entropy_decode.argtypes = [P, C.c_longlong, C.c_int, C.c_int, C.c_int, P, P, P, P, P, P, P]
-    Y, U, V = synth.frames(w, h, 1, 8)
+    Y, U, V = synth.frames(w, h, nframes, 8)       # same call as _write_y4m: the texture depends on the clip length
     ok = oracle.intra_encode_frame(Y[0], U[0], V[0], 8, 8, q)
     nb = (w // 8) * (h // 8)
     pos = data.index(b"\n", data.index(b"SEG 3 ")) + 1
@@ -139,7 +139,7 @@ def test_run_transcode_and_process_job_on_gpu(host, tmp_path):
     first = data.index(b"SEG 3 ")
     assert data[data.index(b"\n", first) + 1:data.index(b"\n", first) + 2] == b"K"
     assert len(data) < src.stat().st_size            # coarse quantiser: packed levels are smaller than the raw input
-    _check_first_segment_against_oracle(host, data, 192, 128, 120)
+    _check_first_segment_against_oracle(host, data, 192, 128, 120, 7)
     out.unlink()
     # lifecycle: generous ratio -> the source is replaced by the coded file; tight ratio -> skipped with markers
     status, reason = C.create_string_buffer(256), C.create_string_buffer(1024)
