@@ -8,10 +8,10 @@
 // signs), so all lanes of a wave are at the SAME kind of symbol with a compile-time alphabet size: the CDF update is a
 // fully unrolled LDS read-modify-write per lane with no divergence on N, and the rare kinds run in short loops.
 //
-//   k_ent_code    lane = tile.  Models: 237 u16 words per lane in LDS ([word][lane]: conflict-free for equal words).
+//   k_ent_code    lane = tile.  Models: 61 CDFs x 8 bytes per lane in LDS, every adaptive symbol is 4-ary: one b64 load + store.
 //                 The current block's 96 levels + its escape list sit in a lane-private LDS row (odd dword stride).
-//                 Bytes leave through a one-byte hold + 0xFF run counter (carries never touch written bytes) into the
-//                 tile's private slot of 6 bytes per coefficient (a bound: <= 43 bits per coefficient + block headers).
+//                 Bits leave 32 at a time as big-endian words (a late carry ripples back through the lane's own words)
+//                 into the tile's private slot of 6 bytes per coefficient (a bound: <= 43 bits per coefficient + block headers).
 //   k_ent_layout  per frame: scan of the tile sizes -> header (varint) and payload offsets inside the frame record.
 //   k_ent_frames  scan over frames -> record offsets, capacity check.
 //   k_ent_pack    per tile: varint + payload copied to its place: the host receives one contiguous stream.
@@ -21,72 +21,84 @@
 // bound by the serial dependency chain of the coder (issue latency of one wave per SIMD), not by bandwidth.
 #include "av1mi_internal.hpp"
 #include "../host/entropy_init.hpp"
+#include <utility>
 
 namespace av1mi {
 
 namespace {
 
-enum { M_EOB = 0, M_TOK = 18, M_GOL = 138, M_MODE = 172, M_SKIP = 200, M_MVC = 203, M_WORDS = 237 };
-static_assert(sizeof(kEntropyInit) == M_WORDS * 2, "entropy_init.hpp layout");
+// CDF ids: same enum as host/entropy.hpp; one CDF = (c0, c1, c2, counter) = 8 bytes
+enum { C_TOK = 0, C_GOL = 24, C_EOB_HI = 34, C_EOB_LO = 36, C_MODE_HI = 40, C_MODE_LO = 42, C_SKIP = 50, C_MV_HI = 51, C_MV_LO = 53, C_COUNT = 61 };
+static_assert(sizeof(kEntropyInit) == C_COUNT * 8, "entropy_init.hpp layout");
 constexpr int ROW = 162;   // int16 per lane row: 96 levels (Y 64, U 16, V 16) + 64 escapes + 2 pad = 81 dwords (odd)
 
-__constant__ uint16_t kInit[M_WORDS];   // filled once per context from kEntropyInit
-__constant__ uint8_t kScan8[64] = { 0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
-                                    35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63 };
-__constant__ uint8_t kScan4[16] = { 0, 1, 4, 8, 5, 2, 3, 6, 9, 12, 13, 10, 7, 11, 14, 15 };
-
-struct Enc {
-  uint32_t low, rng;   // low holds 16 + pend bits
-  int pend, held, ff;  // held-back byte (-1: none) followed by ff bytes of 0xFF
-  uint8_t *out; uint32_t n, cap;
-};
-__device__ inline void raw_out(Enc &e, int b) { if (e.n < e.cap) e.out[e.n] = (uint8_t)b; e.n++; }
-__device__ inline void byte_out(Enc &e, int b) {
-  if (b == 0xFF && e.held >= 0) { e.ff++; return; }
-  if (e.held >= 0) raw_out(e, e.held);
-  for (; e.ff; e.ff--) raw_out(e, 0xFF);
-  e.held = b;
+__constant__ uint2 kInit[C_COUNT];   // filled once per context from kEntropyInit
+// zig-zag scan position of raster index r in an n x n block (compile time): the block is staged into the lane's LDS row
+// already in scan order, so the coding loops index it with the (scalar) loop counter and never look a table up
+constexpr int zz_pos(int n, int r) {
+  int k = 0;
+  for (int d = 0; d < 2 * n - 1; d++)
+    for (int i = 0; i <= d; i++) {
+      const int rr = (d & 1) ? i : d - i, c = d - rr;
+      if (rr < n && c < n) { if (rr * n + c == r) return k; k++; }
+    }
+  return -1;
 }
-__device__ inline void carry(Enc &e) {
-  if (e.ff) { raw_out(e, e.held + 1); for (; e.ff > 1; e.ff--) raw_out(e, 0); e.ff = 0; e.held = 0; }
-  else e.held += 1;
+template <int N, int R> struct ZZ { static constexpr int pos = zz_pos(N, R); };
+static_assert(ZZ<8, 8>::pos == 2 && ZZ<8, 16>::pos == 3 && ZZ<8, 63>::pos == 63 && ZZ<4, 4>::pos == 2 && ZZ<4, 13>::pos == 10, "zig-zag");
+// dwords I... of a block (two raster-adjacent int16 each) scattered to their scan positions
+template <int N, int... I> __device__ inline void stage_scan(int16_t *dst, const uint32_t *dw, std::integer_sequence<int, I...>) {
+  ((dst[ZZ<N, 2 * I>::pos] = (int16_t)(dw[I] & 0xFFFF), dst[ZZ<N, 2 * I + 1>::pos] = (int16_t)(dw[I] >> 16)), ...);
+}
+
+// Coder state of one lane.  `low` carries 16 + pend bits (pend < 32 between symbols) plus, on top, at most one unresolved
+// carry bit: a carry out of an addition is NOT resolved when it happens (the interval never leaves [low, low + rng) of the
+// previous state, so a second one cannot pile up) but when the next 32 finished bits leave as a big-endian word: bit 32 of
+// that word is the carry, and it ripples into the words already in the slot (lane-private memory, rare).  In a wave of 64
+// coders SOME lane flushes at almost every step, so the flush itself must be a few predicated instructions, not a branchy
+// hold-back state machine.  The byte stream is the same as a byte-wise coder's (oracle/av1o_entropy.c).
+struct Enc {
+  uint64_t low; uint32_t rng; int pend;
+  uint32_t *out; uint32_t n, cap;     // words
+};
+__device__ inline void ripple(Enc &e) {    // +1 into the big-endian number already written
+  for (uint32_t i = e.n < e.cap ? e.n : e.cap; i-- > 0;) {
+    const uint32_t w = __builtin_bswap32(e.out[i]) + 1;
+    e.out[i] = __builtin_bswap32(w);
+    if (w) break;
+  }
+}
+__device__ inline void flush_word(Enc &e) {
+  e.pend -= 32;
+  const uint64_t w = e.low >> (16 + e.pend);
+  e.low &= ((uint64_t)1 << (16 + e.pend)) - 1;
+  if (w >> 32) ripple(e);
+  if (e.n < e.cap) e.out[e.n] = __builtin_bswap32((uint32_t)w);
+  e.n++;
 }
 // interval [low + add, low + add + nrng) becomes the state; renormalise to a 16-bit range
 __device__ inline void commit(Enc &e, uint32_t add, uint32_t nrng) {
-  e.low += add;
-  const int lim = 16 + e.pend;
-  if (e.low >> lim) { carry(e); e.low &= (1u << lim) - 1; }
   const int d = __clz((int)nrng) - 16;
+  e.low = (e.low + add) << d;      // <= 17 + 31 + 15 bits
   e.rng = nrng << d;
-  uint64_t wide = (uint64_t)e.low << d;
   e.pend += d;
-  while (e.pend >= 8) {
-    e.pend -= 8;
-    byte_out(e, (int)((wide >> (16 + e.pend)) & 0xFF));
-    wide &= ((uint64_t)1 << (16 + e.pend)) - 1;
-  }
-  e.low = (uint32_t)wide;
+  if (e.pend >= 32) flush_word(e);
 }
-// adaptive symbol s of an N-ary alphabet whose CDF starts at model word `off` of this lane (m = &models[lane])
-template <int N> __device__ inline void enc_sym(Enc &e, uint16_t *m, int off, int s) {
-  uint32_t c[N - 1];
-#pragma unroll
-  for (int i = 0; i < N - 1; i++) c[i] = m[(off + i) * 64];
-  const uint32_t cnt = m[(off + N) * 64];
-  uint32_t cs = 32768, cp = 0;
-#pragma unroll
-  for (int i = 0; i < N - 1; i++) { cs = s == i ? c[i] : cs; cp = s == i + 1 ? c[i] : cp; }
+// adaptive 4-ary symbol with CDF `id` of this lane's model row: one 64-bit LDS load, one store
+__device__ inline void enc4(Enc &e, uint2 *mrow, int id, int s) {
+  const uint2 v = mrow[id];
+  const uint32_t c0 = v.x & 0xFFFF, c1 = v.x >> 16, c2 = v.y & 0xFFFF, cnt = v.y >> 16;
+  const uint32_t cs = s == 0 ? c0 : s == 1 ? c1 : s == 2 ? c2 : 32768u;
+  const uint32_t cp = s == 1 ? c0 : s == 2 ? c1 : c2;
   const uint32_t r8 = e.rng >> 8;
-  const uint32_t bot = ((r8 * ((32768u - cs) >> 6)) >> 1) + 4u * (uint32_t)(N - 1 - s);
-  const uint32_t top = s ? ((r8 * ((32768u - cp) >> 6)) >> 1) + 4u * (uint32_t)(N - s) : e.rng;
+  const uint32_t bot = ((r8 * ((32768u - cs) >> 6)) >> 1) + 4u * (uint32_t)(3 - s);
+  const uint32_t top = s ? ((r8 * ((32768u - cp) >> 6)) >> 1) + 4u * (uint32_t)(4 - s) : e.rng;
   commit(e, bot, top - bot);
-  const int rate = 3 + (cnt > 15) + (cnt > 31) + (N >= 4 ? 2 : 1);
-#pragma unroll
-  for (int i = 0; i < N - 1; i++) {
-    const uint32_t v = c[i];
-    m[(off + i) * 64] = (uint16_t)(i >= s ? v + ((32768u - v) >> rate) : v - (v >> rate));
-  }
-  if (cnt < 32) m[(off + N) * 64] = (uint16_t)(cnt + 1);
+  const int rate = 5 + (cnt > 15) + (cnt > 31);
+  const uint32_t n0 = s <= 0 ? c0 + ((32768u - c0) >> rate) : c0 - (c0 >> rate);
+  const uint32_t n1 = s <= 1 ? c1 + ((32768u - c1) >> rate) : c1 - (c1 >> rate);
+  const uint32_t n2 = s <= 2 ? c2 + ((32768u - c2) >> rate) : c2 - (c2 >> rate);
+  mrow[id] = make_uint2(n0 | (n1 << 16), n2 | ((cnt + (cnt < 32)) << 16));
 }
 // n (1..8) equiprobable bits as one symbol over 2^n slots
 __device__ inline void enc_raw(Enc &e, int n, uint32_t v) {
@@ -105,15 +117,15 @@ __device__ inline int wave_max(int v) {
 }
 
 // one transform block of n coefficients at int16 index `base` of the lane row
-template <int NCOEF> __device__ inline void code_block(Enc &e, uint16_t *m, int16_t *row, int base, int pt, bool coded) {
-  const uint8_t *scan = NCOEF == 64 ? kScan8 : kScan4;
+__device__ inline void code_block(Enc &e, uint2 *m, int16_t *row, int base, int pt, int ncoef, bool coded) {
   int eob = 0;
 #pragma unroll 8
-  for (int i = 0; i < NCOEF; i++) eob = row[base + scan[i]] != 0 ? i + 1 : eob;
+  for (int i = 0; i < ncoef; i++) eob = row[base + i] != 0 ? i + 1 : eob;
   if (!coded) eob = 0;
   if (coded) {
     const int cls = eob <= 2 ? eob : 33 - __clz(eob - 1);
-    enc_sym<8>(e, m, M_EOB + pt * 9, cls);
+    enc4(e, m, C_EOB_HI + pt, cls >> 2);
+    enc4(e, m, C_EOB_LO + pt * 2 + (cls >> 2), cls & 3);
     const int xb = cls >= 3 ? cls - 2 : 0;
     enc_raw16(e, cls >= 3, xb, (uint32_t)(eob - (1 << xb) - 1));
   }
@@ -121,10 +133,10 @@ template <int NCOEF> __device__ inline void code_block(Enc &e, uint16_t *m, int1
   int prev = 0, nnz = 0, nesc = 0;
   uint64_t signs = 0;
   for (int i = 0; i < emax; i++) {          // uniform trip count: scan position and band are scalar
-    const int pos = scan[i], band = i == 0 ? 0 : i <= 4 ? 1 : i <= 15 ? 2 : 3;
+    const int band = i == 0 ? 0 : i <= 4 ? 1 : i <= 15 ? 2 : 3;
     if (i < eob) {
-      const int l = row[base + pos], a = l < 0 ? -l : l, t = a < 3 ? a : 3;
-      enc_sym<4>(e, m, M_TOK + ((pt * 4 + band) * 3 + prev) * 5, t);
+      const int l = row[base + i], a = l < 0 ? -l : l, t = a < 3 ? a : 3;
+      enc4(e, m, C_TOK + (pt * 4 + band) * 3 + prev, t);
       if (a) { signs = (signs << 1) | (uint64_t)(l < 0); nnz++; }
       if (a >= 3) row[96 + nesc++] = (int16_t)(a - 2);           // 1..32766
       prev = t < 2 ? t : 2;
@@ -133,11 +145,12 @@ template <int NCOEF> __device__ inline void code_block(Enc &e, uint16_t *m, int1
   const int xmax = wave_max(nesc);
   for (int j = 0; j < xmax; j++) {
     const bool on = j < nesc;
-    uint32_t x = 1; int k = 0;
-    if (on) {
-      x = (uint32_t)row[96 + j];
-      k = 31 - __clz((int)x);
-      enc_sym<16>(e, m, M_GOL + pt * 17, k);
+    const uint32_t x = on ? (uint32_t)row[96 + j] : 1u;
+    const int k = 31 - __clz((int)x);
+    int rest = on ? k : -1;                  // chain min(k,3), min(k-3,3), ... until a symbol below 3
+    for (int c = 0; c < 5; c++) {
+      if (__builtin_amdgcn_readfirstlane(__any(rest >= 0)) == 0) break;
+      if (rest >= 0) { const int sy = rest < 3 ? rest : 3; enc4(e, m, C_GOL + pt * 5 + c, sy); rest = sy < 3 ? -1 : rest - 3; }
     }
     enc_raw16(e, on, k, x & ((1u << k) - 1));
   }
@@ -150,17 +163,17 @@ template <int NCOEF> __device__ inline void code_block(Enc &e, uint16_t *m, int1
     }
   }
 }
-__device__ inline void code_mvd(Enc &e, uint16_t *m, int off, bool on, int v) {
+__device__ inline void code_mvd(Enc &e, uint2 *m, int comp, bool on, int v) {
   const uint32_t a = (uint32_t)(v < 0 ? -v : v);
   int k = a ? 32 - __clz((int)a) : 0;
   k = k > 15 ? 15 : k;
-  if (on) enc_sym<16>(e, m, off, k);
+  if (on) { enc4(e, m, C_MV_HI + comp, k >> 2); enc4(e, m, C_MV_LO + comp * 4 + (k >> 2), k & 3); }
   enc_raw16(e, on && k > 1, k == 15 ? 15 : k - 1, k == 15 ? a - 16384 : a & ((1u << (k > 0 ? k - 1 : 0)) - 1));
   if (on && a) enc_raw(e, 1, v < 0);
 }
 
 __global__ void __launch_bounds__(64) k_ent_code(EntropyLaunch L) {
-  __shared__ uint16_t s_models[M_WORDS * 64];
+  __shared__ uint2 s_models[64 * C_COUNT];      // lane rows of 61 x 8 bytes (odd multiple of 8: conflict-free for equal ids)
   __shared__ int16_t s_rows[64 * ROW];
   const int lane = threadIdx.x;
   const long long g = (long long)blockIdx.x * 64 + lane;
@@ -171,59 +184,63 @@ __global__ void __launch_bounds__(64) k_ent_code(EntropyLaunch L) {
   const int bx0 = (t % tc) * tb, by0 = (t / tc) * tb;
   const int bx1 = live ? (bx0 + tb < bw ? bx0 + tb : bw) : bx0, by1 = live ? (by0 + tb < bh ? by0 + tb : bh) : by0;
   const size_t nb = (size_t)bw * bh, fb = (size_t)f * nb;
-  uint16_t *m = s_models + lane;
+  uint2 *m = s_models + lane * C_COUNT;
   int16_t *row = s_rows + lane * ROW;
-  for (int w = 0; w < M_WORDS; w++) m[w * 64] = kInit[w];
+  for (int i = 0; i < C_COUNT; i++) m[i] = kInit[i];
   Enc e;
-  e.low = 0; e.rng = 0x8000; e.pend = 0; e.held = -1; e.ff = 0; e.n = 0;
-  e.cap = live ? (uint32_t)L.slot_bytes : 0; e.out = L.slots + (live ? (size_t)g * L.slot_bytes : 0);
+  e.low = 0; e.rng = 0x8000; e.pend = 0; e.n = 0;
+  e.cap = live ? L.slot_bytes / 4 : 0; e.out = (uint32_t *)(L.slots + (live ? (size_t)g * L.slot_bytes : 0));
   for (int lby = 0; lby < tb; lby++)
     for (int lbx = 0; lbx < tb; lbx++) {   // uniform over the wave; ragged tiles mask lanes off
       const int bx = bx0 + lbx, by = by0 + lby;
       const bool valid = bx < bx1 && by < by1;
       const size_t b = fb + (size_t)(valid ? by * bw + bx : 0);
       bool coded = valid;
-      if (valid) {
-        uint32_t *dst = (uint32_t *)row;
+      if (valid) {       // stage the block's levels in SCAN order
         const uint4 *sy = (const uint4 *)(L.lev[0] + b * 64), *su = (const uint4 *)(L.lev[1] + b * 16), *sv = (const uint4 *)(L.lev[2] + b * 16);
+        uint32_t dw[32];
 #pragma unroll
-        for (int k = 0; k < 8; k++) { const uint4 v = sy[k]; dst[k * 4] = v.x; dst[k * 4 + 1] = v.y; dst[k * 4 + 2] = v.z; dst[k * 4 + 3] = v.w; }
+        for (int k = 0; k < 8; k++) { const uint4 v = sy[k]; dw[k * 4] = v.x; dw[k * 4 + 1] = v.y; dw[k * 4 + 2] = v.z; dw[k * 4 + 3] = v.w; }
+        stage_scan<8>(row, dw, std::make_integer_sequence<int, 32>());
+        uint32_t du[16];
 #pragma unroll
-        for (int k = 0; k < 2; k++) { const uint4 v = su[k]; dst[32 + k * 4] = v.x; dst[33 + k * 4] = v.y; dst[34 + k * 4] = v.z; dst[35 + k * 4] = v.w; }
-#pragma unroll
-        for (int k = 0; k < 2; k++) { const uint4 v = sv[k]; dst[40 + k * 4] = v.x; dst[41 + k * 4] = v.y; dst[42 + k * 4] = v.z; dst[43 + k * 4] = v.w; }
+        for (int k = 0; k < 2; k++) { const uint4 v = su[k], w = sv[k]; du[k * 4] = v.x; du[k * 4 + 1] = v.y; du[k * 4 + 2] = v.z; du[k * 4 + 3] = v.w;
+                                      du[8 + k * 4] = w.x; du[9 + k * 4] = w.y; du[10 + k * 4] = w.z; du[11 + k * 4] = w.w; }
+        stage_scan<4>(row + 64, du, std::make_integer_sequence<int, 8>());
+        stage_scan<4>(row + 80, du + 8, std::make_integer_sequence<int, 8>());
       }
       if (L.key) {
         int my = 0, muv = 0;
         if (valid) { my = L.modes_y[b]; muv = L.modes_uv[b]; my = my < 13 ? my : 0; muv = muv < 13 ? muv : 0; }
-        if (valid) enc_sym<13>(e, m, M_MODE, my);
-        if (valid) enc_sym<13>(e, m, M_MODE + 14, muv);
+        if (valid) { enc4(e, m, C_MODE_HI, my >> 2); enc4(e, m, C_MODE_LO + (my >> 2), my & 3); }
+        if (valid) { enc4(e, m, C_MODE_HI + 1, muv >> 2); enc4(e, m, C_MODE_LO + 4 + (muv >> 2), muv & 3); }
       } else {
         int sk = 0, dx = 0, dy = 0;
         if (valid) {
           sk = L.skip[b] != 0;
           const int px = lbx ? L.mvs[(b - 1) * 2] : 0, py = lbx ? L.mvs[(b - 1) * 2 + 1] : 0;
           dx = (int16_t)(L.mvs[b * 2] - px); dy = (int16_t)(L.mvs[b * 2 + 1] - py);
-          enc_sym<2>(e, m, M_SKIP, sk);
+          enc4(e, m, C_SKIP, sk);
         }
-        code_mvd(e, m, M_MVC, valid, dx);
-        code_mvd(e, m, M_MVC + 17, valid, dy);
+        code_mvd(e, m, 0, valid, dx);
+        code_mvd(e, m, 1, valid, dy);
         coded = valid && !sk;
       }
-      code_block<64>(e, m, row, 0, 0, coded);
-      code_block<16>(e, m, row, 64, 1, coded);
-      code_block<16>(e, m, row, 80, 1, coded);
+#pragma unroll 1
+      for (int p = 0; p < 3; p++) code_block(e, m, row, p == 0 ? 0 : 48 + p * 16, p != 0, p == 0 ? 64 : 16, coded);
     }
   if (live) {
-    if (e.held >= 0) raw_out(e, e.held);
-    for (; e.ff; e.ff--) raw_out(e, 0xFF);
-    int bits = 16 + e.pend;
+    if (e.low >> (16 + e.pend)) { ripple(e); e.low &= ((uint64_t)1 << (16 + e.pend)) - 1; }   // a carry still riding on top
+    uint32_t nbytes = e.n * 4;
+    uint8_t *tail = (uint8_t *)e.out;
+    int bits = 16 + e.pend;                    // <= 47
     while (bits > 0) {
       const int take = bits >= 8 ? 8 : bits;
-      raw_out(e, (int)(((e.low >> (bits - take)) << (8 - take)) & 0xFF));
+      if (nbytes < L.slot_bytes) tail[nbytes] = (uint8_t)(((e.low >> (bits - take)) << (8 - take)) & 0xFF);
+      nbytes++;
       bits -= take;
     }
-    L.sizes[g] = e.n;     // > slot_bytes would mean the (proven) bound failed: k_ent_frames turns it into an error
+    L.sizes[g] = nbytes;     // > slot_bytes would mean the (proven) bound failed: k_ent_layout turns it into an error
   }
 }
 

@@ -9,77 +9,63 @@
 namespace av1mi_host {
 
 static inline int msb32(uint32_t v) { return 31 - __builtin_clz(v); }
-static inline int tile_log2(int t) { return msb32((uint32_t)t); }
-
-void cdf_init_uniform(uint16_t *cdf, int n) {
-  for (int i = 0; i < n; i++) cdf[i] = (uint16_t)(((i + 1) * 32768) / n);
-  cdf[n] = 0;
-}
-void cdf_adapt(uint16_t *cdf, int s, int N) {   // spec §8.2.6, N symbols, cdf[N] = adaptation counter
-  const int rate = 3 + (cdf[N] > 15) + (cdf[N] > 31) + (msb32((uint32_t)N) < 2 ? msb32((uint32_t)N) : 2);
-  int tmp = 0;
-  for (int i = 0; i < N - 1; i++) {
-    tmp = (i == s) ? (1 << 15) : tmp;
-    if (tmp < cdf[i]) cdf[i] -= (uint16_t)((cdf[i] - tmp) >> rate);
-    else cdf[i] += (uint16_t)((tmp - cdf[i]) >> rate);
-  }
-  cdf[N] += cdf[N] < 32;
-}
-// spec §8.2.6 interval partition: lower end of symbol s in "value" space (symbol 0 sits at the top of the range)
-static inline uint32_t lower_end(uint32_t rng, const uint16_t *cdf, int s, int N) {
-  const uint32_t f = (1u << 15) - cdf[s];
-  return (((rng >> 8) * (f >> 6)) >> 1) + 4u * (uint32_t)(N - s - 1);
-}
 
 EntropyModels::EntropyModels() {
   static_assert(sizeof(EntropyModels) == sizeof(kEntropyInit), "entropy_init.hpp is out of step with EntropyModels");
   memcpy((void *)this, kEntropyInit, sizeof(*this));
 }
 void EntropyModels::set_uniform() {
-  for (int p = 0; p < 2; p++) {
-    cdf_init_uniform(eob[p], 8); cdf_init_uniform(gol[p], 16); cdf_init_uniform(mode[p], 13); cdf_init_uniform(mvc[p], 16);
-    for (int b = 0; b < 4; b++) for (int c = 0; c < 3; c++) cdf_init_uniform(tok[p][b][c], 4);
+  for (Cdf4 &c : cdf) { c.c[0] = 8192; c.c[1] = 16384; c.c[2] = 24576; c.count = 0; }
+}
+void cdf_adapt(Cdf4 &cdf, int s) {   // spec §8.2.6 with N = 4
+  const int rate = 5 + (cdf.count > 15) + (cdf.count > 31);
+  for (int i = 0; i < 3; i++) {
+    if (i >= s) cdf.c[i] += (uint16_t)((32768 - cdf.c[i]) >> rate);
+    else cdf.c[i] -= (uint16_t)(cdf.c[i] >> rate);
   }
-  cdf_init_uniform(skip, 2);
+  cdf.count += cdf.count < 32;
+}
+// spec §8.2.6 interval partition: lower end of symbol s in "value" space (symbol 0 sits at the top of the range)
+static inline uint32_t lower_end(uint32_t rng, const Cdf4 &cdf, int s) {
+  const uint32_t f = 32768u - (s < 3 ? cdf.c[s] : 32768u);
+  return (((rng >> 8) * (f >> 6)) >> 1) + 4u * (uint32_t)(3 - s);
 }
 
 // ------------------------------------------------------------------------------------------------ encoder
-void RangeEncoder::put_byte_with_carry() {
-  for (size_t i = out.size(); i-- > 0;)
-    if (++out[i] != 0) break;
+void RangeEncoder::add(uint64_t v) {
+  low += v;
+  if (low >> (16 + pending)) {          // carry into the bytes already written
+    for (size_t i = out.size(); i-- > 0;) if (++out[i] != 0) break;
+    low &= ((uint64_t)1 << (16 + pending)) - 1;
+  }
 }
 void RangeEncoder::normalize() {
   const int d = 15 - msb32(rng);
   rng <<= d; low <<= d; pending += d;
   while (pending >= 8) {
-    out.push_back((uint8_t)((low >> (16 + pending - 8)) & 0xFF));
     pending -= 8;
+    out.push_back((uint8_t)((low >> (16 + pending)) & 0xFF));
     low &= ((uint64_t)1 << (16 + pending)) - 1;
   }
 }
-void RangeEncoder::encode(int s, uint16_t *cdf, int N) {
-  const uint32_t hi = s ? lower_end(rng, cdf, s - 1, N) : rng, lo = lower_end(rng, cdf, s, N);
-  low += lo;
-  if (low >> (16 + pending)) { put_byte_with_carry(); low &= ((uint64_t)1 << (16 + pending)) - 1; }
+void RangeEncoder::encode(int s, Cdf4 &cdf) {
+  const uint32_t hi = s ? lower_end(rng, cdf, s - 1) : rng, lo = lower_end(rng, cdf, s);
+  add(lo);
   rng = hi - lo;
   normalize();
-  cdf_adapt(cdf, s, N);
+  cdf_adapt(cdf, s);
 }
 void RangeEncoder::encode_bits(unsigned v, int nbits) {
-  // up to 8 equiprobable bits per step: the range is cut into 2^n slots of rng >> n (the top slot keeps the remainder);
-  // chunk value c takes slot 2^n - 1 - c counted from the bottom, which for n = 1 is the plain half/half bool
   while (nbits > 0) {
     const int n = nbits > 8 ? 8 : nbits;
     nbits -= n;
     const uint32_t top = (1u << n) - 1, j = top - ((v >> nbits) & top), r = rng >> n;
-    low += (uint64_t)r * j;
-    if (low >> (16 + pending)) { put_byte_with_carry(); low &= ((uint64_t)1 << (16 + pending)) - 1; }
+    add((uint64_t)r * j);
     rng = j == top ? rng - r * j : r;
     normalize();
   }
 }
-void RangeEncoder::finish() {
-  // any value in [low, low + rng) decodes; emit `low` itself, padded with zero bits
+void RangeEncoder::finish() {   // any value in [low, low + rng) decodes; emit `low` itself, padded with zero bits
   int bits = 16 + pending;
   while (bits > 0) {
     const int take = bits >= 8 ? 8 : bits;
@@ -93,18 +79,17 @@ void RangeDecoder::init(const uint8_t *p, size_t n) { buf = p; len = n; pos = 0;
 void RangeDecoder::refill() {
   while (avail <= 40) { code = (code << 8) | (pos < len ? buf[pos] : 0); pos++; avail += 8; }
 }
-int RangeDecoder::decode(uint16_t *cdf, int N) {
+int RangeDecoder::decode(Cdf4 &cdf) {
   if (avail < 16) refill();
   const uint32_t value = (uint32_t)(code >> avail);
   uint32_t cur = rng, prev;
   int s = -1;
-  do { s++; prev = cur; cur = lower_end(rng, cdf, s, N); } while (value < cur && s < N - 1);
-  if (value < cur) { cur = 0; }   // corrupt stream guard: the last symbol always reaches down to 0
+  do { s++; prev = cur; cur = lower_end(rng, cdf, s); } while (value < cur && s < 3);
   code -= (uint64_t)cur << avail;
   rng = prev - cur;
   const int d = 15 - msb32(rng);
   rng <<= d; avail -= d;
-  cdf_adapt(cdf, s, N);
+  cdf_adapt(cdf, s);
   return s;
 }
 unsigned RangeDecoder::decode_bits(int nbits) {
@@ -149,38 +134,33 @@ using Models = EntropyModels;
 inline int eob_class(int e) { return e <= 2 ? e : 1 + (32 - __builtin_clz((unsigned)(e - 1))); }   // 3-4:3 5-8:4 9-16:5 17-32:6 33-64:7
 inline int band_of(int i) { return i == 0 ? 0 : i <= 4 ? 1 : i <= 15 ? 2 : 3; }
 
-void put_golomb(RangeEncoder &e, uint16_t *cdf, unsigned r) {   // r >= 0: length class of r + 1, then the mantissa bits
-  const unsigned x = r + 1; const int k = 31 - __builtin_clz(x);
-  e.encode(k > 15 ? 15 : k, cdf, 16);
-  if (k >= 15) e.encode_bits(x, 32); else if (k) e.encode_bits(x & ((1u << k) - 1), k);
-}
-unsigned get_golomb(RangeDecoder &d, uint16_t *cdf) {
-  const int k = d.decode(cdf, 16);
-  if (k >= 15) return d.decode_bits(32) - 1;
-  return ((1u << k) | (k ? d.decode_bits(k) : 0)) - 1;
-}
-// one transform block: eob, then ALL tokens, then the remainders of the escaped tokens, then the signs packed 8 per raw
-// symbol — grouped by kind (not interleaved per coefficient) so that a SIMD coder with one tile per lane spends its steps on
-// the common symbol kind and touches the rare ones in short loops (csrc/entropy_kernels.hip)
+// a value 0..15 as two 4-ary symbols, the low one conditioned on the high one
+inline void put_pair(RangeEncoder &e, Models &m, int hi_id, int lo_id, int v) { e.encode(v >> 2, m.cdf[hi_id]); e.encode(v & 3, m.cdf[lo_id + (v >> 2)]); }
+inline int get_pair(RangeDecoder &d, Models &m, int hi_id, int lo_id) { const int hi = d.decode(m.cdf[hi_id]); return hi * 4 + d.decode(m.cdf[lo_id + hi]); }
+
 void put_block(RangeEncoder &e, Models &m, int pt, const int16_t *lv, int n, const uint8_t *scan) {
   int eob = 0;
   for (int i = 0; i < n; i++) if (lv[scan[i]]) eob = i + 1;
   const int c = eob_class(eob);
-  e.encode(c, m.eob[pt], 8);
+  e.encode(c >> 2, m.cdf[CDF_EOB_HI + pt]); e.encode(c & 3, m.cdf[CDF_EOB_LO + pt * 2 + (c >> 2)]);
   if (c >= 3) e.encode_bits((unsigned)(eob - ((1 << (c - 2)) + 1)), c - 2);
   int prev = 0, nnz = 0;
   uint64_t signs = 0;
   for (int i = 0; i < eob; i++) {
     const int l = lv[scan[i]], a = l < 0 ? -l : l, t = a < 3 ? a : 3;
-    e.encode(t, m.tok[pt][band_of(i)][prev], 4);
+    e.encode(t, m.cdf[CDF_TOK + (pt * 4 + band_of(i)) * 3 + prev]);
     if (a) { signs = (signs << 1) | (uint64_t)(l < 0); nnz++; }
     prev = t < 2 ? t : 2;
   }
   for (int i = 0; i < eob; i++) {
     const int l = lv[scan[i]], a = l < 0 ? -l : l;
-    if (a >= 3) put_golomb(e, m.gol[pt], (unsigned)(a - 3));
+    if (a < 3) continue;
+    const unsigned x = (unsigned)(a - 2);
+    const int k = msb32(x);                                  // 0..14
+    for (int j = 0, r = k;; j++, r -= 3) { const int s = r < 3 ? r : 3; e.encode(s, m.cdf[CDF_GOL + pt * 5 + j]); if (s < 3) break; }
+    if (k) e.encode_bits(x & ((1u << k) - 1), k);
   }
-  while (nnz > 0) {                      // first symbol first, most significant bit of every chunk
+  while (nnz > 0) {
     const int k = nnz > 8 ? 8 : nnz;
     nnz -= k;
     e.encode_bits((unsigned)((signs >> nnz) & 0xFF), k);
@@ -188,19 +168,26 @@ void put_block(RangeEncoder &e, Models &m, int pt, const int16_t *lv, int n, con
 }
 bool get_block(RangeDecoder &d, Models &m, int pt, int16_t *lv, int n, const uint8_t *scan) {
   memset(lv, 0, sizeof(int16_t) * n);
-  const int c = d.decode(m.eob[pt], 8);
+  const int chi = d.decode(m.cdf[CDF_EOB_HI + pt]), c = chi * 4 + d.decode(m.cdf[CDF_EOB_LO + pt * 2 + (chi & 1)]);
+  if (chi > 1) return false;
   int eob = c;
   if (c >= 3) eob = (1 << (c - 2)) + 1 + (int)d.decode_bits(c - 2);
   if (eob > n) return false;
   int mag[64], prev = 0, nnz = 0;
   for (int i = 0; i < eob; i++) {
-    const int t = d.decode(m.tok[pt][band_of(i)][prev], 4);
+    const int t = d.decode(m.cdf[CDF_TOK + (pt * 4 + band_of(i)) * 3 + prev]);
     mag[i] = t;
     nnz += t != 0;
     prev = t < 2 ? t : 2;
   }
-  for (int i = 0; i < eob; i++)
-    if (mag[i] == 3) { mag[i] = 3 + (int)get_golomb(d, m.gol[pt]); if (mag[i] > 32768) return false; }
+  for (int i = 0; i < eob; i++) {
+    if (mag[i] != 3) continue;
+    int k = 0;
+    for (int j = 0;; j++) { const int s = d.decode(m.cdf[CDF_GOL + pt * 5 + j]); k += s; if (s < 3) break; if (j == 4) return false; }
+    if (k > 14) return false;
+    mag[i] = 2 + (int)((1u << k) | (k ? d.decode_bits(k) : 0));
+    if (mag[i] > 32768) return false;
+  }
   int i = 0;
   while (nnz > 0) {
     const int k = nnz > 8 ? 8 : nnz;
@@ -215,19 +202,16 @@ bool get_block(RangeDecoder &d, Models &m, int pt, int16_t *lv, int n, const uin
   }
   return true;
 }
-// vector difference component: class = bit length of |v| capped at 15 (16-ary: the partition's minimum-probability
-// term 4 * (N - 1) needs N <= 16 to leave symbol 0 a non-empty interval, as in AV1), then the bits below the leading one;
-// class 15 carries |v| - 16384 in 15 bits (|v| <= 32768)
-void put_mv_comp(RangeEncoder &e, uint16_t *cdf, int v) {
+void put_mv_comp(RangeEncoder &e, Models &m, int comp, int v) {
   const unsigned a = (unsigned)(v < 0 ? -v : v); int k = a ? 32 - __builtin_clz(a) : 0;
   if (k > 15) k = 15;
-  e.encode(k, cdf, 16);
+  put_pair(e, m, CDF_MV_HI + comp, CDF_MV_LO + comp * 4, k);
   if (k == 15) e.encode_bits(a - 16384, 15);
   else if (k > 1) e.encode_bits(a & ((1u << (k - 1)) - 1), k - 1);
   if (a) e.encode_bits(v < 0, 1);
 }
-int get_mv_comp(RangeDecoder &d, uint16_t *cdf) {
-  const int k = d.decode(cdf, 16);
+int get_mv_comp(RangeDecoder &d, Models &m, int comp) {
+  const int k = get_pair(d, m, CDF_MV_HI + comp, CDF_MV_LO + comp * 4);
   if (!k) return 0;
   const unsigned a = k == 15 ? 16384 + d.decode_bits(15) : (1u << (k - 1)) | (k > 1 ? d.decode_bits(k - 1) : 0);
   return d.decode_bits(1) ? -(int)a : (int)a;
@@ -235,7 +219,6 @@ int get_mv_comp(RangeDecoder &d, uint16_t *cdf) {
 
 }  // namespace
 
-// tile (tx, ty) of the frame: blocks in raster order inside the tile, fresh models, fresh coder
 void entropy_encode_tile(const FrameSyms &f, int tx, int ty, RangeEncoder &e, EntropyModels *final_models) {
   Models m;
   const Scan &sc = scans();
@@ -246,14 +229,14 @@ void entropy_encode_tile(const FrameSyms &f, int tx, int ty, RangeEncoder &e, En
       const int b = by * bw + bx;
       bool coded = true;
       if (f.key) {
-        e.encode(f.modes_y[b] < 13 ? f.modes_y[b] : 0, m.mode[0], 13);
-        e.encode(f.modes_uv[b] < 13 ? f.modes_uv[b] : 0, m.mode[1], 13);
+        put_pair(e, m, CDF_MODE_HI, CDF_MODE_LO, f.modes_y[b] < 13 ? f.modes_y[b] : 0);
+        put_pair(e, m, CDF_MODE_HI + 1, CDF_MODE_LO + 4, f.modes_uv[b] < 13 ? f.modes_uv[b] : 0);
       } else {
         const int sk = f.skip[b] != 0;
-        e.encode(sk, m.skip, 2);
+        e.encode(sk, m.cdf[CDF_SKIP]);
         const int px = bx > bx0 ? f.mvs[(b - 1) * 2] : 0, py = bx > bx0 ? f.mvs[(b - 1) * 2 + 1] : 0;   // left neighbour inside the tile predicts
-        put_mv_comp(e, m.mvc[0], (int16_t)(f.mvs[b * 2] - px));       // differences wrap modulo 2^16
-        put_mv_comp(e, m.mvc[1], (int16_t)(f.mvs[b * 2 + 1] - py));
+        put_mv_comp(e, m, 0, (int16_t)(f.mvs[b * 2] - px));         // differences wrap modulo 2^16
+        put_mv_comp(e, m, 1, (int16_t)(f.mvs[b * 2 + 1] - py));
         coded = !sk;
       }
       if (coded) {
@@ -273,7 +256,7 @@ std::vector<uint8_t> entropy_assemble_frame(int tile, const std::vector<const ui
   size_t tot = 0;
   for (size_t n : sizes) tot += n;
   o.reserve(tot + sizes.size() * 3 + 1);
-  o.push_back((uint8_t)tile_log2(tile));
+  o.push_back((uint8_t)msb32((uint32_t)tile));
   for (size_t n : sizes) put_varint(o, n);
   for (size_t i = 0; i < sizes.size(); i++) o.insert(o.end(), tiles[i], tiles[i] + sizes[i]);
   return o;
@@ -321,13 +304,13 @@ bool entropy_decode_frame(const uint8_t *data, size_t n, int width, int height, 
           const int b = by * bw + bx;
           bool coded = true;
           if (key) {
-            modes_y[b] = (uint8_t)d.decode(m.mode[0], 13);
-            modes_uv[b] = (uint8_t)d.decode(m.mode[1], 13);
+            modes_y[b] = (uint8_t)get_pair(d, m, CDF_MODE_HI, CDF_MODE_LO);
+            modes_uv[b] = (uint8_t)get_pair(d, m, CDF_MODE_HI + 1, CDF_MODE_LO + 4);
           } else {
-            skip[b] = (uint8_t)d.decode(m.skip, 2);
+            skip[b] = (uint8_t)(d.decode(m.cdf[CDF_SKIP]) != 0);
             const int px = bx > bx0 ? mvs[(b - 1) * 2] : 0, py = bx > bx0 ? mvs[(b - 1) * 2 + 1] : 0;
-            mvs[b * 2] = (int16_t)(px + get_mv_comp(d, m.mvc[0]));
-            mvs[b * 2 + 1] = (int16_t)(py + get_mv_comp(d, m.mvc[1]));
+            mvs[b * 2] = (int16_t)(px + get_mv_comp(d, m, 0));
+            mvs[b * 2 + 1] = (int16_t)(py + get_mv_comp(d, m, 1));
             coded = !skip[b];
           }
           if (coded) {

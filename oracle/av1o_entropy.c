@@ -11,17 +11,19 @@
  * count of 0xFF bytes (no back-patching), explicit context arithmetic.  Both must produce identical bytes, and the decoder
  * in entropy.cpp must return the input symbols from this encoder's output.
  *
+ * Every adaptive symbol is 4-ary; a CDF is (c0, c1, c2, counter), 61 of them (ids below = enum in host/entropy.hpp).
  * Frame record: [log2(tile)] [varint size of every tile, raster order] [tile payloads].
  * Tile payload: blocks in raster order inside the tile; per block
- *   key frame:  mode_y (13-ary), mode_uv (13-ary)
- *   P frame:    skip (binary), mv.x and mv.y as differences to the left block of the same tile (wrapping int16):
- *               bit-length class capped at 15 (16-ary), the bits below the leading one (class 15: |d| - 16384 in 15 bits),
- *               sign (raw)
+ *   key frame:  mode_y, mode_uv, each as (m >> 2, m & 3), the second symbol's CDF chosen by the first
+ *   P frame:    skip; mv.x and mv.y as differences to the left block of the same tile (wrapping int16): class = bit length
+ *               of |d| capped at 15 as (k >> 2, k & 3), the bits below the leading one raw (class 15: |d| - 16384 in 15
+ *               bits), sign raw
  *   unless skipped, for Y 8x8 then U 4x4 then V 4x4 in zig-zag order:
- *               eob class (8-ary: 0,1,2,3-4,5-8,9-16,17-32,33-64) + offset bits (raw),
- *               then the token min(|l|,3) of every coefficient below eob (4-ary, context = plane type, band of position,
- *               min(previous token, 2)); then for every token 3, in the same order: bit-length class of |l|-2 (16-ary) +
- *               the bits below the leading one (raw); then the signs of the non-zero coefficients, 8 per raw symbol
+ *               eob class (0,1,2,3-4,5-8,9-16,17-32,33-64) as (c >> 2, c & 3) + offset bits (raw),
+ *               then the token min(|l|,3) of every coefficient below eob (context = plane type, band of position,
+ *               min(previous token, 2)); then for every token 3, in the same order: k = floor(log2(|l| - 2)) as the
+ *               chain min(k,3), min(k-3,3), ... stopped by the first symbol below 3 (CDF per chain position), then the k
+ *               bits below the leading one (raw); then the signs of the non-zero coefficients, 8 per raw symbol
  *               (first coefficient in the most significant bit, the last group holds what is left)
  * Raw bits are coded up to 8 at a time as one symbol over 2^n equal slots of (range >> n), value v in slot 2^n-1-v from the
  * bottom, the top slot taking the remainder.
@@ -64,21 +66,22 @@ static void add_low(enc_t *e, uint32_t v) {
   e->low += v;
   if (e->low >> (16 + e->pend)) { carry(e); e->low &= (1u << (16 + e->pend)) - 1; }
 }
-/* spec 8.2.6: symbol s of N owns [bound(s), bound(s-1)) with bound(-1) = rng */
-static uint32_t bound(uint32_t rng, const uint16_t *cdf, int s, int N) {
-  return ((rng >> 8) * ((32768u - cdf[s]) >> 6) >> 1) + 4u * (uint32_t)(N - 1 - s);
+/* spec 8.2.6 with N = 4: symbol s owns [bound(s), bound(s-1)) with bound(-1) = rng; cdf = (c0, c1, c2, counter) */
+static uint32_t bound(uint32_t rng, const uint16_t *cdf, int s) {
+  const uint32_t c = s < 3 ? cdf[s] : 32768u;
+  return ((rng >> 8) * ((32768u - c) >> 6) >> 1) + 4u * (uint32_t)(3 - s);
 }
-static void put_sym(enc_t *e, uint16_t *cdf, int s, int N) {
-  const uint32_t top = s ? bound(e->rng, cdf, s - 1, N) : e->rng, bot = bound(e->rng, cdf, s, N);
-  int i, rate = 3 + (cdf[N] > 15) + (cdf[N] > 31) + (N >= 4 ? 2 : N >= 2 ? 1 : 0);
+static void put_sym(enc_t *e, uint16_t *cdf, int s) {
+  const uint32_t top = s ? bound(e->rng, cdf, s - 1) : e->rng, bot = bound(e->rng, cdf, s);
+  int i, rate = 3 + (cdf[3] > 15) + (cdf[3] > 31) + 2;
   add_low(e, bot);
   e->rng = top - bot;
   renorm(e);
-  for (i = 0; i < N - 1; i++) {
+  for (i = 0; i < 3; i++) {
     if (i >= s) cdf[i] += (uint16_t)((32768 - cdf[i]) >> rate);
     else cdf[i] -= (uint16_t)(cdf[i] >> rate);
   }
-  if (cdf[N] < 32) cdf[N]++;
+  if (cdf[3] < 32) cdf[3]++;
 }
 static void put_raw(enc_t *e, uint32_t v, int nbits) {
   while (nbits > 0) {
@@ -103,8 +106,9 @@ static size_t finish(enc_t *e) {
   return e->n;
 }
 
-/* model offsets inside kEntropyInit (uint16 words): eob[2][9] tok[2][4][3][5] gol[2][17] mode[2][14] skip[3] mvc[2][17] */
-enum { M_EOB = 0, M_TOK = 18, M_GOL = 138, M_MODE = 172, M_SKIP = 200, M_MVC = 203, M_WORDS = 237 };
+/* CDF ids (x4 = word offset inside kEntropyInit), same enum as av1-go_amd/host/entropy.hpp */
+enum { C_TOK = 0, C_GOL = 24, C_EOB_HI = 34, C_EOB_LO = 36, C_MODE_HI = 40, C_MODE_LO = 42, C_SKIP = 50, C_MV_HI = 51, C_MV_LO = 53, C_COUNT = 61 };
+#define CDF(m, id) ((m) + 4 * (id))
 
 static int bitlen(uint32_t v) { int n = 0; while (v) { n++; v >>= 1; } return n; }
 
@@ -121,11 +125,12 @@ static void put_coeffs(enc_t *e, uint16_t *m, int pt, const int16_t *lv, int n, 
   uint8_t sign[64];
   for (i = 0; i < n; i++) if (lv[scan[i]]) eob = i + 1;
   cls = eob <= 2 ? eob : 1 + bitlen((uint32_t)(eob - 1));
-  put_sym(e, m + M_EOB + pt * 9, cls, 8);
+  put_sym(e, CDF(m, C_EOB_HI + pt), cls >> 2);
+  put_sym(e, CDF(m, C_EOB_LO + pt * 2 + (cls >> 2)), cls & 3);
   if (cls >= 3) put_raw(e, (uint32_t)(eob - (1 << (cls - 2)) - 1), cls - 2);
   for (i = 0; i < eob; i++) {                                        /* 1: every token */
     const int l = lv[scan[i]], a = l < 0 ? -l : l, t = a < 3 ? a : 3, band = i == 0 ? 0 : i <= 4 ? 1 : i <= 15 ? 2 : 3;
-    put_sym(e, m + M_TOK + ((pt * 4 + band) * 3 + prev) * 5, t, 4);
+    put_sym(e, CDF(m, C_TOK + (pt * 4 + band) * 3 + prev), t);
     if (a) sign[nnz++] = l < 0;
     prev = t < 2 ? t : 2;
   }
@@ -134,7 +139,13 @@ static void put_coeffs(enc_t *e, uint16_t *m, int pt, const int16_t *lv, int n, 
     if (a >= 3) {
       const uint32_t x = (uint32_t)(a - 2);
       const int k = bitlen(x) - 1;              /* a <= 32768 so k <= 14 */
-      put_sym(e, m + M_GOL + pt * 17, k, 16);
+      int j, rest = k;
+      for (j = 0; j < 5; j++) {
+        const int sy = rest < 3 ? rest : 3;
+        put_sym(e, CDF(m, C_GOL + pt * 5 + j), sy);
+        if (sy < 3) break;
+        rest -= 3;
+      }
       if (k) put_raw(e, x & ((1u << k) - 1), k);
     }
   }
@@ -147,21 +158,26 @@ static void put_coeffs(enc_t *e, uint16_t *m, int pt, const int16_t *lv, int n, 
     i += k;
   }
 }
-static void put_mvd(enc_t *e, uint16_t *cdf, int v) {
+static void put_mvd(enc_t *e, uint16_t *m, int comp, int v) {
   const uint32_t a = (uint32_t)(v < 0 ? -v : v);
   int k = bitlen(a);
-  if (k > 15) k = 15;                 /* N <= 16 keeps 4 * (N - 1) below the smallest interval symbol 0 can be left with */
-  put_sym(e, cdf, k, 16);
+  if (k > 15) k = 15;
+  put_sym(e, CDF(m, C_MV_HI + comp), k >> 2);
+  put_sym(e, CDF(m, C_MV_LO + comp * 4 + (k >> 2)), k & 3);
   if (k == 15) put_raw(e, a - 16384, 15);
   else if (k > 1) put_raw(e, a & ((1u << (k - 1)) - 1), k - 1);
   if (a) put_raw(e, v < 0, 1);
+}
+static void put_mode(enc_t *e, uint16_t *m, int which, int mode) {
+  put_sym(e, CDF(m, C_MODE_HI + which), mode >> 2);
+  put_sym(e, CDF(m, C_MODE_LO + which * 4 + (mode >> 2)), mode & 3);
 }
 
 /* one tile's payload; returns its size, or (size_t)-1 when cap is too small */
 size_t av1o_entropy_encode_tile(int w, int h, int key, int tile, int tx, int ty, const int16_t *lev_y, const int16_t *lev_u,
                                 const int16_t *lev_v, const uint8_t *modes_y, const uint8_t *modes_uv, const int16_t *mvs,
                                 const uint8_t *skip, uint8_t *out, size_t cap) {
-  uint16_t m[M_WORDS];
+  uint16_t m[C_COUNT * 4];
   uint8_t s8[64], s4[16];
   enc_t e;
   const int bw = w / 8, bh = h / 8, tb = tile / 8;
@@ -177,13 +193,13 @@ size_t av1o_entropy_encode_tile(int w, int h, int key, int tile, int tx, int ty,
       const int b = by * bw + bx;
       int coded = 1;
       if (key) {
-        put_sym(&e, m + M_MODE, modes_y[b] < 13 ? modes_y[b] : 0, 13);
-        put_sym(&e, m + M_MODE + 14, modes_uv[b] < 13 ? modes_uv[b] : 0, 13);
+        put_mode(&e, m, 0, modes_y[b] < 13 ? modes_y[b] : 0);
+        put_mode(&e, m, 1, modes_uv[b] < 13 ? modes_uv[b] : 0);
       } else {
         const int px = bx > bx0 ? mvs[(b - 1) * 2] : 0, py = bx > bx0 ? mvs[(b - 1) * 2 + 1] : 0;
-        put_sym(&e, m + M_SKIP, skip[b] != 0, 2);
-        put_mvd(&e, m + M_MVC, (int16_t)(mvs[b * 2] - px));
-        put_mvd(&e, m + M_MVC + 17, (int16_t)(mvs[b * 2 + 1] - py));
+        put_sym(&e, CDF(m, C_SKIP), skip[b] != 0);
+        put_mvd(&e, m, 0, (int16_t)(mvs[b * 2] - px));
+        put_mvd(&e, m, 1, (int16_t)(mvs[b * 2 + 1] - py));
         coded = !skip[b];
       }
       if (coded) {
