@@ -75,7 +75,7 @@ class EntropyJob(C.Structure):
                 ("d_out", C.c_void_p), ("out_cap", C.c_size_t), ("d_frame_off", C.c_void_p)]
 
 
-N_KERNEL_KINDS = 14   # enum av1mi_kernel_kind
+N_KERNEL_KINDS = 15   # enum av1mi_kernel_kind
 _lib = None
 
 
@@ -337,6 +337,12 @@ class Context:
     # ---- K9
     def entropy_encode(self, job):
         self._chk(self.lib.av1mi_entropy_encode(self.h, C.byref(job)))
+
+    def entropy_encode_async(self, job, slot):
+        self._chk(self.lib.av1mi_entropy_encode_async(self.h, C.byref(job), slot))
+
+    def entropy_wait(self, slot):
+        self._chk(self.lib.av1mi_entropy_wait(self.h, slot))
 
     def entropy_encode_arrays(self, w, h, key, tile, lev_y, lev_u, lev_v, modes_y=None, modes_uv=None, mvs=None, skip=None, out_cap=None):
         """tests: arrays with a leading frame axis; returns the list of frame records (bytes)"""

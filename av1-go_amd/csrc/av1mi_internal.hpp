@@ -90,6 +90,8 @@ hipError_t launch_dequantize(const int16_t *levels, int32_t *dqcoef, long long n
 struct EntropyLaunch {
   const int16_t *lev[3]; const uint8_t *modes_y, *modes_uv; const int16_t *mvs; const uint8_t *skip;
   int w, h, nframes, key, tile;
+  uint16_t *ops; uint32_t ops_per_tile;       // scratch: one op list per tile (k_ent_tokens -> k_ent_code)
+  uint32_t *nops;                             // scratch: ops per tile
   uint8_t *slots; uint32_t slot_bytes;        // scratch: one payload slot per tile
   uint32_t *sizes, *hdr_off, *pay_off;        // scratch: per tile
   uint32_t *frame_hdr; uint64_t *frame_size;  // scratch: per frame
@@ -97,6 +99,8 @@ struct EntropyLaunch {
   uint8_t *out; uint64_t out_cap; uint64_t *frame_off;
 };
 hipError_t entropy_init_tables();
+size_t entropy_ops_per_tile(int tile);
+hipError_t launch_entropy_tokens(const EntropyLaunch &L, hipStream_t s);
 hipError_t launch_entropy_code(const EntropyLaunch &L, hipStream_t s);
 hipError_t launch_entropy_pack(const EntropyLaunch &L, hipStream_t s);
 

@@ -2,23 +2,28 @@
 // §7 / §8e name as the scaling risk: "host entropy coding throughput … needs on-GPU compaction").
 //
 // A range coder is serial in its state, so the parallel axis is the TILE: every entropy tile (32/64/128 luma samples
-// square) has its own coder and its own adaptive CDFs, and one LANE codes one tile — a wave codes 64 tiles in lockstep,
-// a 48-frame 1080p batch is 24 480 tiles (32: 97 920).  What makes lockstep cheap is the syntax (host/entropy.hpp,
-// oracle/av1o_entropy.c): symbols are grouped by kind inside a transform block (eob, all tokens, the escapes, packed
-// signs), so all lanes of a wave are at the SAME kind of symbol with a compile-time alphabet size: the CDF update is a
-// fully unrolled LDS read-modify-write per lane with no divergence on N, and the rare kinds run in short loops.
+// square) has its own coder and its own adaptive CDFs (syntax: host/entropy.hpp, oracle/av1o_entropy.c).  The work is
+// split where its nature changes:
 //
-//   k_ent_code    lane = tile.  Models: 61 CDFs x 8 bytes per lane in LDS, every adaptive symbol is 4-ary: one b64 load + store.
-//                 The current block's 96 levels + its escape list sit in a lane-private LDS row (odd dword stride).
-//                 Bits leave 32 at a time as big-endian words (a late carry ripples back through the lane's own words)
-//                 into the tile's private slot of 6 bytes per coefficient (a bound: <= 43 bits per coefficient + block headers).
+//   k_ent_tokens  PARALLEL part, one thread per 8x8 block: reads the block's levels (+ modes / vectors), walks it in scan
+//                 order and writes the block's symbols as 16-bit OPS into the tile's op list (count pass, workgroup scan
+//                 for the block's offset, emit pass).  An op is either "adaptive 4-ary symbol s with CDF id" or "n raw
+//                 bits of value v" — all syntax knowledge (contexts, chains, escapes, sign packing) ends here.
+//   k_ent_code    SERIAL part, one LANE per tile: a wave runs 64 independent range coders in lockstep over their op
+//                 lists — one uniform loop, no divergence on the kind of symbol: both interval formulas are evaluated and
+//                 selected, the CDF (three 15-bit values + counter = 8 bytes, 61 per lane in LDS) is updated with one
+//                 64-bit load and store.  Trip count = the longest op list of the wave (tiles of one frame are within a
+//                 few % of each other), not the sum of per-block maxima a block-synchronous design pays.
+//                 Bits leave 32 at a time as big-endian words into the tile's private slot (6 bytes per coefficient: a
+//                 bound); a carry is resolved when the word leaves and ripples back through the lane's own words.
 //   k_ent_layout  per frame: scan of the tile sizes -> header (varint) and payload offsets inside the frame record.
 //   k_ent_frames  scan over frames -> record offsets, capacity check.
 //   k_ent_pack    per tile: varint + payload copied to its place: the host receives one contiguous stream.
 //
 // Arithmetic: AV1 spec §8.2.6 interval partition + CDF adaptation (restated in oracle/av1o_entropy.c, byte-exact parity);
-// initial CDFs: host/entropy_init.hpp (own constants).  HBM traffic: 2 B per coefficient in, <1 B out — the kernel is
-// bound by the serial dependency chain of the coder (issue latency of one wave per SIMD), not by bandwidth.
+// initial CDFs: host/entropy_init.hpp (own constants).  HBM traffic: 2 B per coefficient in, 2 B per op out and in again,
+// <1 B per coefficient out — k_ent_code is bound by the serial dependency chain of the coder (one wave per SIMD issues an
+// instruction every ~5 cycles), not by bandwidth: what counts is instructions per op and ops per tile.
 #include "av1mi_internal.hpp"
 #include "../host/entropy_init.hpp"
 #include <utility>
@@ -30,7 +35,6 @@ namespace {
 // CDF ids: same enum as host/entropy.hpp; one CDF = (c0, c1, c2, counter) = 8 bytes
 enum { C_TOK = 0, C_GOL = 24, C_EOB_HI = 34, C_EOB_LO = 36, C_MODE_HI = 40, C_MODE_LO = 42, C_SKIP = 50, C_MV_HI = 51, C_MV_LO = 53, C_COUNT = 61 };
 static_assert(sizeof(kEntropyInit) == C_COUNT * 8, "entropy_init.hpp layout");
-constexpr int ROW = 162;   // int16 per lane row: 96 levels (Y 64, U 16, V 16) + 64 escapes + 2 pad = 81 dwords (odd)
 
 __constant__ uint2 kInit[C_COUNT];   // filled once per context from kEntropyInit
 // zig-zag scan position of raster index r in an n x n block (compile time): the block is staged into the lane's LDS row
@@ -51,6 +55,143 @@ template <int N, int... I> __device__ inline void stage_scan(int16_t *dst, const
   ((dst[ZZ<N, 2 * I>::pos] = (int16_t)(dw[I] & 0xFFFF), dst[ZZ<N, 2 * I + 1>::pos] = (int16_t)(dw[I] >> 16)), ...);
 }
 
+// ------------------------------------------------------------------------------------------------ ops
+// adaptive: id << 8 | sym (bit 15 clear, id <= 60)
+// raw:      0x8000 | nbits << 8 | j, j = 2^nbits - 1 - value = the slot from the bottom (nbits 1..8), 0x4000 set for the top slot
+constexpr uint32_t OP_RAW = 0x8000, OP_TOPSLOT = 0x4000;
+constexpr int OPS_PER_BLOCK = 800;   // bound: Y 3 + 64 + 64 * 7 + 8, U/V 2 * (3 + 16 + 16 * 7 + 2), header <= 11
+
+struct Emit { uint16_t *p; uint32_t n; };
+template <bool WRITE> __device__ inline void put(Emit &E, uint32_t op) { if (WRITE) E.p[E.n] = (uint16_t)op; E.n++; }
+template <bool WRITE> __device__ inline void put_sym(Emit &E, int id, int s) { put<WRITE>(E, (uint32_t)(id << 8 | s)); }
+// up to 16 raw bits, the most significant chunk of <= 8 first (entropy.hpp "raw bits")
+template <bool WRITE> __device__ inline void put_chunk(Emit &E, int n, uint32_t v) {   // n = 1..8 bits
+  const uint32_t slots = (1u << n) - 1, j = slots - (v & slots);
+  put<WRITE>(E, OP_RAW | (j == slots ? OP_TOPSLOT : 0u) | (uint32_t)n << 8 | j);
+}
+template <bool WRITE> __device__ inline void put_raw(Emit &E, int nbits, uint32_t v) {
+  if (nbits > 8) { put_chunk<WRITE>(E, 8, v >> (nbits - 8)); nbits -= 8; }
+  if (nbits > 0) put_chunk<WRITE>(E, nbits, v);
+}
+template <bool WRITE> __device__ inline void put_pair(Emit &E, int hi_id, int lo_id, int v) { put_sym<WRITE>(E, hi_id, v >> 2); put_sym<WRITE>(E, lo_id + (v >> 2), v & 3); }
+
+// one transform block, levels in scan order at row[0..n)
+template <bool WRITE> __device__ inline void block_ops(Emit &E, const int16_t *row, int n, int pt) {
+  int eob = 0;
+  for (int i = 0; i < n; i++) eob = row[i] != 0 ? i + 1 : eob;
+  const int cls = eob <= 2 ? eob : 33 - __clz(eob - 1);
+  put_pair<WRITE>(E, C_EOB_HI + pt, C_EOB_LO + pt * 2, cls);
+  if (cls >= 3) put_raw<WRITE>(E, cls - 2, (uint32_t)(eob - (1 << (cls - 2)) - 1));
+  int prev = 0, nnz = 0;
+  uint64_t signs = 0;
+  for (int i = 0; i < eob; i++) {
+    const int l = row[i], a = l < 0 ? -l : l, t = a < 3 ? a : 3, band = i == 0 ? 0 : i <= 4 ? 1 : i <= 15 ? 2 : 3;
+    put_sym<WRITE>(E, C_TOK + (pt * 4 + band) * 3 + prev, t);
+    if (a) { signs = (signs << 1) | (uint64_t)(l < 0); nnz++; }
+    prev = t < 2 ? t : 2;
+  }
+  for (int i = 0; i < eob; i++) {
+    const int l = row[i], a = l < 0 ? -l : l;
+    if (a < 3) continue;
+    const uint32_t x = (uint32_t)(a - 2);
+    const int k = 31 - __clz((int)x);
+    for (int j = 0, rest = k;; j++, rest -= 3) { const int sy = rest < 3 ? rest : 3; put_sym<WRITE>(E, C_GOL + pt * 5 + j, sy); if (sy < 3) break; }
+    put_raw<WRITE>(E, k, x & ((1u << k) - 1));
+  }
+  while (nnz > 0) {
+    const int k = nnz > 8 ? 8 : nnz;
+    nnz -= k;
+    put_chunk<WRITE>(E, k, (uint32_t)(signs >> nnz));
+  }
+}
+template <bool WRITE> __device__ inline void mvd_ops(Emit &E, int comp, int v) {
+  const uint32_t a = (uint32_t)(v < 0 ? -v : v);
+  int k = a ? 32 - __clz((int)a) : 0;
+  k = k > 15 ? 15 : k;
+  put_pair<WRITE>(E, C_MV_HI + comp, C_MV_LO + comp * 4, k);
+  if (k == 15) put_raw<WRITE>(E, 15, a - 16384);
+  else if (k > 1) put_raw<WRITE>(E, k - 1, a & ((1u << (k - 1)) - 1));
+  if (a) put_chunk<WRITE>(E, 1, (uint32_t)(v < 0));
+}
+struct BlockHdr { int key, my, muv, sk, dx, dy; };
+template <bool WRITE> __device__ inline void all_ops(Emit &E, const BlockHdr &H, const int16_t *row) {
+  bool coded = true;
+  if (H.key) {
+    put_pair<WRITE>(E, C_MODE_HI, C_MODE_LO, H.my);
+    put_pair<WRITE>(E, C_MODE_HI + 1, C_MODE_LO + 4, H.muv);
+  } else {
+    put_sym<WRITE>(E, C_SKIP, H.sk);
+    mvd_ops<WRITE>(E, 0, H.dx);
+    mvd_ops<WRITE>(E, 1, H.dy);
+    coded = !H.sk;
+  }
+  if (coded) {
+    block_ops<WRITE>(E, row, 64, 0);
+    block_ops<WRITE>(E, row + 64, 16, 1);
+    block_ops<WRITE>(E, row + 80, 16, 1);
+  }
+}
+
+// thread = 8x8 block; a workgroup holds TB2 = (tile/8)^2 threads per tile and blockDim / TB2 tiles
+__global__ void __launch_bounds__(256) k_ent_tokens(EntropyLaunch L) {
+  extern __shared__ uint32_t s_dyn[];        // per thread: 96 levels in scan order (49-dword stride), then the scan array
+  int16_t *s_rows = (int16_t *)s_dyn;
+  uint32_t *s_cnt = s_dyn + blockDim.x * 49;
+  const int tid = threadIdx.x, tb = L.tile >> 3, tb2 = tb * tb, tpg = blockDim.x / tb2;
+  const int tc = (L.w + L.tile - 1) / L.tile, tr = (L.h + L.tile - 1) / L.tile, tpf = tc * tr;
+  const long long g = (long long)blockIdx.x * tpg + tid / tb2;       // global tile
+  const int lb = tid % tb2;
+  const bool live = g < (long long)tpf * L.nframes;
+  const int f = live ? (int)(g / tpf) : 0, t = live ? (int)(g % tpf) : 0;
+  const int bw = L.w >> 3, bh = L.h >> 3;
+  const int bx = (t % tc) * tb + lb % tb, by = (t / tc) * tb + lb / tb;
+  const bool valid = live && bx < bw && by < bh;
+  const size_t b = (size_t)f * bw * bh + (size_t)(valid ? by * bw + bx : 0);
+  int16_t *row = s_rows + tid * 98;
+  BlockHdr H = { L.key, 0, 0, 0, 0, 0 };
+  if (valid) {
+    const uint4 *sy = (const uint4 *)(L.lev[0] + b * 64), *su = (const uint4 *)(L.lev[1] + b * 16), *sv = (const uint4 *)(L.lev[2] + b * 16);
+    uint32_t dw[32];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { const uint4 v = sy[k]; dw[k * 4] = v.x; dw[k * 4 + 1] = v.y; dw[k * 4 + 2] = v.z; dw[k * 4 + 3] = v.w; }
+    stage_scan<8>(row, dw, std::make_integer_sequence<int, 32>());
+    uint32_t du[16];
+#pragma unroll
+    for (int k = 0; k < 2; k++) { const uint4 v = su[k], w = sv[k]; du[k * 4] = v.x; du[k * 4 + 1] = v.y; du[k * 4 + 2] = v.z; du[k * 4 + 3] = v.w;
+                                  du[8 + k * 4] = w.x; du[9 + k * 4] = w.y; du[10 + k * 4] = w.z; du[11 + k * 4] = w.w; }
+    stage_scan<4>(row + 64, du, std::make_integer_sequence<int, 8>());
+    stage_scan<4>(row + 80, du + 8, std::make_integer_sequence<int, 8>());
+    if (L.key) {
+      H.my = L.modes_y[b]; H.muv = L.modes_uv[b];
+      H.my = H.my < 13 ? H.my : 0; H.muv = H.muv < 13 ? H.muv : 0;
+    } else {
+      H.sk = L.skip[b] != 0;
+      const bool left = lb % tb != 0;                // the left neighbour inside the tile predicts the vector
+      const int px = left ? L.mvs[(b - 1) * 2] : 0, py = left ? L.mvs[(b - 1) * 2 + 1] : 0;
+      H.dx = (int16_t)(L.mvs[b * 2] - px); H.dy = (int16_t)(L.mvs[b * 2 + 1] - py);
+    }
+  }
+  Emit E = { nullptr, 0 };
+  if (valid) all_ops<false>(E, H, row);
+  const uint32_t mine = E.n;
+  s_cnt[tid] = mine;
+  __syncthreads();
+  for (int o = 1; o < (int)blockDim.x; o <<= 1) {         // inclusive scan over the workgroup
+    const uint32_t add = tid >= o ? s_cnt[tid - o] : 0;
+    __syncthreads();
+    s_cnt[tid] += add;
+    __syncthreads();
+  }
+  const int seg0 = tid - lb;                               // first thread of this tile
+  const uint32_t before = seg0 ? s_cnt[seg0 - 1] : 0, off = s_cnt[tid] - mine - before, total = s_cnt[seg0 + tb2 - 1] - before;
+  if (live && lb == 0) L.nops[g] = total;
+  if (valid) {
+    E.p = L.ops + (size_t)g * L.ops_per_tile + off; E.n = 0;
+    all_ops<true>(E, H, row);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ coder
 // Coder state of one lane.  `low` carries 16 + pend bits (pend < 32 between symbols) plus, on top, at most one unresolved
 // carry bit: a carry out of an addition is NOT resolved when it happens (the interval never leaves [low, low + rng) of the
 // previous state, so a second one cannot pile up) but when the next 32 finished bits leave as a big-endian word: bit 32 of
@@ -68,47 +209,51 @@ __device__ inline void ripple(Enc &e) {    // +1 into the big-endian number alre
     if (w) break;
   }
 }
-__device__ inline void flush_word(Enc &e) {
-  e.pend -= 32;
-  const uint64_t w = e.low >> (16 + e.pend);
-  e.low &= ((uint64_t)1 << (16 + e.pend)) - 1;
-  if (w >> 32) ripple(e);
-  if (e.n < e.cap) e.out[e.n] = __builtin_bswap32((uint32_t)w);
-  e.n++;
-}
-// interval [low + add, low + add + nrng) becomes the state; renormalise to a 16-bit range
-__device__ inline void commit(Enc &e, uint32_t add, uint32_t nrng) {
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ inline uint32_t pk(u16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ inline u16x2 unpk(uint32_t v) { return __builtin_bit_cast(u16x2, v); }
+
+// one op: both interval formulas are evaluated and selected (no divergence on the kind of op).
+// The lane's CDFs live in LDS in INVERSE form, x = i0 | i1 << 16, y = i2 | count << 16 with i_k = 32768 - c_k (what the
+// partition formula consumes): the pair (f of symbol s - 1, f of symbol s) is one 64-bit shift of (0, i0, i1, i2, 0) by
+// 16 s bits, the zeros supplying "32768 - 32768" for the last symbol, and the update is packed 16-bit arithmetic.
+__device__ inline uint2 step(Enc &e, const uint2 v, uint32_t op) {   // returns the adapted CDF (meaningful for adaptive ops)
+  const bool raw = (op & OP_RAW) != 0;
+  const uint32_t s = op & 3;
+  const uint64_t w64 = ((uint64_t)((v.x >> 16) | (v.y << 16)) << 32 | (uint64_t)(v.x << 16)) >> (s * 16);
+  const uint32_t t = (uint32_t)w64, fp = t & 0xFFFF, fs = t >> 16;        // f(s - 1) (0 for s = 0), f(s) (0 for s = 3)
+  const uint32_t r8 = e.rng >> 8;
+  const uint32_t bot = (__umul24(r8, fs >> 6) >> 1) + 4u * (3 - s);
+  const uint32_t topc = (__umul24(r8, fp >> 6) >> 1) + 4u * (4 - s);
+  const uint32_t top = s == 0 ? e.rng : topc;
+  // raw: nb bits, j = slot counted from the bottom (precomputed by the tokenizer), bit 14 = top slot
+  const uint32_t nb = (op >> 8) & 15, r = e.rng >> nb, radd = __umul24(r, op & 0xFF);
+  const uint32_t rrng = (op & OP_TOPSLOT) ? e.rng - radd : r;
+  const uint32_t add = raw ? radd : bot, nrng = raw ? rrng : top - bot;
+  // interval [low + add, low + add + nrng) becomes the state; renormalise to a 16-bit range
   const int d = __clz((int)nrng) - 16;
   e.low = (e.low + add) << d;      // <= 17 + 31 + 15 bits
   e.rng = nrng << d;
   e.pend += d;
-  if (e.pend >= 32) flush_word(e);
-}
-// adaptive 4-ary symbol with CDF `id` of this lane's model row: one 64-bit LDS load, one store
-__device__ inline void enc4(Enc &e, uint2 *mrow, int id, int s) {
-  const uint2 v = mrow[id];
-  const uint32_t c0 = v.x & 0xFFFF, c1 = v.x >> 16, c2 = v.y & 0xFFFF, cnt = v.y >> 16;
-  const uint32_t cs = s == 0 ? c0 : s == 1 ? c1 : s == 2 ? c2 : 32768u;
-  const uint32_t cp = s == 1 ? c0 : s == 2 ? c1 : c2;
-  const uint32_t r8 = e.rng >> 8;
-  const uint32_t bot = ((r8 * ((32768u - cs) >> 6)) >> 1) + 4u * (uint32_t)(3 - s);
-  const uint32_t top = s ? ((r8 * ((32768u - cp) >> 6)) >> 1) + 4u * (uint32_t)(4 - s) : e.rng;
-  commit(e, bot, top - bot);
-  const int rate = 5 + (cnt > 15) + (cnt > 31);
-  const uint32_t n0 = s <= 0 ? c0 + ((32768u - c0) >> rate) : c0 - (c0 >> rate);
-  const uint32_t n1 = s <= 1 ? c1 + ((32768u - c1) >> rate) : c1 - (c1 >> rate);
-  const uint32_t n2 = s <= 2 ? c2 + ((32768u - c2) >> rate) : c2 - (c2 >> rate);
-  mrow[id] = make_uint2(n0 | (n1 << 16), n2 | ((cnt + (cnt < 32)) << 16));
-}
-// n (1..8) equiprobable bits as one symbol over 2^n slots
-__device__ inline void enc_raw(Enc &e, int n, uint32_t v) {
-  const uint32_t top = (1u << n) - 1, j = top - v, r = e.rng >> n, add = r * j;
-  commit(e, add, j == top ? e.rng - add : r);
-}
-// up to 16 raw bits, most significant chunk of <= 8 first; both steps are wave-level branches
-__device__ inline void enc_raw16(Enc &e, bool on, int nbits, uint32_t v) {
-  if (on && nbits > 0) { const int n = nbits > 8 ? 8 : nbits; enc_raw(e, n, (v >> (nbits - n)) & ((1u << n) - 1)); }
-  if (on && nbits > 8) { const int n = nbits - 8; enc_raw(e, n, v & ((1u << n) - 1)); }
+  if (e.pend >= 32) {
+    e.pend -= 32;
+    const uint64_t w = e.low >> (16 + e.pend);
+    e.low &= ((uint64_t)1 << (16 + e.pend)) - 1;
+    if (w >> 32) ripple(e);
+    if (e.n < e.cap) e.out[e.n] = __builtin_bswap32((uint32_t)w);
+    e.n++;
+  }
+  // adaptation in inverse form: i_k -= i_k >> rate for k >= s (c_k moves up), i_k += (32768 - i_k) >> rate for k < s
+  const uint32_t cnt = v.y >> 16;
+  const unsigned short rate = (unsigned short)(5 + (cnt > 15) + (cnt > 31));
+  const u16x2 rr = { rate, rate }, k15 = { 32768, 32768 };
+  const u16x2 x = unpk(v.x), y = unpk(v.y & 0xFFFF);
+  const u16x2 xd = x - (x >> rr), xu = x + ((k15 - x) >> rr);
+  const u16x2 yd = y - (y >> rr), yu = y + ((k15 - y) >> rr);   // high half of y is 0 here: the counter is put back below
+  const uint32_t mx = s == 0 ? 0xFFFFFFFFu : s == 1 ? 0xFFFF0000u : 0u;   // halves with k >= s take the "down" form
+  const uint32_t nx = (pk(xd) & mx) | (pk(xu) & ~mx);
+  const uint32_t ny = (s == 3 ? pk(yu) : pk(yd)) & 0xFFFF;
+  return make_uint2(nx, ny | ((cnt + (cnt < 32)) << 16));
 }
 __device__ inline int wave_max(int v) {
 #pragma unroll
@@ -116,119 +261,35 @@ __device__ inline int wave_max(int v) {
   return __builtin_amdgcn_readfirstlane(v);
 }
 
-// one transform block of n coefficients at int16 index `base` of the lane row
-__device__ inline void code_block(Enc &e, uint2 *m, int16_t *row, int base, int pt, int ncoef, bool coded) {
-  int eob = 0;
-#pragma unroll 8
-  for (int i = 0; i < ncoef; i++) eob = row[base + i] != 0 ? i + 1 : eob;
-  if (!coded) eob = 0;
-  if (coded) {
-    const int cls = eob <= 2 ? eob : 33 - __clz(eob - 1);
-    enc4(e, m, C_EOB_HI + pt, cls >> 2);
-    enc4(e, m, C_EOB_LO + pt * 2 + (cls >> 2), cls & 3);
-    const int xb = cls >= 3 ? cls - 2 : 0;
-    enc_raw16(e, cls >= 3, xb, (uint32_t)(eob - (1 << xb) - 1));
-  }
-  const int emax = wave_max(eob);
-  int prev = 0, nnz = 0, nesc = 0;
-  uint64_t signs = 0;
-  for (int i = 0; i < emax; i++) {          // uniform trip count: scan position and band are scalar
-    const int band = i == 0 ? 0 : i <= 4 ? 1 : i <= 15 ? 2 : 3;
-    if (i < eob) {
-      const int l = row[base + i], a = l < 0 ? -l : l, t = a < 3 ? a : 3;
-      enc4(e, m, C_TOK + (pt * 4 + band) * 3 + prev, t);
-      if (a) { signs = (signs << 1) | (uint64_t)(l < 0); nnz++; }
-      if (a >= 3) row[96 + nesc++] = (int16_t)(a - 2);           // 1..32766
-      prev = t < 2 ? t : 2;
-    }
-  }
-  const int xmax = wave_max(nesc);
-  for (int j = 0; j < xmax; j++) {
-    const bool on = j < nesc;
-    const uint32_t x = on ? (uint32_t)row[96 + j] : 1u;
-    const int k = 31 - __clz((int)x);
-    int rest = on ? k : -1;                  // chain min(k,3), min(k-3,3), ... until a symbol below 3
-    for (int c = 0; c < 5; c++) {
-      if (__builtin_amdgcn_readfirstlane(__any(rest >= 0)) == 0) break;
-      if (rest >= 0) { const int sy = rest < 3 ? rest : 3; enc4(e, m, C_GOL + pt * 5 + c, sy); rest = sy < 3 ? -1 : rest - 3; }
-    }
-    enc_raw16(e, on, k, x & ((1u << k) - 1));
-  }
-  const int smax = wave_max((nnz + 7) >> 3);
-  for (int c = 0; c < smax; c++) {
-    if (nnz > 0) {
-      const int k = nnz > 8 ? 8 : nnz;
-      nnz -= k;
-      enc_raw(e, k, (uint32_t)(signs >> nnz) & ((1u << k) - 1));
-    }
-  }
-}
-__device__ inline void code_mvd(Enc &e, uint2 *m, int comp, bool on, int v) {
-  const uint32_t a = (uint32_t)(v < 0 ? -v : v);
-  int k = a ? 32 - __clz((int)a) : 0;
-  k = k > 15 ? 15 : k;
-  if (on) { enc4(e, m, C_MV_HI + comp, k >> 2); enc4(e, m, C_MV_LO + comp * 4 + (k >> 2), k & 3); }
-  enc_raw16(e, on && k > 1, k == 15 ? 15 : k - 1, k == 15 ? a - 16384 : a & ((1u << (k > 0 ? k - 1 : 0)) - 1));
-  if (on && a) enc_raw(e, 1, v < 0);
-}
-
 __global__ void __launch_bounds__(64) k_ent_code(EntropyLaunch L) {
-  __shared__ uint2 s_models[64 * C_COUNT];      // lane rows of 61 x 8 bytes (odd multiple of 8: conflict-free for equal ids)
-  __shared__ int16_t s_rows[64 * ROW];
+  __shared__ uint2 s_models[64 * C_COUNT];      // lane rows of 61 x 8 bytes (odd multiple of 8)
   const int lane = threadIdx.x;
   const long long g = (long long)blockIdx.x * 64 + lane;
-  const int tc = (L.w + L.tile - 1) / L.tile, tr = (L.h + L.tile - 1) / L.tile, tpf = tc * tr;
-  const bool live = g < (long long)tpf * L.nframes;
-  const int f = live ? (int)(g / tpf) : 0, t = live ? (int)(g % tpf) : 0;
-  const int bw = L.w >> 3, bh = L.h >> 3, tb = L.tile >> 3;
-  const int bx0 = (t % tc) * tb, by0 = (t / tc) * tb;
-  const int bx1 = live ? (bx0 + tb < bw ? bx0 + tb : bw) : bx0, by1 = live ? (by0 + tb < bh ? by0 + tb : bh) : by0;
-  const size_t nb = (size_t)bw * bh, fb = (size_t)f * nb;
+  const int tc = (L.w + L.tile - 1) / L.tile, tr = (L.h + L.tile - 1) / L.tile;
+  const bool live = g < (long long)tc * tr * L.nframes;
   uint2 *m = s_models + lane * C_COUNT;
-  int16_t *row = s_rows + lane * ROW;
-  for (int i = 0; i < C_COUNT; i++) m[i] = kInit[i];
+  for (int i = 0; i < C_COUNT; i++) { const uint2 c = kInit[i]; m[i] = make_uint2(0x80008000u - c.x, 0x8000u - (c.y & 0xFFFF)); }   // inverse form, counter 0
   Enc e;
   e.low = 0; e.rng = 0x8000; e.pend = 0; e.n = 0;
   e.cap = live ? L.slot_bytes / 4 : 0; e.out = (uint32_t *)(L.slots + (live ? (size_t)g * L.slot_bytes : 0));
-  for (int lby = 0; lby < tb; lby++)
-    for (int lbx = 0; lbx < tb; lbx++) {   // uniform over the wave; ragged tiles mask lanes off
-      const int bx = bx0 + lbx, by = by0 + lby;
-      const bool valid = bx < bx1 && by < by1;
-      const size_t b = fb + (size_t)(valid ? by * bw + bx : 0);
-      bool coded = valid;
-      if (valid) {       // stage the block's levels in SCAN order
-        const uint4 *sy = (const uint4 *)(L.lev[0] + b * 64), *su = (const uint4 *)(L.lev[1] + b * 16), *sv = (const uint4 *)(L.lev[2] + b * 16);
-        uint32_t dw[32];
+  const int nops = live ? (int)L.nops[g] : 0;
+  const uint4 *src = (const uint4 *)(L.ops + (live ? (size_t)g * L.ops_per_tile : 0));
+  const int last = (int)(L.ops_per_tile >> 3) - 1;          // lists are padded: any index <= last is in bounds
+  const int nmax = wave_max(nops);
+  uint4 cur = src[0];
+  for (int base = 0; base < nmax; base += 8) {
+    const int nq = (base >> 3) + 1;
+    const uint4 nxt = src[nq < last ? nq : last];            // next 8 ops, in flight while these are coded
+    const uint32_t wd[4] = { cur.x, cur.y, cur.z, cur.w };
 #pragma unroll
-        for (int k = 0; k < 8; k++) { const uint4 v = sy[k]; dw[k * 4] = v.x; dw[k * 4 + 1] = v.y; dw[k * 4 + 2] = v.z; dw[k * 4 + 3] = v.w; }
-        stage_scan<8>(row, dw, std::make_integer_sequence<int, 32>());
-        uint32_t du[16];
-#pragma unroll
-        for (int k = 0; k < 2; k++) { const uint4 v = su[k], w = sv[k]; du[k * 4] = v.x; du[k * 4 + 1] = v.y; du[k * 4 + 2] = v.z; du[k * 4 + 3] = v.w;
-                                      du[8 + k * 4] = w.x; du[9 + k * 4] = w.y; du[10 + k * 4] = w.z; du[11 + k * 4] = w.w; }
-        stage_scan<4>(row + 64, du, std::make_integer_sequence<int, 8>());
-        stage_scan<4>(row + 80, du + 8, std::make_integer_sequence<int, 8>());
+    for (int k = 0; k < 8; k++)
+      if (base + k < nops) {
+        const uint32_t op = (wd[k >> 1] >> ((k & 1) * 16)) & 0xFFFF, id = (op & OP_RAW) ? 0u : op >> 8;   // raw ops read CDF 0 and leave it alone
+        const uint2 nv = step(e, m[id], op);
+        if (!(op & OP_RAW)) m[id] = nv;
       }
-      if (L.key) {
-        int my = 0, muv = 0;
-        if (valid) { my = L.modes_y[b]; muv = L.modes_uv[b]; my = my < 13 ? my : 0; muv = muv < 13 ? muv : 0; }
-        if (valid) { enc4(e, m, C_MODE_HI, my >> 2); enc4(e, m, C_MODE_LO + (my >> 2), my & 3); }
-        if (valid) { enc4(e, m, C_MODE_HI + 1, muv >> 2); enc4(e, m, C_MODE_LO + 4 + (muv >> 2), muv & 3); }
-      } else {
-        int sk = 0, dx = 0, dy = 0;
-        if (valid) {
-          sk = L.skip[b] != 0;
-          const int px = lbx ? L.mvs[(b - 1) * 2] : 0, py = lbx ? L.mvs[(b - 1) * 2 + 1] : 0;
-          dx = (int16_t)(L.mvs[b * 2] - px); dy = (int16_t)(L.mvs[b * 2 + 1] - py);
-          enc4(e, m, C_SKIP, sk);
-        }
-        code_mvd(e, m, 0, valid, dx);
-        code_mvd(e, m, 1, valid, dy);
-        coded = valid && !sk;
-      }
-#pragma unroll 1
-      for (int p = 0; p < 3; p++) code_block(e, m, row, p == 0 ? 0 : 48 + p * 16, p != 0, p == 0 ? 64 : 16, coded);
-    }
+    cur = nxt;
+  }
   if (live) {
     if (e.low >> (16 + e.pend)) { ripple(e); e.low &= ((uint64_t)1 << (16 + e.pend)) - 1; }   // a carry still riding on top
     uint32_t nbytes = e.n * 4;
@@ -301,6 +362,16 @@ __global__ void __launch_bounds__(64) k_ent_pack(EntropyLaunch L, int tpf, int t
 
 hipError_t entropy_init_tables() { return hipMemcpyToSymbol(HIP_SYMBOL(kInit), kEntropyInit, sizeof(kEntropyInit)); }
 
+size_t entropy_ops_per_tile(int tile) { const size_t tb2 = (size_t)(tile / 8) * (tile / 8); return (tb2 * OPS_PER_BLOCK + 16 + 7) & ~(size_t)7; }
+
+hipError_t launch_entropy_tokens(const EntropyLaunch &L, hipStream_t s) {
+  const int tc = (L.w + L.tile - 1) / L.tile, tr = (L.h + L.tile - 1) / L.tile;
+  const long long tiles = (long long)tc * tr * L.nframes;
+  if (tiles <= 0) return hipSuccess;
+  const int tb2 = (L.tile / 8) * (L.tile / 8), threads = tb2 < 64 ? 64 : tb2, tpg = threads / tb2;
+  k_ent_tokens<<<dim3((unsigned)((tiles + tpg - 1) / tpg)), dim3(threads), (size_t)threads * 50 * 4, s>>>(L);
+  return hipGetLastError();
+}
 hipError_t launch_entropy_code(const EntropyLaunch &L, hipStream_t s) {
   const int tc = (L.w + L.tile - 1) / L.tile, tr = (L.h + L.tile - 1) / L.tile;
   const long long tiles = (long long)tc * tr * L.nframes;

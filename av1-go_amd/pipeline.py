@@ -45,7 +45,7 @@ class IntraPipeline:
          2 steps    k_ent_code + pack   (entropy_tile > 0 only) tile entropy coder: levels + modes -> one byte stream
     Filter parameters are fixed per segment by simple policies (no RD search)."""
 
-    def __init__(self, ctx, width, height, bd, frames, qindex, first_frame=0, block_size=8, entropy_tile=0):
+    def __init__(self, ctx, width, height, bd, frames, qindex, first_frame=0, block_size=8, entropy_tile=0, entropy_async=False):
         self.ctx, self.bd, self.frames, self.bs, self.qindex = ctx, bd, frames, block_size, qindex
         self.width, self.height = width, height
         Y, U, V = synth.frames(width, height, frames, bd, first_frame)
@@ -61,19 +61,30 @@ class IntraPipeline:
                         ("lev_y", Y.size * 2), ("lev_u", U.size * 2), ("lev_v", V.size * 2),
                         ("modes_y", frames * nb), ("modes_uv", frames * nb)):
             self.d[name] = ctx.alloc(n)
-        self.entropy_tile, self.ent_job, self.entropy_in_step = entropy_tile, None, True
-        if entropy_tile:
-            if block_size != 8:
-                raise ValueError("the entropy coder's syntax is defined for 8x8 blocks")
-            self.ent_cap = frames * (width * height * 3 + 65536)      # raw int16 size: the coded stream stays far below
-            self.d["ent_out"], self.d["ent_off"] = ctx.alloc(self.ent_cap), ctx.alloc((frames + 1) * 8)
-            self.ent_job = av1mi.EntropyJob(width, height, frames, 1, entropy_tile)
+        self.entropy_tile, self.entropy_in_step, self.entropy_async, self.nsteps = entropy_tile, True, bool(entropy_async and entropy_tile), 0
+        self.jobs, self.ent_jobs = [], []
+        for slot in range(2 if self.entropy_async else 1):
+            sfx = "" if slot == 0 else "_b"               # asynchronous coder: levels / modes / stream are double-buffered
+            if slot:
+                for name, n in (("lev_y", Y.size * 2), ("lev_u", U.size * 2), ("lev_v", V.size * 2), ("modes_y", frames * nb), ("modes_uv", frames * nb)):
+                    self.d[name + sfx] = ctx.alloc(n)
+            job = av1mi.IntraJob(width, height, bd, frames, qindex, block_size, width, width // 2)
+            for k in ("src_y", "src_u", "src_v", "rec_y", "rec_u", "rec_v"):
+                setattr(job, "d_" + k, self.d[k].ptr)
             for k in ("lev_y", "lev_u", "lev_v", "modes_y", "modes_uv"):
-                setattr(self.ent_job, "d_" + k, self.d[k].ptr)
-            self.ent_job.d_out, self.ent_job.out_cap, self.ent_job.d_frame_off = self.d["ent_out"].ptr, self.ent_cap, self.d["ent_off"].ptr
-        self.job = av1mi.IntraJob(width, height, bd, frames, qindex, block_size, width, width // 2)
-        for k in ("src_y", "src_u", "src_v", "rec_y", "rec_u", "rec_v", "lev_y", "lev_u", "lev_v", "modes_y", "modes_uv"):
-            setattr(self.job, "d_" + k, self.d[k].ptr)
+                setattr(job, "d_" + k, self.d[k + sfx].ptr)
+            self.jobs.append(job)
+            if entropy_tile:
+                if block_size != 8:
+                    raise ValueError("the entropy coder's syntax is defined for 8x8 blocks")
+                self.ent_cap = frames * (width * height * 3 + 65536)      # raw int16 size: the coded stream stays far below
+                self.d["ent_out" + sfx], self.d["ent_off" + sfx] = ctx.alloc(self.ent_cap), ctx.alloc((frames + 1) * 8)
+                ej = av1mi.EntropyJob(width, height, frames, 1, entropy_tile)
+                for k in ("lev_y", "lev_u", "lev_v", "modes_y", "modes_uv"):
+                    setattr(ej, "d_" + k, self.d[k + sfx].ptr)
+                ej.d_out, ej.out_cap, ej.d_frame_off = self.d["ent_out" + sfx].ptr, self.ent_cap, self.d["ent_off" + sfx].ptr
+                self.ent_jobs.append(ej)
+        self.job, self.ent_job = self.jobs[0], (self.ent_jobs[0] if self.ent_jobs else None)
         lib = ctx.lib
         self.dc_q, self.ac_q = lib.av1mi_dc_q(qindex, bd), lib.av1mi_ac_q(qindex, bd)
         self.lf_level = lf_level_from_q(self.ac_q, bd)
@@ -103,16 +114,24 @@ class IntraPipeline:
                 "(11 modes, SAD decision) + fwd DCT + quant + dequant + inv DCT + recon fused, then deblocking (level %d), "
                 "CDEF (strengths %s, damping %d) and Wiener loop restoration (64x64 units, default taps); %s"
                 % (self.width, self.height, self.bd, self.bs, self.bs, self.lf_level, self.cdef_sb[0].tolist(), self.cdef_damping,
-                   "levels + modes coded on the GPU by the tile entropy coder (%dx%d tiles, own syntax, not an AV1 bitstream)"
-                   % (self.entropy_tile, self.entropy_tile) if self.entropy_tile and self.entropy_in_step else
+                   "levels + modes coded on the GPU by the tile entropy coder (%dx%d tiles, own syntax, not an AV1 bitstream%s)"
+                   % (self.entropy_tile, self.entropy_tile, "; side stream, overlapping the next step" if self.entropy_async else "")
+                   if self.entropy_tile and self.entropy_in_step else
                    "levels + modes stay uncoded in HBM (entropy coding not in the timed step)"))
 
     def step(self):
         c, d = self.ctx, self.d
         w, h, f = self.width, self.height, self.frames
-        c.intra_encode(self.job)
-        if self.ent_job is not None and self.entropy_in_step:
-            c.entropy_encode(self.ent_job)
+        slot = self.nsteps % len(self.jobs)
+        self.nsteps += 1
+        if self.entropy_async and self.entropy_in_step:
+            c.entropy_wait(slot)               # the coder that read this slot's levels two steps ago has finished (device-side wait)
+        c.intra_encode(self.jobs[slot])
+        if self.ent_jobs and self.entropy_in_step:
+            if self.entropy_async:
+                c.entropy_encode_async(self.ent_jobs[slot], slot)   # side stream: overlaps the filters and the next step's coding kernel
+            else:
+                c.entropy_encode(self.ent_jobs[slot])
         c.deblock_frames(d["rec_y"], w, d["dbl_y"], w, w, h, self.bd, 0, d["mi_y"], w // 4, 0, 0, f)
         c.deblock_frames(d["rec_u"], w // 2, d["dbl_u"], w // 2, w // 2, h // 2, self.bd, 1, d["mi_c"], w // 8, 0, 0, f)
         c.deblock_frames(d["rec_v"], w // 2, d["dbl_v"], w // 2, w // 2, h // 2, self.bd, 1, d["mi_c"], w // 8, 0, 0, f)
@@ -131,11 +150,13 @@ class IntraPipeline:
 
     def coded_records(self):
         """the frame records written by the last step (entropy_tile > 0)"""
-        off = self.d["ent_off"].download((self.frames + 1,), np.uint64)
+        self.ctx.sync()
+        sfx = "_b" if self.entropy_async and self.entropy_in_step and self.nsteps % 2 == 0 else ""
+        off = self.d["ent_off" + sfx].download((self.frames + 1,), np.uint64)
         total = int(off[-1])
         if total > self.ent_cap:
             raise RuntimeError("entropy output needs %d bytes, capacity %d" % (total, self.ent_cap))
-        data = self.d["ent_out"].download((max(total, 1),), np.uint8)[:total].tobytes()
+        data = self.d["ent_out" + sfx].download((max(total, 1),), np.uint8)[:total].tobytes()
         return [data[int(off[i]):int(off[i + 1])] for i in range(self.frames)]
 
     def download(self, frame=0):

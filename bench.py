@@ -32,10 +32,10 @@ def parse():
                          "frames, 1 key + 29 P (configs 3/4)")
     ap.add_argument("--frames", type=int, default=0, help="frames per step (segment length); 0 = default")
     ap.add_argument("--qindex", type=int, default=128)
-    ap.add_argument("--entropy", default="none", choices=["none", "gpu"],
+    ap.add_argument("--entropy", default="none", choices=["none", "gpu", "gpu-async"],
                     help="gpu = the tile entropy coder (K9) runs inside the timed step; none (default) = BASELINE config 2 as "
                          "written (transform + prediction + filters), with the entropy stage timed in a separate leg and "
-                         "reported under \"entropy\"")
+                         "reported under \"entropy\"; gpu-async = the coder on the context's side stream, overlapping the next step")
     ap.add_argument("--entropy-tile", type=int, default=64, choices=[32, 64, 128])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dry-run-cpu", action="store_true",
@@ -213,8 +213,8 @@ def main():
         pipe = pipeline.GopPipeline(ctx, W, H, bd, segs, gop, args.qindex, first_frame=segment_of_rank(rank, frames))
     else:
         pipe = pipeline.IntraPipeline(ctx, W, H, bd, frames, args.qindex, first_frame=segment_of_rank(rank, frames),
-                                      entropy_tile=args.entropy_tile)
-        pipe.entropy_in_step = args.entropy == "gpu"
+                                      entropy_tile=args.entropy_tile, entropy_async=args.entropy == "gpu-async")
+        pipe.entropy_in_step = args.entropy != "none"
 
     def barrier():
         ctx.sync()

@@ -79,7 +79,7 @@ int av1mi_timer_end(av1mi_ctx *ctx, float *elapsed_ms);
 enum av1mi_kernel_kind {
   AV1MI_K_FWD_TXFM, AV1MI_K_INV_TXFM, AV1MI_K_QUANT, AV1MI_K_DEQUANT, AV1MI_K_INTRA_PRED, AV1MI_K_MC,
   AV1MI_K_DEBLOCK, AV1MI_K_CDEF, AV1MI_K_LR, AV1MI_K_INTRA_PIPE, AV1MI_K_INTER_PIPE, AV1MI_K_MISC, AV1MI_K_ENTROPY,
-  AV1MI_K_ENTROPY_PACK, AV1MI_K_KINDS
+  AV1MI_K_ENTROPY_PACK, AV1MI_K_ENTROPY_TOKENS, AV1MI_K_KINDS
 };
 int av1mi_prof_enable(av1mi_ctx *ctx, int on);
 int av1mi_prof_reset(av1mi_ctx *ctx);
@@ -247,6 +247,14 @@ typedef struct av1mi_entropy_job {
   uint64_t *d_frame_off;                   /* nframes + 1 entries, 8-byte aligned */
 } av1mi_entropy_job;
 int av1mi_entropy_encode(av1mi_ctx *ctx, const av1mi_entropy_job *job);
+/* Asynchronous form.  The coder is a latency-bound kernel (one wave per SIMD at most, a serial chain per tile) that
+ * leaves most of the chip idle, so it runs on the context's SIDE stream: it starts after everything queued so far on
+ * the main stream (which produced its inputs) and overlaps whatever the main stream is given next — the next batch's
+ * block pipeline, the in-loop filters.  `slot` (0..7) names the completion event.  av1mi_entropy_wait makes the MAIN
+ * stream (not the host) wait for that slot's coder: call it before launching work that overwrites the job's input
+ * buffers (double-buffer levels / modes and alternate two slots).  av1mi_sync waits for both streams. */
+int av1mi_entropy_encode_async(av1mi_ctx *ctx, const av1mi_entropy_job *job, int slot);
+int av1mi_entropy_wait(av1mi_ctx *ctx, int slot);
 
 /* ---- host-pointer single-block forms (SURVEY.md §8b "per-stage test entry points"): copy in, run the
  * same kernels, copy out, synchronous. */

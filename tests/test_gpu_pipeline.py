@@ -95,3 +95,22 @@ def test_pipeline_with_gpu_entropy_stage(ctx, O):
         assert recs[f] == ref, "frame %d: %d vs %d bytes" % (f, len(recs[f]), len(ref))
         assert len(ref) < Y[f].nbytes           # and it compresses
     pipe.close()
+
+
+def test_async_entropy_stage_matches_sync(ctx, O):
+    """side-stream coder with double-buffered levels: every step's records equal the oracle's, whichever slot they used"""
+    import pipeline
+    w, h, bd, q = 256, 136, 8, 150
+    pipe = pipeline.IntraPipeline(ctx, w, h, bd, 2, q, first_frame=0, entropy_tile=32, entropy_async=True)
+    Y, U, V = pipe.src
+    ref = []
+    for f in range(2):
+        r = O.intra_encode_frame(Y[f], U[f], V[f], bd, 8, q)
+        ref.append(O.entropy_encode_frame(w, h, 1, 32, r["lev_y"], r["lev_u"], r["lev_v"], r["modes_y"], r["modes_uv"]))
+    for _ in range(3):                      # slots 0, 1, 0: the third step had to wait for the first one's coder
+        pipe.step()
+        assert pipe.coded_records() == ref
+    for _ in range(4):                      # back to back without host syncs in between
+        pipe.step()
+    assert pipe.coded_records() == ref
+    pipe.close()

@@ -27,7 +27,8 @@ for frames, tile, q in cases:
     prof = ctx.prof_get()
     recs = pipe.coded_records()
     ms = prof["entropy_code"][1] / prof["entropy_code"][0]
-    print("frames %3d tile %3d q %3d: code %.3f ms  pack %.3f ms  %.0f fps  %.0f bytes/frame" %
-          (frames, tile, q, ms, prof["entropy_pack"][1] / prof["entropy_pack"][0], frames / ms * 1e3, sum(map(len, recs)) / frames), flush=True)
+    tk = prof["entropy_tokens"][1] / prof["entropy_tokens"][0]
+    print("frames %3d tile %3d q %3d: tokens %.3f ms  code %.3f ms  pack %.3f ms  %.0f fps  %.0f bytes/frame" %
+          (frames, tile, q, tk, ms, prof["entropy_pack"][1] / prof["entropy_pack"][0], frames / (ms + tk) * 1e3, sum(map(len, recs)) / frames), flush=True)
     pipe.close()
 ctx.close()
