@@ -2,15 +2,15 @@
 //
 // Input is raw video because demux / H.264 decode stay FFmpeg's job (SURVEY.md §8b "Gap to flag"); the output is NOT an
 // AV1 bitstream: the container written here ("AV1MI2") holds, per closed-GOP segment, one record per frame: the frame type
-// and the frame's symbols (modes or vectors + skip flags, quantised levels) coded by the host entropy coder of entropy.hpp
-// (AV1's range-coder arithmetic and CDF adaptation over this project's own syntax, one coder state
-// per frame, the frames of a segment coded in parallel on the host cores while the next segment is on the GPU queue).
+// and the frame's symbols (modes or vectors + skip flags, quantised levels) in the syntax of entropy.hpp (SURVEY.md §8a row
+// H1: AV1's range-coder arithmetic and CDF adaptation over this project's own symbols, one coder state per 64x64 tile).
+// The record is produced on the GPU by the tile entropy coder (K9, av1mi_entropy_encode): only coded bytes cross PCIe;
+// entropy.cpp holds the same coder for host threads (byte-identical, tests/test_entropy.py) and the decoder.
 // It exists so that the job contract (output file present, size gate, atomic replace) can be exercised end to end through
 // every kernel K1-K8 and H1; OBU packing and AV1's default CDFs are not built.
 #include "backend.hpp"
 #include <cstdio>
 #include <cstring>
-#include <thread>
 #include <vector>
 #include "../../include/av1mi.h"
 #include "entropy.hpp"
@@ -79,11 +79,8 @@ int RunBackend(const BackendJob &job, std::string *err) {
   int code = 0;
   FILE *out = nullptr;
   std::vector<unsigned char> hY, hU, hV, packed, bytes;
-  std::vector<int16_t> levY, levU, levV, mvh;
-  std::vector<FrameSyms> syms;
-  std::vector<std::vector<uint8_t>> coded;
-  const int host_threads = (int)std::thread::hardware_concurrency() > 0 ? (int)std::thread::hardware_concurrency() : 1;
-  enum { SY, SU, SV, RY, RU, RV, DY, DU, DV, CY, CU, CV, OY, OU, OV, LY, LU, LV, MY, MUV, MVS, SKIP, ZSKIP, MIY, MIC, CSB, LRY, LRC, NBUF };
+  std::vector<unsigned char> rec;
+  enum { SY, SU, SV, RY, RU, RV, DY, DU, DV, CY, CU, CV, OY, OU, OV, LY, LU, LV, MY, MUV, MVS, SKIP, ZSKIP, MIY, MIC, CSB, LRY, LRC, ENT, EOFF, NBUF };
   void *d[NBUF] = { nullptr };
   long frames_total = 0;
   if (!y4m_open(job.input, &y, err)) { code = 1; goto done; }
@@ -96,11 +93,12 @@ int RunBackend(const BackendJob &job, std::string *err) {
     const int ury = (h + 32) / 64 > 1 ? (h + 32) / 64 : 1, ucy = (w + 32) / 64 > 1 ? (w + 32) / 64 : 1;
     const int urc = (h / 2 + 32) / 64 > 1 ? (h / 2 + 32) / 64 : 1, ucc = (w / 2 + 32) / 64 > 1 ? (w / 2 + 32) / 64 : 1;
     hY.resize(ny * bps * G); hU.resize(nc * bps * G); hV.resize(nc * bps * G);
-    levY.resize(ny * G); levU.resize(nc * G); levV.resize(nc * G); bytes.resize(nb * 2 * G); mvh.resize(nb * 2 * G);
+    const size_t ent_cap = ny * 3 + 65536;      // the raw int16 size of a frame's levels: a coded frame stays far below
     size_t sizes[NBUF];
     for (int i = SY; i <= SV; i++) sizes[i] = (i == SY ? ny : nc) * bps * G;
     for (int i = RY; i <= OV; i++) sizes[i] = ((i - RY) % 3 == 0 ? ny : nc) * bps;
     sizes[LY] = ny * 2; sizes[LU] = sizes[LV] = nc * 2; sizes[MY] = sizes[MUV] = sizes[SKIP] = sizes[ZSKIP] = nb; sizes[MVS] = nb * 4;
+    sizes[ENT] = ent_cap; sizes[EOFF] = 16;
     sizes[MIY] = (ny / 16) * 4; sizes[MIC] = (nc / 16) * 4; sizes[CSB] = (size_t)nsb * 4; sizes[LRY] = (size_t)ury * ucy * 8; sizes[LRC] = (size_t)urc * ucc * 8;
     for (int i = 0; i < NBUF; i++) CHK(av1mi_malloc(ctx, &d[i], sizes[i]));
     CHK(av1mi_memset(ctx, d[ZSKIP], 0, nb));
@@ -130,7 +128,7 @@ int RunBackend(const BackendJob &job, std::string *err) {
       CHK(av1mi_upload(ctx, d[SY], hY.data(), ny * bps * n));
       CHK(av1mi_upload(ctx, d[SU], hU.data(), nc * bps * n));
       CHK(av1mi_upload(ctx, d[SV], hV.data(), nc * bps * n));
-      packed.clear(); syms.clear();
+      packed.clear();
       for (int t = 0; t < n; t++) {
         const bool key = t == 0;
         const char *sy = (const char *)d[SY] + ny * bps * t, *su = (const char *)d[SU] + nc * bps * t, *sv = (const char *)d[SV] + nc * bps * t;
@@ -173,26 +171,23 @@ int RunBackend(const BackendJob &job, std::string *err) {
           CHK(av1mi_lr_frames(ctx, d[CU], d[DU], d[OU], w / 2, w / 2, h / 2, y.bd, 1, 64, (const int8_t *)d[LRC], 0, 1));
           CHK(av1mi_lr_frames(ctx, d[CV], d[DV], d[OV], w / 2, w / 2, h / 2, y.bd, 1, 64, (const int8_t *)d[LRC], 0, 1));
         }
-        // symbols of this frame -> host (coded after the segment's last launch has been queued)
-        FrameSyms fs; fs.width = w; fs.height = h; fs.key = key;
-        unsigned char *by = bytes.data() + nb * 2 * t;
-        if (key) {
-          CHK(av1mi_download(ctx, by, d[MY], nb)); CHK(av1mi_download(ctx, by + nb, d[MUV], nb));
-          fs.modes_y = by; fs.modes_uv = by + nb;
-        } else {
-          CHK(av1mi_download(ctx, mvh.data() + nb * 2 * t, d[MVS], nb * 4)); CHK(av1mi_download(ctx, by, d[SKIP], nb));
-          fs.mvs = mvh.data() + nb * 2 * t; fs.skip = by;
-        }
-        CHK(av1mi_download(ctx, levY.data() + ny * t, d[LY], ny * 2)); fs.lev_y = levY.data() + ny * t;
-        CHK(av1mi_download(ctx, levU.data() + nc * t, d[LU], nc * 2)); fs.lev_u = levU.data() + nc * t;
-        CHK(av1mi_download(ctx, levV.data() + nc * t, d[LV], nc * 2)); fs.lev_v = levV.data() + nc * t;
-        syms.push_back(fs);
-      }
-      entropy_encode_frames(syms, host_threads, &coded);
-      for (int t = 0; t < n; t++) {
-        packed.push_back(t == 0 ? 'K' : 'P');
-        put_varint(packed, (unsigned)coded[(size_t)t].size());
-        packed.insert(packed.end(), coded[(size_t)t].begin(), coded[(size_t)t].end());
+        // symbols of this frame -> coded record, on the device; only the record travels to the host
+        av1mi_entropy_job ej;
+        memset(&ej, 0, sizeof(ej));
+        ej.width = w; ej.height = h; ej.nframes = 1; ej.key = key; ej.tile = 64;
+        ej.d_lev_y = (const int16_t *)d[LY]; ej.d_lev_u = (const int16_t *)d[LU]; ej.d_lev_v = (const int16_t *)d[LV];
+        ej.d_modes_y = (const uint8_t *)d[MY]; ej.d_modes_uv = (const uint8_t *)d[MUV];
+        ej.d_mvs = (const int16_t *)d[MVS]; ej.d_skip = (const uint8_t *)d[SKIP];
+        ej.d_out = (uint8_t *)d[ENT]; ej.out_cap = ent_cap; ej.d_frame_off = (uint64_t *)d[EOFF];
+        CHK(av1mi_entropy_encode(ctx, &ej));
+        uint64_t off[2];
+        CHK(av1mi_download(ctx, off, d[EOFF], sizeof(off)));
+        if (off[1] > ent_cap) { *err = "entropy record larger than its buffer"; code = 2; goto done; }
+        rec.resize((size_t)off[1]);
+        CHK(av1mi_download(ctx, rec.data(), d[ENT], rec.size()));
+        packed.push_back(key ? 'K' : 'P');
+        put_varint(packed, (unsigned)rec.size());
+        packed.insert(packed.end(), rec.begin(), rec.end());
       }
       fprintf(out, "SEG %d %zu\n", n, packed.size());
       if (fwrite(packed.data(), 1, packed.size(), out) != packed.size()) { *err = job.output + ": No space left on device"; code = 1; goto done; }
