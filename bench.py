@@ -90,10 +90,11 @@ def entropy_leg(ctx, pipe, args, launches=5, host_seconds=6.0):
     recs = pipe.coded_records()
     code_ms = prof["entropy_code"][1] / prof["entropy_code"][0]
     pack_ms = prof["entropy_pack"][1] / prof["entropy_pack"][0]
+    tok_ms = prof["entropy_tokens"][1] / prof["entropy_tokens"][0]
     out = {"syntax": "own (AV1 range-coder arithmetic + CDF adaptation, spec 8.2.6); not an AV1 bitstream",
            "tile": pipe.entropy_tile, "bytes_per_frame": sum(len(r) for r in recs) / len(recs),
-           "gpu": {"code_ms_per_launch": code_ms, "pack_ms_per_launch": pack_ms, "frames_per_launch": pipe.frames,
-                   "frames_per_s": pipe.frames / ((code_ms + pack_ms) * 1e-3),
+           "gpu": {"tokens_ms_per_launch": tok_ms, "code_ms_per_launch": code_ms, "pack_ms_per_launch": pack_ms,
+                   "frames_per_launch": pipe.frames, "frames_per_s": pipe.frames / ((tok_ms + code_ms + pack_ms) * 1e-3),
                    "levels_GBps": 2 * pipe.samples / (code_ms * 1e-3) / 1e9}}
     host = os.path.join(ROOT, "av1-go_amd", "host", "libav1mi_host.so")
     if os.path.exists(host):
