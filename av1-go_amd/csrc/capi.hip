@@ -83,6 +83,7 @@ void prof_drain(av1mi_ctx *ctx) {
 }
 
 bool tx_valid(int tx_size, int tx_type) {
+  if (tx_type == AV1MI_WHT_WHT) return tx_size == AV1MI_TX_4X4;
   if (tx_size < 0 || tx_size >= AV1MI_TX_SIZES_ALL || tx_type < 0 || tx_type >= AV1MI_TX_TYPES) return false;
   const int w = av1mi::tx_width(tx_size), h = av1mi::tx_height(tx_size);
   static const int colk[16] = { 0, 1, 0, 1, 2, 0, 2, 1, 2, 3, 0, 3, 1, 3, 2, 3 };

@@ -296,6 +296,23 @@ template <int N> AV1MI_DI void identity(int32_t *x) {
 }
 
 enum { T1D_DCT = 0, T1D_ADST = 1, T1D_FLIPADST = 2, T1D_IDTX = 3 };
+constexpr int kWhtType = 16;   // AV1MI_WHT_WHT: lossless 4x4 Walsh-Hadamard, handled apart from the kind tables
+// spec 7.13.2.10 on (T[0], T[1], T[2], T[3]) = x[0..3]
+AV1MI_DI void iwht4(int32_t *x, int shift) {
+  int32_t a = x[0] >> shift, c = x[1] >> shift, d = x[2] >> shift, b = x[3] >> shift;
+  a += c; d -= b;
+  const int32_t e = (a - d) >> 1;
+  b = e - b; c = e - c; a -= b; d += c;
+  x[0] = a; x[1] = b; x[2] = c; x[3] = d;
+}
+// libaom av1_fwht4x4_c butterfly: outputs in the order (a, c, d, b)
+AV1MI_DI void fwht4(int32_t *x) {
+  int32_t a = x[0], b = x[1], c = x[2], d = x[3];
+  a += b; d -= c;
+  const int32_t e = (a - d) >> 1;
+  b = e - b; c = e - c; a -= c; d += b;
+  x[0] = a; x[1] = c; x[2] = d; x[3] = b;
+}
 // TX_TYPE -> vertical (column) / horizontal (row) 1-D kind, packed 2 bits each (libaom vtx_tab/htx_tab)
 AV1MI_HD int col_kind(int tx_type) {
   constexpr int t[16] = { 0, 1, 0, 1, 2, 0, 2, 1, 2, 3, 0, 3, 1, 3, 2, 3 };

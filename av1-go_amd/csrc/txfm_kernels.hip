@@ -79,6 +79,7 @@ __global__ __launch_bounds__(256) void k_inv_txfm_add(TxLaunch L) {
   int tx_type = 0;
   if (live) resolve_block(L, b, W, H, CW * CH, coef_off, pix_off, tx_type);
   const int rk = row_kind(tx_type), ck = col_kind(tx_type);
+  const bool wht = W == 4 && H == 4 && tx_type == kWhtType;   // lossless: no clamps, no rounding, no final shift
 
   // phase 0: coalesced 16-byte loads HBM -> LDS tile (rows 0..CH-1, cols 0..CW-1)
   if (live) {
@@ -110,9 +111,10 @@ __global__ __launch_bounds__(256) void k_inv_txfm_add(TxLaunch L) {
         v = min(max(v, -(1 << ROW_RANGE)), 1 << ROW_RANGE);
         v = (__mul24(v, kNewInvSqrt2) + 2048) >> 12;
       }
-      x[c] = clampr<ROW_RANGE>(v);
+      x[c] = wht ? v : clampr<ROW_RANGE>(v);
     }
-    inv1d<W, ROW_RANGE>(x, rk);
+    if constexpr (W == 4 && H == 4) { if (wht) iwht4(x, 2); else inv1d<W, ROW_RANGE>(x, rk); }
+    else inv1d<W, ROW_RANGE>(x, rk);
     constexpr int rsh = inv_row_shift(W, H);
 #pragma unroll
     for (int c = 0; c < W; c += 4) {
@@ -127,13 +129,14 @@ __global__ __launch_bounds__(256) void k_inv_txfm_add(TxLaunch L) {
     int32_t x[H];
     const int sc = rk == T1D_FLIPADST ? W - 1 - lane : lane;
 #pragma unroll
-    for (int r = 0; r < H; r++) x[r] = r < CH ? clampr<COL_RANGE>(tile[r * RS + sc]) : 0;
-    inv1d<H, COL_RANGE>(x, ck);
+    for (int r = 0; r < H; r++) x[r] = r < CH ? (wht ? tile[r * RS + sc] : clampr<COL_RANGE>(tile[r * RS + sc])) : 0;
+    if constexpr (W == 4 && H == 4) { if (wht) iwht4(x, 0); else inv1d<H, COL_RANGE>(x, ck); }
+    else inv1d<H, COL_RANGE>(x, ck);
     __builtin_amdgcn_wave_barrier();   // all lanes of the block have read their column (same wave)
     const bool ud = ck == T1D_FLIPADST;
 #pragma unroll
     for (int r = 0; r < H; r++) {
-      const int32_t v = round2(x[r], 4);
+      const int32_t v = wht ? x[r] : round2(x[r], 4);
       tile[(ud ? H - 1 - r : r) * RS + lane] = v;
     }
   }
@@ -172,6 +175,7 @@ __global__ __launch_bounds__(256) void k_fwd_txfm(TxLaunch L) {
   int tx_type = 0;
   if (live) resolve_block(L, b, W, H, CW * CH, coef_off, pix_off, tx_type);
   const int rk = row_kind(tx_type), ck = col_kind(tx_type);
+  const bool wht = W == 4 && H == 4 && tx_type == kWhtType;
   // phase 0: residual rows -> LDS (4 samples = 8 bytes per lane per step)
   if (live) {
     const int16_t *src = reinterpret_cast<const int16_t *>(L.plane) + pix_off;
@@ -190,13 +194,14 @@ __global__ __launch_bounds__(256) void k_fwd_txfm(TxLaunch L) {
     int32_t x[H];
     const bool ud = ck == T1D_FLIPADST;
 #pragma unroll
-    for (int r = 0; r < H; r++) x[r] = tile[(ud ? H - 1 - r : r) * RS + lane] << fwd_shift(W, H, 0);
-    fwd1d<H, fwd_cos_bit_col(W, H)>(x, ck);
+    for (int r = 0; r < H; r++) x[r] = tile[(ud ? H - 1 - r : r) * RS + lane] << (wht ? 0 : fwd_shift(W, H, 0));
+    if constexpr (W == 4 && H == 4) { if (wht) fwht4(x); else fwd1d<H, fwd_cos_bit_col(W, H)>(x, ck); }
+    else fwd1d<H, fwd_cos_bit_col(W, H)>(x, ck);
     __builtin_amdgcn_wave_barrier();
     const int dc = rk == T1D_FLIPADST ? W - 1 - lane : lane;
     constexpr int s1 = -fwd_shift(W, H, 1);
 #pragma unroll
-    for (int r = 0; r < H; r++) tile[r * RS + dc] = round2(x[r], s1);
+    for (int r = 0; r < H; r++) tile[r * RS + dc] = wht ? x[r] : round2(x[r], s1);
   }
   __syncthreads();
   // phase 2: rows (only the CH stored rows)
@@ -207,7 +212,8 @@ __global__ __launch_bounds__(256) void k_fwd_txfm(TxLaunch L) {
       const int4 v = *reinterpret_cast<const int4 *>(tile + lane * RS + c);
       x[c] = v.x; x[c + 1] = v.y; x[c + 2] = v.z; x[c + 3] = v.w;
     }
-    fwd1d<W, fwd_cos_bit_row(W, H)>(x, rk);
+    if constexpr (W == 4 && H == 4) { if (wht) { fwht4(x); x[0] *= 4; x[1] *= 4; x[2] *= 4; x[3] *= 4; } else fwd1d<W, fwd_cos_bit_row(W, H)>(x, rk); }
+    else fwd1d<W, fwd_cos_bit_row(W, H)>(x, rk);
     constexpr int s2 = -fwd_shift(W, H, 2);
 #pragma unroll
     for (int c = 0; c < CW; c++) {

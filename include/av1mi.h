@@ -41,7 +41,8 @@ enum av1mi_tx_size {
 enum av1mi_tx_type {
   AV1MI_DCT_DCT, AV1MI_ADST_DCT, AV1MI_DCT_ADST, AV1MI_ADST_ADST, AV1MI_FLIPADST_DCT, AV1MI_DCT_FLIPADST,
   AV1MI_FLIPADST_FLIPADST, AV1MI_ADST_FLIPADST, AV1MI_FLIPADST_ADST, AV1MI_IDTX, AV1MI_V_DCT, AV1MI_H_DCT,
-  AV1MI_V_ADST, AV1MI_H_ADST, AV1MI_V_FLIPADST, AV1MI_H_FLIPADST, AV1MI_TX_TYPES
+  AV1MI_V_ADST, AV1MI_H_ADST, AV1MI_V_FLIPADST, AV1MI_H_FLIPADST, AV1MI_TX_TYPES,
+  AV1MI_WHT_WHT = 16   /* lossless blocks: 4x4 Walsh-Hadamard (spec 7.13.2.10), valid with AV1MI_TX_4X4 only */
 };
 
 typedef struct av1mi_ctx av1mi_ctx;

@@ -38,6 +38,7 @@ enum {
   V_ADST, H_ADST, V_FLIPADST, H_FLIPADST, TX_TYPES
 };
 enum { T1D_DCT, T1D_ADST, T1D_FLIPADST, T1D_IDTX };
+#define AV1O_WHT_WHT 16   /* not a TX_TYPE of the spec: selects the lossless 4x4 Walsh-Hadamard path */
 
 extern const int av1o_tx_w[TX_SIZES_ALL];
 extern const int av1o_tx_h[TX_SIZES_ALL];

@@ -344,6 +344,7 @@ static int row_1d(int tx_type) {
 }
 /* 1: the (size,type) pair is arithmetically defined: ADST needs length 4/8/16, IDTX length <= 32. */
 int av1o_txfm_valid(int tx_size, int tx_type) {
+  if (tx_type == AV1O_WHT_WHT) return tx_size == TX_4X4;   /* lossless blocks: Walsh-Hadamard, 4x4 only (spec 7.13.3) */
   if (tx_size < 0 || tx_size >= TX_SIZES_ALL || tx_type < 0 || tx_type >= TX_TYPES) return 0;
   const int w = av1o_tx_w[tx_size], h = av1o_tx_h[tx_size];
   const int r = row_1d(tx_type), c = col_1d(tx_type);
@@ -368,6 +369,54 @@ static void fwd_1d(int kind, const int32_t *in, int32_t *out, int N, int bit) {
   else av1o_fadst16(in, out, bit);
 }
 
+/*
+ * Lossless 4x4: spec 7.13.2.10 (inverse Walsh-Hadamard transform process) applied as 7.13.3 prescribes for Lossless —
+ * rows with shift 2, columns with shift 0, no intermediate rounding, the result is the residual itself (no final shift)
+ * == libaom av1_iwht4x4_16_add_c / av1_highbd_iwht4x4_16_add_c.  Forward: libaom av1_fwht4x4_c (UNIT_QUANT_FACTOR 4).
+ */
+static void iwht4(int32_t *a, int32_t *b, int32_t *c, int32_t *d, int shift) {   /* in: T[0], T[3], T[1], T[2] order of the spec */
+  int32_t e;
+  *a >>= shift; *c >>= shift; *d >>= shift; *b >>= shift;
+  *a += *c; *d -= *b; e = (*a - *d) >> 1; *b = e - *b; *c = e - *c; *a -= *b; *d += *c;
+}
+static int inv_wht4x4_add(const int32_t *coef, void *dst, int stride, int bd) {
+  int32_t t[16];
+  const int maxpix = (1 << bd) - 1;
+  for (int r = 0; r < 4; r++) {
+    int32_t a = coef[r * 4], c = coef[r * 4 + 1], d = coef[r * 4 + 2], b = coef[r * 4 + 3];
+    iwht4(&a, &b, &c, &d, 2);
+    t[r * 4] = a; t[r * 4 + 1] = b; t[r * 4 + 2] = c; t[r * 4 + 3] = d;
+  }
+  for (int col = 0; col < 4; col++) {
+    int32_t a = t[col], c = t[4 + col], d = t[8 + col], b = t[12 + col];
+    iwht4(&a, &b, &c, &d, 0);
+    const int32_t res[4] = { a, b, c, d };
+    for (int r = 0; r < 4; r++) {
+      if (bd == 8) { uint8_t *p = (uint8_t *)dst + (size_t)r * stride + col; *p = (uint8_t)av1o_clampi(*p + res[r], 0, maxpix); }
+      else { uint16_t *p = (uint16_t *)dst + (size_t)r * stride + col; *p = (uint16_t)av1o_clampi(*p + res[r], 0, maxpix); }
+    }
+  }
+  return 0;
+}
+static void fwht4(int32_t *a, int32_t *b, int32_t *c, int32_t *d) {
+  int32_t e;
+  *a += *b; *d -= *c; e = (*a - *d) >> 1; *b = e - *b; *c = e - *c; *a -= *c; *d += *b;
+}
+static int fwd_wht4x4(const int16_t *resid, int stride, int32_t *coef) {
+  int32_t t[16];
+  for (int col = 0; col < 4; col++) {
+    int32_t a = resid[col], b = resid[stride + col], c = resid[2 * stride + col], d = resid[3 * stride + col];
+    fwht4(&a, &b, &c, &d);
+    t[col] = a; t[4 + col] = c; t[8 + col] = d; t[12 + col] = b;
+  }
+  for (int r = 0; r < 4; r++) {
+    int32_t a = t[r * 4], b = t[r * 4 + 1], c = t[r * 4 + 2], d = t[r * 4 + 3];
+    fwht4(&a, &b, &c, &d);
+    coef[r * 4] = a * 4; coef[r * 4 + 1] = c * 4; coef[r * 4 + 2] = d * 4; coef[r * 4 + 3] = b * 4;
+  }
+  return 0;
+}
+
 /* spec Transform_Row_Shift[] == -libaom av1_inv_txfm_shift_ls[][0]. */
 static const int inv_row_shift[TX_SIZES_ALL] = { 0, 1, 2, 2, 2, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2 };
 
@@ -383,6 +432,7 @@ static int rect_log_ratio(int w, int h) { return ilog2(w) - ilog2(h); }
 int av1o_inv_txfm2d_add(const int32_t *coef, void *dst, int stride, int tx_size, int tx_type, int bd,
                         int libaom_clamps) {
   if (!av1o_txfm_valid(tx_size, tx_type)) return -1;
+  if (tx_type == AV1O_WHT_WHT) return inv_wht4x4_add(coef, dst, stride, bd);
   const int w = av1o_tx_w[tx_size], h = av1o_tx_h[tx_size];
   const int cw = w > 32 ? 32 : w, ch = h > 32 ? 32 : h;
   const int rkind = row_1d(tx_type), ckind = col_1d(tx_type);
@@ -445,6 +495,7 @@ static int32_t shift_val(int32_t v, int sh) { /* libaom av1_round_shift_array: s
 int av1o_fwd_txfm2d(const int16_t *resid, int stride, int32_t *coef, int tx_size, int tx_type, int bd) {
   (void)bd;
   if (!av1o_txfm_valid(tx_size, tx_type)) return -1;
+  if (tx_type == AV1O_WHT_WHT) return fwd_wht4x4(resid, stride, coef);
   const int w = av1o_tx_w[tx_size], h = av1o_tx_h[tx_size];
   const int cw = w > 32 ? 32 : w, ch = h > 32 ? 32 : h;
   const int rkind = row_1d(tx_type), ckind = col_1d(tx_type);

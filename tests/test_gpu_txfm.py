@@ -119,6 +119,41 @@ def test_fwd_grid_all_sizes(ctx, O):
                 assert (got[b] == exp).all(), (O.TX_NAMES[ts], O.TX_TYPE_NAMES[tts[b]], amp)
 
 
+@pytest.mark.parametrize("bd", [8, 10])
+def test_wht_lossless_blocks(ctx, O, bd):
+    """tx_type AV1MI_WHT_WHT (16) on 4x4 grids, mixed with the 16 regular types per block: GPU == oracle both ways, and the
+    GPU pair alone reconstructs every residual exactly"""
+    rng = np.random.default_rng(40 + bd)
+    nbx, nby = 9, 7
+    amp = (1 << bd) - 1
+    tts = rng.choice(np.array(list(range(17)), np.uint8), nbx * nby)
+    tts[::2] = 16
+    res = rng.integers(-amp, amp + 1, (nby * 4, nbx * 4)).astype(np.int16)
+    d_res, d_types = ctx.to_device(res), ctx.to_device(tts)
+    d_coef = ctx.alloc(nbx * nby * 16 * 4)
+    ctx.fwd_txfm_grid(0, d_res, res.shape[1], d_coef, nbx, nbx * nby, d_types)
+    coef = d_coef.download((nbx * nby, 4, 4), np.int32)
+    dt = np.uint8 if bd == 8 else np.uint16
+    pred = rng.integers(0, 1 << bd, res.shape).astype(dt)
+    d_plane = ctx.to_device(pred)
+    ctx.inv_txfm_add_grid(0, d_coef, d_plane, pred.shape[1], bd, nbx, nbx * nby, d_types)
+    got = d_plane.download(pred.shape, dt)
+    for b in range(nbx * nby):
+        by, bx = divmod(b, nbx)
+        sl = (slice(by * 4, by * 4 + 4), slice(bx * 4, bx * 4 + 4))
+        assert (coef[b] == O.fwd_txfm2d(res[sl], 0, int(tts[b]))).all(), (b, tts[b])
+        assert (got[sl] == O.inv_txfm2d_add(coef[b], pred[sl], 0, int(tts[b]), bd)).all(), (b, tts[b])
+        if tts[b] == 16:
+            assert (got[sl].astype(np.int64) == np.clip(pred[sl].astype(np.int64) + res[sl], 0, amp)).all()
+    for b in (d_res, d_types, d_coef, d_plane):
+        b.free()
+    # uniform-type form and the validity rule
+    d = ctx.alloc(64 * 64 * 4)
+    with pytest.raises(Exception):
+        ctx.inv_txfm_add_grid(1, d, d, 8, 8, 1, 1, None, 16)      # WHT is defined for 4x4 only
+    d.free()
+
+
 def test_full_frame_round_trip_1080p(ctx, O):
     """BASELINE size, size-independent property: inv(fwd(residual)) reconstructs within +-2 on a whole
     1920x1088 8-bit plane of 8x8 DCT blocks, and the GPU result equals the oracle on sampled blocks."""

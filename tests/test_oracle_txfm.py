@@ -61,7 +61,8 @@ def test_valid_combinations(O):
     assert n == 193
     assert O.txfm_valid(4, 0) and not O.txfm_valid(4, 1) and not O.txfm_valid(4, 9)  # 64x64: DCT only
     assert O.txfm_valid(3, 9) and not O.txfm_valid(3, 3)  # 32x32: DCT + identity
-    assert not O.txfm_valid(19, 0) and not O.txfm_valid(0, 16)
+    assert not O.txfm_valid(19, 0) and not O.txfm_valid(0, 17)
+    assert O.txfm_valid(0, 16) and not any(O.txfm_valid(ts, 16) for ts in range(1, 19))   # WHT: lossless 4x4 only
 
 
 def test_inverse_of_forward_round_trip(O):
@@ -79,6 +80,38 @@ def test_inverse_of_forward_round_trip(O):
             coef = O.fwd_txfm2d(res, ts, tt)
             rec = O.inv_txfm2d_add(coef, np.full((h, w), 512, np.uint16), ts, tt, 10).astype(np.int32) - 512
             assert np.abs(rec - res).max() <= 2, (O.TX_NAMES[ts], O.TX_TYPE_NAMES[tt])
+
+
+def _spec_iwht_1d(t, shift):
+    """AV1 spec 7.13.2.10, written out independently of the C oracle"""
+    a, c, d, b = t[0] >> shift, t[1] >> shift, t[2] >> shift, t[3] >> shift
+    a += c
+    d -= b
+    e = (a - d) >> 1
+    b = e - b
+    c = e - c
+    a -= b
+    d += c
+    return [a, b, c, d]
+
+
+def test_wht_lossless_4x4(O):
+    """spec 7.13.3 for Lossless: rows with shift 2, columns with shift 0, no rounding, no final shift; and the forward
+    transform the encoder pairs with it reconstructs EVERY residual exactly (that is what lossless means)"""
+    rng = np.random.default_rng(3)
+    for bd, amp in ((8, 255), (10, 1023)):
+        for _ in range(300):
+            res = rng.integers(-amp, amp + 1, (4, 4)).astype(np.int16)
+            coef = O.fwd_txfm2d(res, 0, 16)
+            assert (coef % 4 == 0).all()                                  # UNIT_QUANT_FACTOR
+            pred = rng.integers(0, 1 << bd, (4, 4)).astype(np.uint8 if bd == 8 else np.uint16)
+            rec = O.inv_txfm2d_add(coef, pred, 0, 16, bd).astype(np.int64)
+            assert (rec == np.clip(pred.astype(np.int64) + res, 0, (1 << bd) - 1)).all()
+            rows = np.array([_spec_iwht_1d([int(v) for v in coef[r]], 2) for r in range(4)])
+            cols = np.array([_spec_iwht_1d([int(v) for v in rows[:, c]], 0) for c in range(4)]).T
+            assert (cols == res).all()
+    flat = O.fwd_txfm2d(np.full((4, 4), 7, np.int16), 0, 16)
+    assert flat[0, 0] == 7 * 16 and np.count_nonzero(flat) == 1           # DC gain 16, nothing else
 
 
 def test_dc_only_block_is_flat(O):
