@@ -77,4 +77,24 @@ int av1mi_host_entropy_final_models(int w, int h, int key, const int16_t *ly, co
   memcpy(out, &m, sizeof(m));
   return (int)(sizeof(m) / 2);
 }
+// RunJobPool over `n` source files joined with '\n'; statuses joined with '\n' into buf; returns the number of successes
+int av1mi_host_job_pool(const char *sources, int workers, int ngpus, double ratio, const char *state_dir, char *buf, int cap) {
+  std::vector<Job> jobs; std::string s = sources; size_t p = 0, q;
+  auto add = [&](const std::string &path) {
+    Job j; j.ID = "pool" + std::to_string(jobs.size()); j.SourcePath = path;
+    FILE *f = fopen(path.c_str(), "rb");
+    if (f) { fseek(f, 0, SEEK_END); j.OriginalSize = ftell(f); fclose(f); }
+    jobs.push_back(j);
+  };
+  while ((q = s.find('\n', p)) != std::string::npos) { add(s.substr(p, q - p)); p = q + 1; }
+  add(s.substr(p));
+  TranscodeConfig cfg; cfg.MaxSizeRatio = ratio; cfg.JobStateDir = state_dir ? state_dir : ""; cfg.StableWaitSeconds = 0;
+  ProbeResult pr; pr.HasVideo = true; pr.has_video_stream = true; pr.VideoStream.Height = 720;
+  std::vector<std::string> errs;
+  const PoolStats ps = RunJobPool(&jobs, workers, ngpus, pr, cfg, &errs);
+  std::string out;
+  for (size_t i = 0; i < jobs.size(); i++) out += (i ? "\n" : "") + jobs[i].Status + (errs[i].empty() ? "" : ": " + errs[i]);
+  strncpy(buf, out.c_str(), cap - 1); buf[cap - 1] = 0;
+  return ps.succeeded;
+}
 }

@@ -1,5 +1,8 @@
 // daemon.cpp — see daemon.hpp.
 #include "daemon.hpp"
+#include <atomic>
+#include <chrono>
+#include <thread>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <cerrno>
@@ -68,6 +71,7 @@ std::string ProcessJob(Job *job, const std::string &backendPath, const ProbeResu
     job->Status = "failed"; job->Reason = "failed to build ffmpeg args: " + err; save_job(*job, cfg.JobStateDir);
     return "failed to build transcode args: " + err;
   }
+  if (cfg.Device) { const std::string out = args.back(); args.back() = "-av1mi_device"; args.push_back(std::to_string(cfg.Device)); args.push_back(out); }
   const RunResult rr = RunTranscode(backendPath, args);                                                                                 // :101
   if (!rr.err.empty() || rr.exitCode != 0) {                                                                                            // :102-112
     job->Status = "failed"; job->Reason = "ffmpeg exit code " + std::to_string(rr.exitCode) + ": " + rr.err;
@@ -105,6 +109,28 @@ std::string ProcessJob(Job *job, const std::string &backendPath, const ProbeResu
   job->Status = "success";                                                                                                             // :176-179
   save_job(*job, cfg.JobStateDir);
   return "";
+}
+
+PoolStats RunJobPool(std::vector<Job> *jobs, int workers, int ngpus, const ProbeResult &probeResult, const TranscodeConfig &cfg,
+                     std::vector<std::string> *errors) {
+  PoolStats st;
+  if (workers < 1) workers = 1;
+  if (ngpus < 1) ngpus = 1;
+  errors->assign(jobs->size(), "");
+  std::atomic<size_t> next{0};
+  const auto t0 = std::chrono::steady_clock::now();
+  auto work = [&](int w) {
+    TranscodeConfig mine = cfg;
+    mine.Device = w % ngpus;
+    for (size_t i; (i = next.fetch_add(1)) < jobs->size();) (*errors)[i] = ProcessJob(&(*jobs)[i], "av1mi", probeResult, mine);
+  };
+  std::vector<std::thread> pool;
+  for (int w = 1; w < workers; w++) pool.emplace_back(work, w);
+  work(0);
+  for (auto &t : pool) t.join();
+  st.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  for (const Job &j : *jobs) { st.succeeded += j.Status == "success"; st.skipped += j.Status == "skipped"; st.failed += j.Status == "failed"; }
+  return st;
 }
 
 }  // namespace av1mi_host

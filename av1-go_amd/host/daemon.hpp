@@ -3,6 +3,7 @@
 #pragma once
 #include <cstdint>
 #include <string>
+#include <vector>
 #include "transcode.hpp"
 
 namespace av1mi_host {
@@ -16,10 +17,21 @@ struct Job {                       // jobs.Job, the fields ProcessJob reads or w
   int64_t OriginalSize = 0, NewSize = 0;
   bool IsWebRipLike = false;
 };
-struct TranscodeConfig { std::string JobStateDir; double MaxSizeRatio = 0.90; int StableWaitSeconds = 10; };   // daemon.go:185-188
+struct TranscodeConfig {           // daemon.go:185-188; Device is this backend's addition (which GPU runs the job)
+  std::string JobStateDir; double MaxSizeRatio = 0.90; int StableWaitSeconds = 10; int Device = 0;
+};
 
 // daemon.go:57-182.  Returns "" where the reference returns nil, else the error text; job.Status / job.Reason are
 // updated exactly as upstream ("running" -> "success" | "failed" | "skipped").
 std::string ProcessJob(Job *job, const std::string &backendPath, const ProbeResult &probeResult, const TranscodeConfig &cfg);
+
+// The job loop of cmd/av1d/main.go:291-349, which the reference runs serially on one device, as a pool of `workers`
+// threads (BASELINE config 5: 8 concurrent jobs, one per GPU).  Worker i owns GPU
+// i % ngpus (its own av1mi context and stream, nothing shared, no GPU<->GPU traffic) and pulls the next pending job.
+// Every job goes through ProcessJob unchanged, so the job JSON files keep being written the way av1top expects.
+// errors[i] = what ProcessJob returned for jobs[i].  Returns the number of jobs that ended in "success".
+struct PoolStats { int succeeded = 0, skipped = 0, failed = 0; double seconds = 0; };
+PoolStats RunJobPool(std::vector<Job> *jobs, int workers, int ngpus, const ProbeResult &probeResult, const TranscodeConfig &cfg,
+                     std::vector<std::string> *errors);
 
 }  // namespace av1mi_host

@@ -151,3 +151,42 @@ def test_run_transcode_and_process_job_on_gpu(host, tmp_path):
     assert (tmp_path / "other.av1qsvd-why.txt").exists() and not (tmp_path / "other.av1-tmp.mkv").exists() and src2.stat().st_size == orig
     assert host.av1mi_host_process_job(str(src).encode(), orig, 5.0, str(tmp_path).encode(), 0, status, reason, 256) == 0
     assert status.value == b"success" and src.read_bytes().startswith(b"AV1MI2 ") and (tmp_path / "test.json").exists()
+
+
+def _pool(host, paths, workers, ngpus, ratio, state):
+    host.av1mi_host_job_pool.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_double, C.c_char_p, C.c_char_p, C.c_int]
+    buf = C.create_string_buffer(8192)
+    n = host.av1mi_host_job_pool("\n".join(paths).encode(), workers, ngpus, ratio, str(state).encode(), buf, 8192)
+    return n, buf.value.decode().split("\n")
+
+
+def test_job_pool_runs_every_job_even_when_the_backend_cannot_run(host, tmp_path, av1mi):
+    """the worker pool that replaces the serial loop of cmd/av1d/main.go:291-349: every job is visited exactly once and
+    its record written, whatever happens to it (here: no GPU / missing inputs)"""
+    paths = [str(tmp_path / ("clip%d.y4m" % i)) for i in range(5)]
+    n, status = _pool(host, paths, 3, 2, 0.9, tmp_path)
+    assert n == 0 and len(status) == 5
+    # missing sources: the reference's stability check fails first (daemon.go:59-62) -> error returned, job left pending
+    assert all(s.startswith("pending: failed to check file stability") for s in status)
+
+
+@pytest.mark.gpu
+def test_job_pool_concurrent_contexts_are_deterministic(host, tmp_path):
+    """BASELINE config 5 in miniature: 4 jobs on 3 workers (all on GPU 0 here, one context + stream each).  Concurrent
+    contexts must not disturb each other: every output equals the one a lone job produces."""
+    clips = []
+    for i in range(4):
+        p = tmp_path / ("c%d.y4m" % i)
+        _write_y4m(str(p), 192, 128, 4)
+        clips.append(p)
+    solo = tmp_path / "solo.y4m"
+    solo.write_bytes(clips[0].read_bytes())
+    n, status = _pool(host, [str(solo)], 1, 1, 5.0, tmp_path)
+    assert n == 1 and status == ["success"]
+    ref = solo.read_bytes()
+    assert ref.startswith(b"AV1MI2 ")
+    n, status = _pool(host, [str(c) for c in clips], 3, 1, 5.0, tmp_path)
+    assert n == 4 and status == ["success"] * 4
+    for i, c in enumerate(clips):
+        assert c.read_bytes() == ref, "job %d differs from the solo run" % i
+        assert (tmp_path / ("pool%d.json" % i)).exists()
