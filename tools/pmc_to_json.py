@@ -39,6 +39,7 @@ for k, d in load(tag).items():
     if "FETCH_SIZE" not in d and "WRITE_SIZE" not in d:
         continue
     res["kernels"][k] = {"FETCH_SIZE_KB_per_launch": d.get("FETCH_SIZE"), "WRITE_SIZE_KB_per_launch": d.get("WRITE_SIZE"),
-                         "fetch_bytes_uncorrected": d.get("FETCH_SIZE", 0) * 1024, "write_bytes": d.get("WRITE_SIZE", 0) * 1024}
+                         "fetch_bytes_uncorrected": d.get("FETCH_SIZE", 0) * 1024, "write_bytes": d.get("WRITE_SIZE", 0) * 1024,
+                         "sq_counters_per_launch": {c: v for c, v in sorted(d.items()) if c not in ("FETCH_SIZE", "WRITE_SIZE")}}
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1)[:3000])
