@@ -189,14 +189,22 @@ __global__ __launch_bounds__(256, BS == 8 ? 3 : 1) void k_intra_pipe(IntraPipeLa
     if (have_left) { const int m = mode_y[by * N + bx - 1], mc = mode_c[by * N + bx - 1]; ft |= m >= 9 && m <= 11; ftc |= mc >= 9 && mc <= 11; }
     const size_t blk = (size_t)fy * bw + fx;
     {
+#ifdef AV1MI_EXP_TILED   // timing experiment only (wrong pixels): planes addressed as if block-tiled, 64 contiguous bytes per block
+      const size_t off = blk * BS * BS + lane * BS;
+#else
       const size_t off = ((size_t)fy * BS + lane) * L.stride_y + (size_t)fx * BS;
+#endif
       const int m = code_block<BS, BS, Pix>(Y, lane, bx, by, N, have_top ? BS : 0, have_tr ? BS : 0, have_left ? BS : 0,
                                              have_bl ? BS : 0, ft, L.dc_q, L.ac_q, src_y + off, rec_y + off,
                                              lev_y + blk * BS * BS + lane * BS STAMP_PASS);
       if (lane == 0) { modes_y[blk] = (uint8_t)m; mode_y[by * N + bx] = (uint8_t)m; }
     }
     {
+#ifdef AV1MI_EXP_TILED
+      const size_t off = blk * CS * CS + cl * CS;
+#else
       const size_t off = ((size_t)fy * CS + cl) * L.stride_uv + (size_t)fx * CS;
+#endif
       const int m = code_block<CS, BS, Pix>(Cp, cl, bx, by, N, have_top ? CS : 0, have_tr ? CS : 0, have_left ? CS : 0,
                                              have_bl ? CS : 0, ftc, L.dc_q, L.ac_q, src_c + off, rec_c + off,
                                              lev_c + blk * CS * CS + cl * CS STAMP_PASS);
