@@ -3,7 +3,7 @@
 //
 // The workgroup stages the deblocked luma block with a 2-sample halo (and both chroma blocks likewise) in LDS as
 // uint16, samples outside the picture stored as 0xFFFF = "not available" (taps skip them, as the spec's
-// CdefAvailable).  Wave 0 then runs the direction search, one 8x8 block per lane with every bin index a
+// CdefAvailable: in the packed filter a marked tap is replaced by the centre sample).  Wave 0 then runs the direction search, one 8x8 block per lane with every bin index a
 // compile-time constant; afterwards all 256 lanes filter: 16 luma + 8 chroma samples each, 12 taps per sample
 // read from LDS.  Output goes to separate planes, so taps never see filtered samples and superblocks are
 // independent.  HBM traffic: b*S read + b*S written (= 2b*S of SURVEY.md §8d); halo re-reads hit L2.
@@ -21,75 +21,68 @@ __device__ constexpr int8_t kCdefDir[8][2][2] = {
   { { 1, 1 }, { 2, 2 } },   { { 1, 0 }, { 2, 1 } },  { { 1, 0 }, { 2, 0 } }, { { 1, 0 }, { 2, -1 } } };
 
 __device__ __forceinline__ int msb(unsigned v) { return 31 - __clz(v); }
-__device__ __forceinline__ int cdef_constrain(int diff, int threshold, int shift) {
-  const int mag = abs(diff);
-  const int v = min(mag, max(0, threshold - (mag >> shift)));
-  return diff < 0 ? -v : v;
-}
-
-// one sample: p = centre pointer in an LDS tile with row stride LS
-template <int LS>
-__device__ __forceinline__ int cdef_sample(const uint16_t *p, int pri, int sec, int damping, int dir, int cs) {
-  const int x = *p;
-  int sum = 0, mx = x, mn = x;
-  const int pshift = pri ? max(0, damping - msb(pri)) : 0, sshift = sec ? max(0, damping - msb(sec)) : 0;
-  const int pt0 = ((pri >> cs) & 1) ? 3 : 4, pt1 = ((pri >> cs) & 1) ? 3 : 2;
-#pragma unroll
-  for (int k = 0; k < 2; k++) {
-    const int o0 = kCdefDir[dir][k][0] * LS + kCdefDir[dir][k][1];
-    const int o1 = kCdefDir[(dir + 2) & 7][k][0] * LS + kCdefDir[(dir + 2) & 7][k][1];
-    const int o2 = kCdefDir[(dir + 6) & 7][k][0] * LS + kCdefDir[(dir + 6) & 7][k][1];
-    const int ptap = k ? pt1 : pt0, stap = k ? 1 : 2;
-#pragma unroll
-    for (int sg = 0; sg < 2; sg++) {
-      const int a = sg ? p[o0] : p[-o0], b = sg ? p[o1] : p[-o1], c = sg ? p[o2] : p[-o2];
-      if (a != 0xFFFF) { if (pri) sum += ptap * cdef_constrain(a - x, pri, pshift); mx = max(mx, a); mn = min(mn, a); }
-      if (b != 0xFFFF) { if (sec) sum += stap * cdef_constrain(b - x, sec, sshift); mx = max(mx, b); mn = min(mn, b); }
-      if (c != 0xFFFF) { if (sec) sum += stap * cdef_constrain(c - x, sec, sshift); mx = max(mx, c); mn = min(mn, c); }
-    }
-  }
-  return min(max(x + ((8 + sum - (sum < 0)) >> 4), mn), mx);
-}
-
-// Four horizontally adjacent samples at once with packed 16-bit VALU (v_pk_*_i16: two samples per lane-op); used where
-// every tap is inside the picture (no 0xFFFF sentinels in the tile), i.e. for all but the picture-border superblocks.
+// Four horizontally adjacent samples at once with packed 16-bit VALU (v_pk_*_i16: two samples per lane-op).  SENT = the
+// tile may hold 0xFFFF "outside the picture" marks (picture-border superblocks): two more ops per tap pair.
 // p: 4-byte aligned centre pointer (first of the four samples) in an LDS tile with even row stride LS.
 typedef short v2s __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ v2s pk_constrain(v2s diff, int thr, int shift) {
-  const v2s mag = __builtin_elementwise_max(diff, -diff);
-  v2s t = (v2s){ (short)thr, (short)thr } - (mag >> (v2s){ (short)shift, (short)shift });
-  t = __builtin_elementwise_max(t, (v2s){ 0, 0 });
-  const v2s m = __builtin_elementwise_min(mag, t), sgn = diff >> (v2s){ 15, 15 };
-  return (m ^ sgn) - sgn;
+typedef unsigned short v2u __attribute__((ext_vector_type(2)));
+// constrain() on two samples: clamp(diff, -t, t) with t = max(0, thr - (|diff| >> shift)) — the same value as
+// sign(diff) * min(|diff|, t) (spec 7.15.2), written so that it is a saturating subtract and a min/max pair
+__device__ __forceinline__ v2s pk_constrain(v2s diff, v2u thr, v2u shift) {
+  const v2u mag = __builtin_bit_cast(v2u, __builtin_elementwise_max(diff, -diff));
+  const v2s t = __builtin_bit_cast(v2s, __builtin_elementwise_sub_sat(thr, mag >> shift));
+  return __builtin_elementwise_max(__builtin_elementwise_min(diff, t), -t);
 }
-template <int LS>
-__device__ __forceinline__ void cdef_quad_packed(const uint16_t *p, int pri, int sec, int damping, int dir, int cs, v2s *out) {
+// linear tap offsets of one direction in a tile of row stride LS: {o0 k0, o0 k1, o1 k0, o1 k1, o2 k0, o2 k1, 0, 0} as
+// int16, o0 = dir, o1 = dir + 2, o2 = dir + 6 (mod 8): one 16-byte LDS row per direction, read once per quad
+template <int LS> __device__ __forceinline__ void cdef_fill_offsets(int16_t *tab, int i) {   // i in [0, 64)
+  const int dir = i >> 3, j = i & 7;
+  const int d = j < 2 ? dir : j < 4 ? (dir + 2) & 7 : (dir + 6) & 7, k = j & 1;
+  tab[i] = j < 6 ? (int16_t)(kCdefDir[d][k][0] * LS + kCdefDir[d][k][1]) : (int16_t)0;
+}
+template <int LS, bool SENT>
+__device__ __forceinline__ void cdef_quad_packed(const uint16_t *p, const int16_t *offtab, int pri, int sec, int damping, int dir, int cs, v2s *out) {
   const uint32_t *c32 = reinterpret_cast<const uint32_t *>(p);
   const v2s x0 = __builtin_bit_cast(v2s, c32[0]), x1 = __builtin_bit_cast(v2s, c32[1]);
   v2s s0 = { 0, 0 }, s1 = { 0, 0 }, mx0 = x0, mx1 = x1, mn0 = x0, mn1 = x1;
   const int pshift = pri ? max(0, damping - msb(pri)) : 0, sshift = sec ? max(0, damping - msb(sec)) : 0;
   const int pt0 = ((pri >> cs) & 1) ? 3 : 4, pt1 = ((pri >> cs) & 1) ? 3 : 2;
-  auto tap = [&](int off, int thr, int shift, int w) {
-    // the four samples at p + off .. p + off + 3 as two packed pairs; off may be odd: funnel-shift three aligned dwords
-    const int odd = off & 1;
-    const uint32_t *q = reinterpret_cast<const uint32_t *>(p + off - odd);
-    const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
-    const v2s a0 = __builtin_bit_cast(v2s, __builtin_amdgcn_alignbit(d1, d0, odd * 16));
-    const v2s a1 = __builtin_bit_cast(v2s, __builtin_amdgcn_alignbit(d2, d1, odd * 16));
+  const uint4 ot = *reinterpret_cast<const uint4 *>(offtab + dir * 8);
+  const int offs[6] = { (int16_t)(ot.x & 0xffff), (int16_t)(ot.x >> 16), (int16_t)(ot.y & 0xffff), (int16_t)(ot.y >> 16),
+                        (int16_t)(ot.z & 0xffff), (int16_t)(ot.z >> 16) };
+  // one tap position and its mirror image share weight and strength: constrain both, add, one multiply-add per pair
+  auto taps = [&](int off, int thr, int shift, int w) {
+    const v2u th = { (unsigned short)thr, (unsigned short)thr }, sh = { (unsigned short)shift, (unsigned short)shift };
+    v2s c0 = { 0, 0 }, c1 = { 0, 0 };
+#pragma unroll
+    for (int sg = 0; sg < 2; sg++) {
+      const int o = sg ? -off : off, odd = o & 1;
+      // the four samples at p + o .. p + o + 3 as two packed pairs; o may be odd: funnel-shift three aligned dwords
+      const uint32_t *q = reinterpret_cast<const uint32_t *>(p + o - odd);
+      const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
+      v2s a0 = __builtin_bit_cast(v2s, __builtin_amdgcn_alignbit(d1, d0, odd * 16));
+      v2s a1 = __builtin_bit_cast(v2s, __builtin_amdgcn_alignbit(d2, d1, odd * 16));
+      if constexpr (SENT) {
+        // picture-border superblocks: 0xFFFF marks a sample outside the picture (CdefAvailable = 0).  Valid samples are
+        // < 2^15, so the sign bit is the mark; a marked tap is replaced by the centre sample: difference 0, and it cannot
+        // move the min/max clamp — exactly "skip the tap"
+        const v2s fifteen = { 15, 15 };
+        const uint32_t m0 = __builtin_bit_cast(uint32_t, a0 >> fifteen), m1 = __builtin_bit_cast(uint32_t, a1 >> fifteen);
+        a0 = __builtin_bit_cast(v2s, (__builtin_bit_cast(uint32_t, x0) & m0) | (__builtin_bit_cast(uint32_t, a0) & ~m0));
+        a1 = __builtin_bit_cast(v2s, (__builtin_bit_cast(uint32_t, x1) & m1) | (__builtin_bit_cast(uint32_t, a1) & ~m1));
+      }
+      c0 += pk_constrain(a0 - x0, th, sh); c1 += pk_constrain(a1 - x1, th, sh);
+      mx0 = __builtin_elementwise_max(mx0, a0); mx1 = __builtin_elementwise_max(mx1, a1);
+      mn0 = __builtin_elementwise_min(mn0, a0); mn1 = __builtin_elementwise_min(mn1, a1);
+    }
     const v2s ww = { (short)w, (short)w };
-    s0 += ww * pk_constrain(a0 - x0, thr, shift); s1 += ww * pk_constrain(a1 - x1, thr, shift);
-    mx0 = __builtin_elementwise_max(mx0, a0); mx1 = __builtin_elementwise_max(mx1, a1);
-    mn0 = __builtin_elementwise_min(mn0, a0); mn1 = __builtin_elementwise_min(mn1, a1);
+    s0 += ww * c0; s1 += ww * c1;
   };
 #pragma unroll
   for (int k = 0; k < 2; k++) {
-    const int o0 = kCdefDir[dir][k][0] * LS + kCdefDir[dir][k][1];
-    const int o1 = kCdefDir[(dir + 2) & 7][k][0] * LS + kCdefDir[(dir + 2) & 7][k][1];
-    const int o2 = kCdefDir[(dir + 6) & 7][k][0] * LS + kCdefDir[(dir + 6) & 7][k][1];
-    const int ptap = k ? pt1 : pt0, stap = k ? 1 : 2;
-    tap(o0, pri, pshift, ptap); tap(-o0, pri, pshift, ptap);
-    tap(o1, sec, sshift, stap); tap(-o1, sec, sshift, stap);
-    tap(o2, sec, sshift, stap); tap(-o2, sec, sshift, stap);
+    taps(offs[k], pri, pshift, k ? pt1 : pt0);
+    taps(offs[2 + k], sec, sshift, k ? 1 : 2);
+    taps(offs[4 + k], sec, sshift, k ? 1 : 2);
   }
   const v2s eight = { 8, 8 }, four = { 4, 4 }, fifteen = { 15, 15 };
   const v2s y0 = x0 + ((s0 + (s0 >> fifteen) + eight) >> four), y1 = x1 + ((s1 + (s1 >> fifteen) + eight) >> four);
@@ -104,7 +97,9 @@ __global__ __launch_bounds__(256) void k_cdef(CdefLaunch L) {
   __shared__ __attribute__((aligned(16))) uint16_t tc[2][(32 + 4) * CSZ + 8];
   __shared__ uint8_t bdir[64];
   __shared__ int bvar[64];
+  __shared__ __attribute__((aligned(16))) int16_t offy[64], offc[64];   // tap offsets per direction for the two tile strides
   const int tid = threadIdx.x;
+  if (tid < 64) cdef_fill_offsets<YS>(offy, tid); else if (tid < 128) cdef_fill_offsets<CSZ>(offc, tid - 64);
   const int sbx = blockIdx.x, sby = blockIdx.y, f = blockIdx.z;
   const int bd = L.bd, cs = bd - 8;
   const Pix *sy = reinterpret_cast<const Pix *>(L.src[0]) + (size_t)f * L.h * L.stride_y;
@@ -218,14 +213,10 @@ __global__ __launch_bounds__(256) void k_cdef(CdefLaunch L) {
       const int vs = (var >> 6) ? min(msb((unsigned)(var >> 6)), 12) : 0;
       const int pri = var ? (ypri0 * (4 + vs) + 8) >> 4 : 0;
       const int dir = ypri0 == 0 ? 0 : bdir[b];
-      if (interior) {
-        v2s r[2];
-        cdef_quad_packed<YS>(p, pri, ysec, L.damping + cs, dir, cs, r);
-        o[0] = r[0].x; o[1] = r[0].y; o[2] = r[1].x; o[3] = r[1].y;
-      } else {
-#pragma unroll
-        for (int k = 0; k < 4; k++) o[k] = cdef_sample<YS>(p + k, pri, ysec, L.damping + cs, dir, cs);
-      }
+      v2s r[2];
+      if (interior) cdef_quad_packed<YS, false>(p, offy, pri, ysec, L.damping + cs, dir, cs, r);
+      else cdef_quad_packed<YS, true>(p, offy, pri, ysec, L.damping + cs, dir, cs, r);
+      o[0] = r[0].x; o[1] = r[0].y; o[2] = r[1].x; o[3] = r[1].y;
     }
     Pix *d = dy + (size_t)fy * L.stride_y + fx;
     if constexpr (sizeof(Pix) == 1) *reinterpret_cast<uint32_t *>(d) = (uint32_t)o[0] | ((uint32_t)o[1] << 8) | ((uint32_t)o[2] << 16) | ((uint32_t)o[3] << 24);
@@ -242,14 +233,10 @@ __global__ __launch_bounds__(256) void k_cdef(CdefLaunch L) {
     if (skip) { o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; o[3] = p[3]; }
     else {
       const int dir = upri == 0 ? 0 : bdir[b];
-      if (interior) {
-        v2s r[2];
-        cdef_quad_packed<CSZ>(p, upri, usec, L.damping + cs - 1, dir, cs, r);
-        o[0] = r[0].x; o[1] = r[0].y; o[2] = r[1].x; o[3] = r[1].y;
-      } else {
-#pragma unroll
-        for (int k = 0; k < 4; k++) o[k] = cdef_sample<CSZ>(p + k, upri, usec, L.damping + cs - 1, dir, cs);
-      }
+      v2s r[2];
+      if (interior) cdef_quad_packed<CSZ, false>(p, offc, upri, usec, L.damping + cs - 1, dir, cs, r);
+      else cdef_quad_packed<CSZ, true>(p, offc, upri, usec, L.damping + cs - 1, dir, cs, r);
+      o[0] = r[0].x; o[1] = r[0].y; o[2] = r[1].x; o[3] = r[1].y;
     }
     Pix *d = reinterpret_cast<Pix *>(L.dst[1 + pl]) + (size_t)f * chh * L.stride_uv + (size_t)fy * L.stride_uv + fx;
     if constexpr (sizeof(Pix) == 1) *reinterpret_cast<uint32_t *>(d) = (uint32_t)o[0] | ((uint32_t)o[1] << 8) | ((uint32_t)o[2] << 16) | ((uint32_t)o[3] << 24);
