@@ -177,10 +177,13 @@ class GopPipeline:
     """BASELINE config 3: closed GOPs of `gop` frames (1 key frame + gop-1 P frames, single reference = the previous
     reconstructed, loop-filtered frame).  Frames inside a GOP are serially dependent, so the batch dimension is the
     SEGMENT: `segments` independent GOPs are coded in lockstep, the t-th frames of all of them stacked in one launch.
-    Per step: gop x (coding launch(es) + 3 deblock + 1 CDEF + 3 LR)."""
+    Per step: gop x (coding launch(es) + 3 deblock + 1 CDEF + 3 LR [+ the tile entropy coder, entropy_tile > 0: every frame's
+    symbols — modes or vectors + skip flags, levels — coded on the GPU; with entropy_async on the side stream, overlapping
+    the filters of the same frame and the coding kernel of the next, symbols double-buffered])."""
 
-    def __init__(self, ctx, width, height, bd, segments, gop, qindex, first_frame=0, search_range=8):
+    def __init__(self, ctx, width, height, bd, segments, gop, qindex, first_frame=0, search_range=8, entropy_tile=0, entropy_async=False):
         self.ctx, self.bd, self.segments, self.gop, self.qindex, self.range = ctx, bd, segments, gop, qindex, search_range
+        self.entropy_tile, self.entropy_async = entropy_tile, bool(entropy_async and entropy_tile)
         self.width, self.height, self.frames = width, height, segments * gop
         self.key = IntraPipeline(ctx, width, height, bd, segments, qindex, first_frame=first_frame)   # buffers + filter params
         # source: segment s holds frames first + s*gop .. ; re-stack as [t][s]
@@ -191,6 +194,16 @@ class GopPipeline:
         self.d_src = [[ctx.to_device(p) for p in self.src[t]] for t in range(gop)]
         nb = (height // 8) * (width // 8)
         self.d_mvs, self.d_skip = ctx.alloc(segments * nb * 4), ctx.alloc(segments * nb)
+        # symbol buffers: slot 0 = the key pipeline's; slot 1 only for the asynchronous coder (frame t uses slot t % 2)
+        self.sym = [dict(lev_y=d["lev_y"], lev_u=d["lev_u"], lev_v=d["lev_v"], modes_y=d["modes_y"], modes_uv=d["modes_uv"],
+                         mvs=self.d_mvs, skip=self.d_skip)]
+        if self.entropy_async:
+            self.sym.append(dict(lev_y=ctx.alloc(Y.size // gop * 2), lev_u=ctx.alloc(U.size // gop * 2), lev_v=ctx.alloc(V.size // gop * 2),
+                                 modes_y=ctx.alloc(segments * nb), modes_uv=ctx.alloc(segments * nb),
+                                 mvs=ctx.alloc(segments * nb * 4), skip=ctx.alloc(segments * nb)))
+        self.ent_cap = segments * (width * height * 3 // 2 + 65536)
+        self.ent_out = [ctx.alloc(self.ent_cap) for _ in range(gop)] if entropy_tile else []     # one stream per frame index t
+        self.ent_off = [ctx.alloc((segments + 1) * 8) for _ in range(gop)] if entropy_tile else []
         self.d_ref = [ctx.alloc(self.src[0][i].nbytes) for i in range(3)]      # loop-filtered previous frame
         self.zero_skip = ctx.to_device(np.zeros(segments * nb, np.uint8))
         self.samples = sum(a.size for a in self.src[0]) * gop
@@ -198,8 +211,11 @@ class GopPipeline:
 
     def describe(self):
         return ("%dx%d %d-bit 4:2:0, %d closed GOPs of %d frames in lockstep (1 key + %d P frames, single reference, +-%d full "
-                "search + half/quarter-pel refinement, 8x8 blocks), deblock + CDEF + Wiener LR on every frame; entropy coding "
-                "not built" % (self.width, self.height, self.bd, self.segments, self.gop, self.gop - 1, self.range))
+                "search + half/quarter-pel refinement, 8x8 blocks), deblock + CDEF + Wiener LR on every frame; %s"
+                % (self.width, self.height, self.bd, self.segments, self.gop, self.gop - 1, self.range,
+                   ("symbols coded on the GPU by the tile entropy coder (%dx%d tiles, own syntax, not an AV1 bitstream%s)"
+                    % (self.entropy_tile, self.entropy_tile, "; side stream" if self.entropy_async else ""))
+                   if self.entropy_tile else "symbols stay uncoded in HBM"))
 
     def _filters(self, skip_buf, skip_stride):
         c, k, d = self.ctx, self.key, self.key.d
@@ -220,30 +236,51 @@ class GopPipeline:
         nb = (h // 8) * (w // 8)
         for t in range(self.gop):
             s = self.d_src[t]
+            slot = t % len(self.sym)
+            y = self.sym[slot]
+            if self.entropy_async:
+                c.entropy_wait(slot)         # the coder of frame t - 2 has released this slot's symbol buffers
             if t == 0:
                 job = av1mi.IntraJob(w, h, self.bd, f, self.qindex, 8, w, w // 2, s[0].ptr, s[1].ptr, s[2].ptr, d["rec_y"].ptr,
-                                     d["rec_u"].ptr, d["rec_v"].ptr, d["lev_y"].ptr, d["lev_u"].ptr, d["lev_v"].ptr, d["modes_y"].ptr,
-                                     d["modes_uv"].ptr)
+                                     d["rec_u"].ptr, d["rec_v"].ptr, y["lev_y"].ptr, y["lev_u"].ptr, y["lev_v"].ptr, y["modes_y"].ptr,
+                                     y["modes_uv"].ptr)
                 c.intra_encode(job)
-                self._filters(self.zero_skip, 0)
             else:
                 job = av1mi.InterJob(w, h, self.bd, f, self.qindex, self.range, w, w // 2, s[0].ptr, s[1].ptr, s[2].ptr,
                                      self.d_ref[0].ptr, self.d_ref[1].ptr, self.d_ref[2].ptr, d["rec_y"].ptr, d["rec_u"].ptr,
-                                     d["rec_v"].ptr, d["lev_y"].ptr, d["lev_u"].ptr, d["lev_v"].ptr, self.d_mvs.ptr, self.d_skip.ptr)
+                                     d["rec_v"].ptr, y["lev_y"].ptr, y["lev_u"].ptr, y["lev_v"].ptr, y["mvs"].ptr, y["skip"].ptr)
                 c.inter_encode(job)
-                self._filters(self.d_skip, nb)
+            if self.entropy_tile:
+                ej = av1mi.EntropyJob(w, h, f, int(t == 0), self.entropy_tile, y["lev_y"].ptr, y["lev_u"].ptr, y["lev_v"].ptr,
+                                      y["modes_y"].ptr, y["modes_uv"].ptr, y["mvs"].ptr, y["skip"].ptr,
+                                      self.ent_out[t].ptr, self.ent_cap, self.ent_off[t].ptr)
+                if self.entropy_async:
+                    c.entropy_encode_async(ej, slot)
+                else:
+                    c.entropy_encode(ej)
+            self._filters(self.zero_skip if t == 0 else y["skip"], 0 if t == 0 else nb)
             if on_frame:
                 on_frame(t)
+
+    def coded_records(self, t):
+        """records of the t-th frames of all segments written by the last step (entropy_tile > 0)"""
+        self.ctx.sync()
+        off = self.ent_off[t].download((self.segments + 1,), np.uint64)
+        total = int(off[-1])
+        if total > self.ent_cap:
+            raise RuntimeError("entropy output needs %d bytes, capacity %d" % (total, self.ent_cap))
+        data = self.ent_out[t].download((max(total, 1),), np.uint8)[:total].tobytes()
+        return [data[int(off[i]):int(off[i + 1])] for i in range(self.segments)]
 
     def algorithmic_bytes(self):
         b, per_frame = self.bps, self.samples / self.gop
         return {"intra_pipeline": (2 * b + 2) * per_frame, "inter_pipeline": (3 * b + 2) * per_frame, "deblock": 2 * b * per_frame / 3.0,
-                "cdef": 2 * b * per_frame, "loop_restoration": 2 * b * per_frame / 3.0}
+                "cdef": 2 * b * per_frame, "loop_restoration": 2 * b * per_frame / 3.0, "entropy_code": 2 * per_frame}
 
     def close(self):
         for t in self.d_src:
             for b in t:
                 b.free()
-        for b in [self.d_mvs, self.d_skip, self.zero_skip] + self.d_ref:
+        for b in [self.d_mvs, self.d_skip, self.zero_skip] + self.d_ref + self.ent_out + self.ent_off + (list(self.sym[1].values()) if len(self.sym) > 1 else []):
             b.free()
         self.key.close()

@@ -211,7 +211,8 @@ def main():
         gop = 30
         segs = max(1, frames // 2)               # GOPs coded in lockstep per step
         frames = segs * gop
-        pipe = pipeline.GopPipeline(ctx, W, H, bd, segs, gop, args.qindex, first_frame=segment_of_rank(rank, frames))
+        pipe = pipeline.GopPipeline(ctx, W, H, bd, segs, gop, args.qindex, first_frame=segment_of_rank(rank, frames),
+                                    entropy_tile=args.entropy_tile if args.entropy != "none" else 0, entropy_async=args.entropy == "gpu-async")
     else:
         pipe = pipeline.IntraPipeline(ctx, W, H, bd, frames, args.qindex, first_frame=segment_of_rank(rank, frames),
                                       entropy_tile=args.entropy_tile, entropy_async=args.entropy == "gpu-async")

@@ -114,3 +114,37 @@ def test_async_entropy_stage_matches_sync(ctx, O):
         pipe.step()
     assert pipe.coded_records() == ref
     pipe.close()
+
+
+@pytest.mark.parametrize("use_async", [False, True])
+def test_closed_gop_chain_coded_records(ctx, O, use_async):
+    """config 3 with the entropy stage: key + P frames of 2 segments, every frame's record (modes or vectors + skip flags,
+    levels) equals the oracle coder's on the oracle chain's symbols — in the serial and in the side-stream form, twice in a
+    row (the second step reuses every double-buffered slot)"""
+    import pipeline
+    w, h, bd, q, gop = 192, 136, 8, 120, 4
+    gp = pipeline.GopPipeline(ctx, w, h, bd, segments=2, gop=gop, qindex=q, first_frame=3, search_range=6, entropy_tile=64,
+                              entropy_async=use_async)
+    k = gp.key
+    want = [[None] * 2 for _ in range(gop)]
+    for s in range(2):
+        ref = None
+        for t in range(gop):
+            src = [gp.src[t][i][s] for i in range(3)]
+            if t == 0:
+                r = O.intra_encode_frame(src[0], src[1], src[2], bd, 8, q)
+                skip8 = np.zeros((h // 8, w // 8), np.uint8)
+                want[t][s] = O.entropy_encode_frame(w, h, 1, 64, r["lev_y"], r["lev_u"], r["lev_v"], r["modes_y"], r["modes_uv"])
+            else:
+                r = O.inter_encode_frame(src, ref, bd, q, 6)
+                skip8 = r["skip"].reshape(h // 8, w // 8)
+                want[t][s] = O.entropy_encode_frame(w, h, 0, 64, r["lev_y"], r["lev_u"], r["lev_v"], mvs=r["mvs"], skip=r["skip"])
+            dbl = [O.deblock_plane(r["rec_y"], bd, 0, k.mi_y), O.deblock_plane(r["rec_u"], bd, 1, k.mi_c), O.deblock_plane(r["rec_v"], bd, 1, k.mi_c)]
+            cdef = O.cdef_frame(dbl[0], dbl[1], dbl[2], bd, k.cdef_damping, k.cdef_sb, skip8)
+            ref = [O.lr_plane(cdef[0], dbl[0], bd, 0, k.lr_unit, k.lr_units_y), O.lr_plane(cdef[1], dbl[1], bd, 1, k.lr_unit, k.lr_units_c),
+                   O.lr_plane(cdef[2], dbl[2], bd, 1, k.lr_unit, k.lr_units_c)]
+    for _ in range(2):
+        gp.step()
+        for t in range(gop):
+            assert gp.coded_records(t) == want[t], "frame index %d" % t
+    gp.close()
