@@ -131,3 +131,37 @@ def test_threaded_stack_matches_single_frames(host):
     tot = host.av1mi_host_entropy_encode_stack(w, h, nf, 3, 64, _vp(ly), _vp(lu), _vp(lv), _vp(my), _vp(muv))
     single = sum(_roundtrip(host, w, h, 1, ly[i], lu[i], lv[i], my[i], muv[i]) for i in range(nf))
     assert tot == single
+
+
+G = os.path.join(os.path.dirname(__file__), "golden", "entropy_kat.npz")
+KAT = (("key", 1), ("p", 0), ("adv", 1))
+
+
+def _kat_args(g, name, key):
+    a = [g["%s_%s" % (name, f)] for f in ("lev_y", "lev_u", "lev_v")]
+    return a + ([g[name + "_modes_y"], g[name + "_modes_uv"], None, None] if key else [None, None, g[name + "_mvs"], g[name + "_skip"]])
+
+
+def test_committed_entropy_vectors(host, O):
+    """tests/golden/entropy_kat.npz (tools/gen_golden.py): the oracle and the host coder still produce the committed bytes
+    (format drift guard: the syntax and entropy_init.hpp are this project's own), and the decoder returns the symbols"""
+    g = np.load(G)
+    for name, key in KAT:
+        a = _kat_args(g, name, key)
+        for tile in (32, 64, 128):
+            want = g["%s_rec_%d" % (name, tile)].tobytes()
+            assert O.entropy_encode_frame(136, 72, key, tile, *a) == want, (name, tile)
+            n = _roundtrip(host, 136, 72, key, *a, tile=tile)       # host bytes decode back to the symbols ...
+            out = np.zeros(n, np.uint8)
+            assert host.av1mi_host_entropy_encode(136, 72, key, tile, *[_vp(None if x is None else np.ascontiguousarray(x)) for x in a],
+                                                  _vp(out), n) == n and out.tobytes() == want      # ... and are the committed ones
+
+
+@pytest.mark.gpu
+def test_gpu_reproduces_entropy_vectors(ctx):
+    g = np.load(G)
+    for name, key in KAT:
+        a = [None if x is None else x[None] for x in _kat_args(g, name, key)]
+        for tile in (32, 64, 128):
+            got = ctx.entropy_encode_arrays(136, 72, key, tile, *a)
+            assert got[0] == g["%s_rec_%d" % (name, tile)].tobytes(), (name, tile)
