@@ -161,8 +161,11 @@ __global__ __launch_bounds__(256) void k_deblock(DeblockLaunch L) {
   // pass 0: vertical edges at lx = 4*uc, uc in [3, TW/4+5], rows [4, TH+28)
   {
     constexpr int NU = TW / 4 + 3, NR = TH + 24;
+    // lanes of a wave walk DOWN one unit column (rows are an odd number of dwords apart: no bank conflicts), so the edge
+    // decision — transform edge or not, filter length — is the same for nearly the whole wave instead of alternating lane
+    // by lane with 8x8 transforms
     for (int t = tid; t < NU * NR; t += 256) {
-      const int uc = 3 + t % NU, ly = 4 + t / NU;
+      const int uc = 3 + t / NR, ly = 4 + t % NR;
       const int fx = X0 + 4 * uc, fy = Y0 + ly;
       if (fx <= 0 || fy < 0 || fy >= L.h) continue;
       int lvl = 0;
