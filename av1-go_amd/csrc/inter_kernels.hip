@@ -147,39 +147,76 @@ __device__ __forceinline__ void mc_row(const ES *win, int ws, int16_t *im, int l
 
 // The same filter split in two, so that the candidates of a refinement round that share a horizontal phase share its
 // (more expensive) horizontal pass: mc_h16 filters all 16 rows of the luma window for one horizontal displacement,
-// mc_v8 produces row `lane` of the prediction for one vertical displacement from that intermediate.
+// mc_rows9 + mc_v9 produce row `lane` of the prediction for the vertical displacements from that intermediate.
 template <typename ES>
 __device__ __forceinline__ void mc_h16(const ES *win, int ws, int16_t *im, int lane, int posx, const int16_t (*filt)[8]) {
-  const int ox = 4 + (posx >> 4) - 3;
+  const int ox = 4 + (posx >> 4) - 3;            // 0 or 1
   int fx[8];
 #pragma unroll
   for (int t = 0; t < 8; t++) fx[t] = filt[posx & 15][t];
 #pragma unroll
   for (int it = 0; it < 2; it++) {
     const int j = lane + it * 8;
-    const ES *p = win + j * ws + ox;
+    // the row leaves LDS as aligned dwords (ws * sizeof(ES) is a multiple of 4) and is funnel-shifted by ox samples:
+    // 5 (8-bit) or 9 (10-bit) reads instead of 15 single-sample ones — the kernel is LDS-bound
+    const uint32_t *q = reinterpret_cast<const uint32_t *>(win + j * ws);
+    int v[15];
+    if constexpr (sizeof(ES) == 1) {
+      uint32_t w[5], a[4];
+#pragma unroll
+      for (int i = 0; i < 5; i++) w[i] = q[i];
+#pragma unroll
+      for (int i = 0; i < 4; i++) a[i] = __builtin_amdgcn_alignbyte(w[i + 1], w[i], ox);
+#pragma unroll
+      for (int i = 0; i < 15; i++) v[i] = (a[i >> 2] >> ((i & 3) * 8)) & 255;
+    } else {
+      uint32_t w[9], a[8];
+#pragma unroll
+      for (int i = 0; i < 9; i++) w[i] = q[i];
+#pragma unroll
+      for (int i = 0; i < 8; i++) a[i] = __builtin_amdgcn_alignbit(w[i + 1], w[i], ox * 16);
+#pragma unroll
+      for (int i = 0; i < 15; i++) v[i] = (a[i >> 1] >> ((i & 1) * 16)) & 0xffff;
+    }
+    uint32_t o[4];
 #pragma unroll
     for (int c = 0; c < 8; c++) {
-      int s = 0;
+      int sum = 0;
 #pragma unroll
-      for (int t = 0; t < 8; t++) s += fx[t] * (int)p[c + t];
-      im[j * 8 + c] = (int16_t)((s + 4) >> 3);
+      for (int t = 0; t < 8; t++) sum += fx[t] * v[c + t];
+      const uint32_t h = (uint32_t)((sum + 4) >> 3) & 0xffff;
+      o[c >> 1] = (c & 1) ? (o[c >> 1] | (h << 16)) : h;
     }
+    *reinterpret_cast<uint4 *>(im + j * 8) = make_uint4(o[0], o[1], o[2], o[3]);
   }
 }
-__device__ __forceinline__ void mc_v8(const int16_t *im, int lane, int posy, const int16_t (*filt)[8], int bd, int *out) {
-  const int oy = 4 + (posy >> 4) - 3;
-  int fy[8];
+// The vertical displacements of one refinement round differ by less than a sample, so row `lane` of all of them reads
+// intermediate rows lane .. lane + 8: those nine rows (16 bytes each) are loaded ONCE per horizontal position (mc_rows9) and
+// every vertical candidate is a 9-tap sum over them — the 8 taps of its phase shifted by its integer part, a zero at the
+// other end (mc_v9).  k_inter_pipe is LDS-bound (LDS busy 85 % of the kernel by PMC); this cuts the reads of the vertical
+// pass from 8 per candidate to 9 per three candidates.
+__device__ __forceinline__ void mc_rows9(const int16_t *im, int lane, uint4 *rw) {
 #pragma unroll
-  for (int t = 0; t < 8; t++) fy[t] = filt[posy & 15][t];
-  const int maxpix = (1 << bd) - 1;
+  for (int k = 0; k < 9; k++) rw[k] = *reinterpret_cast<const uint4 *>(im + (lane + k) * 8);
+}
+__device__ __forceinline__ void mc_v9(const uint4 *rw, int posy, const int16_t (*filt)[8], int bd, int *out) {
+  const int oy = 4 + (posy >> 4) - 3;            // 0 or 1
+  int g[9];
 #pragma unroll
-  for (int c = 0; c < 8; c++) {
-    int s = 0;
-#pragma unroll
-    for (int t = 0; t < 8; t++) s += fy[t] * (int)im[(oy + lane + t) * 8 + c];
-    out[c] = min(max((s + 1024) >> 11, 0), maxpix);
+  for (int k = 0; k < 9; k++) {
+    const int lo = k < 8 ? filt[posy & 15][k] : 0, hi = k > 0 ? filt[posy & 15][k - 1] : 0;
+    g[k] = oy ? hi : lo;
   }
+  const int maxpix = (1 << bd) - 1;
+  int s[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+    const uint32_t w[4] = { rw[k].x, rw[k].y, rw[k].z, rw[k].w };
+#pragma unroll
+    for (int c = 0; c < 8; c++) s[c] += g[k] * (int)(int16_t)((w[c >> 1] >> ((c & 1) * 16)) & 0xffff);
+  }
+#pragma unroll
+  for (int c = 0; c < 8; c++) out[c] = min(max((s[c] + 1024) >> 11, 0), maxpix);
 }
 
 template <typename Pix>
@@ -187,7 +224,7 @@ __global__ __launch_bounds__(256) void k_inter_pipe(InterLaunch L) {
   using ES = Pix;
   constexpr int bd = sizeof(Pix) == 1 ? 8 : 10;
   constexpr int GPW = 32;                        // groups (blocks) per workgroup
-  constexpr int YW = 16, YWS = 18;               // luma window 16 x 16 (integer vector -4 .. +11), padded stride
+  constexpr int YW = 16, YWS = 20;               // luma window 16 x 16 (integer vector -4 .. +11); rows are whole dwords
   constexpr int CW = 12, CWS = 14;               // chroma window 12 x 12 (chroma integer position -4 .. +7)
   constexpr int WIN_N = YW * YWS + 2 * CW * CWS;
   constexpr int WIN_BYTES = ((WIN_N * (int)sizeof(ES) + 127) / 128) * 128 + 16;
@@ -219,8 +256,18 @@ __global__ __launch_bounds__(256) void k_inter_pipe(InterLaunch L) {
     const int r = lane + it * 8;
     const int fy = min(max(y + imy - 4 + r, 0), L.h - 1);
     const Pix *row = ref_y + (size_t)fy * L.stride_y;
+    ES px[YW];
 #pragma unroll
-    for (int c = 0; c < YW; c++) wy[r * YWS + c] = row[min(max(x + imx - 4 + c, 0), L.w - 1)];
+    for (int c = 0; c < YW; c++) px[c] = row[min(max(x + imx - 4 + c, 0), L.w - 1)];
+    uint32_t *wrow = reinterpret_cast<uint32_t *>(wy + r * YWS);      // packed dword stores
+    constexpr int PER = 4 / (int)sizeof(ES);
+#pragma unroll
+    for (int d = 0; d < YW / PER; d++) {
+      uint32_t u = 0;
+#pragma unroll
+      for (int k = 0; k < PER; k++) u |= (uint32_t)px[d * PER + k] << (k * 8 * (int)sizeof(ES));
+      wrow[d] = u;
+    }
   }
   int s[8], bp[8], out[8];
   load_row<8>(src_y + (size_t)(y + lane) * L.stride_y + x, s);
@@ -245,11 +292,13 @@ __global__ __launch_bounds__(256) void k_inter_pipe(InterLaunch L) {
       const int fx = cx + (ix - 1) * step;
       mc_h16<ES>(wy, YWS, im, lane, fx * 2, kRegular8);
       AV1MI_GROUP_SYNC();
+      uint4 rw[9];
+      mc_rows9(im, lane, rw);
 #pragma unroll 1
       for (int iy = 0; iy < 3; iy++) {
         if (ix == 1 && iy == 1) continue;
         const int fy = cy + (iy - 1) * step, k = iy * 3 + ix;
-        mc_v8(im, lane, fy * 2, kRegular8, bd, out);
+        mc_v9(rw, fy * 2, kRegular8, bd, out);
         const int sd = sad_of(out);
         const bool better = sd < best || (sd == best && rbest >= 0 && k < rbest);
         best = better ? sd : best; bfx = better ? fx : bfx; bfy = better ? fy : bfy; rbest = better ? k : rbest;
