@@ -112,6 +112,23 @@ __global__ __launch_bounds__(256) void k_me_int(InterLaunch L) {
 // 2-D sub-pel prediction of row `lane` of a B x B block from a window in LDS (origin = integer position - 4, i.e. the
 // window starts 4 samples left of / above the integer-vector block): posx/posy = displacement from the window's block
 // origin in 1/16 samples, in [-16, 15].  im: (B+7) x B int16 scratch of the group.  NL = lanes of the block.
+// N consecutive samples starting `ox` samples into a dword-aligned LDS row: aligned dword reads + funnel shift, so that the
+// row costs (N * sizeof(ES)) / 4 + 1 LDS reads instead of N (k_inter_pipe is LDS-bound).  ox in [0, 4 / sizeof(ES)).
+template <int N, typename ES> __device__ __forceinline__ void row_samples(const ES *row, int ox, int *v) {
+  const uint32_t *q = reinterpret_cast<const uint32_t *>(row);
+  constexpr int PER = 4 / (int)sizeof(ES), ND = (N + PER - 1) / PER;
+  uint32_t w[ND + 1], a[ND];
+#pragma unroll
+  for (int i = 0; i <= ND; i++) w[i] = q[i];
+#pragma unroll
+  for (int i = 0; i < ND; i++) {
+    if constexpr (sizeof(ES) == 1) a[i] = __builtin_amdgcn_alignbyte(w[i + 1], w[i], ox);
+    else a[i] = __builtin_amdgcn_alignbit(w[i + 1], w[i], ox * 16);
+  }
+#pragma unroll
+  for (int i = 0; i < N; i++) v[i] = (a[i / PER] >> ((i % PER) * 8 * (int)sizeof(ES))) & (sizeof(ES) == 1 ? 255u : 0xffffu);
+}
+
 template <int B, typename ES>
 __device__ __forceinline__ void mc_row(const ES *win, int ws, int16_t *im, int lane, int posx, int posy, const int16_t (*filt)[8], int bd,
                                        int *out) {
@@ -123,12 +140,13 @@ __device__ __forceinline__ void mc_row(const ES *win, int ws, int16_t *im, int l
   for (int it = 0; it < (2 * B + 6) / B; it++) {   // B + 7 intermediate rows over B lanes
     const int j = lane + it * B;
     if (j < B + 7) {
-      const ES *p = win + (oy + j) * ws + ox;
+      int v[B + 7];
+      row_samples<B + 7, ES>(win + (oy + j) * ws, ox, v);
 #pragma unroll
       for (int c = 0; c < B; c++) {
         int s = 0;
 #pragma unroll
-        for (int t = 0; t < 8; t++) s += fx[t] * (int)p[c + t];
+        for (int t = 0; t < 8; t++) s += fx[t] * v[c + t];
         im[j * B + c] = (int16_t)((s + 4) >> 3);
       }
     }
@@ -157,27 +175,8 @@ __device__ __forceinline__ void mc_h16(const ES *win, int ws, int16_t *im, int l
 #pragma unroll
   for (int it = 0; it < 2; it++) {
     const int j = lane + it * 8;
-    // the row leaves LDS as aligned dwords (ws * sizeof(ES) is a multiple of 4) and is funnel-shifted by ox samples:
-    // 5 (8-bit) or 9 (10-bit) reads instead of 15 single-sample ones — the kernel is LDS-bound
-    const uint32_t *q = reinterpret_cast<const uint32_t *>(win + j * ws);
     int v[15];
-    if constexpr (sizeof(ES) == 1) {
-      uint32_t w[5], a[4];
-#pragma unroll
-      for (int i = 0; i < 5; i++) w[i] = q[i];
-#pragma unroll
-      for (int i = 0; i < 4; i++) a[i] = __builtin_amdgcn_alignbyte(w[i + 1], w[i], ox);
-#pragma unroll
-      for (int i = 0; i < 15; i++) v[i] = (a[i >> 2] >> ((i & 3) * 8)) & 255;
-    } else {
-      uint32_t w[9], a[8];
-#pragma unroll
-      for (int i = 0; i < 9; i++) w[i] = q[i];
-#pragma unroll
-      for (int i = 0; i < 8; i++) a[i] = __builtin_amdgcn_alignbit(w[i + 1], w[i], ox * 16);
-#pragma unroll
-      for (int i = 0; i < 15; i++) v[i] = (a[i >> 1] >> ((i & 1) * 16)) & 0xffff;
-    }
+    row_samples<15, ES>(win + j * ws, ox, v);
     uint32_t o[4];
 #pragma unroll
     for (int c = 0; c < 8; c++) {
@@ -225,7 +224,7 @@ __global__ __launch_bounds__(256) void k_inter_pipe(InterLaunch L) {
   constexpr int bd = sizeof(Pix) == 1 ? 8 : 10;
   constexpr int GPW = 32;                        // groups (blocks) per workgroup
   constexpr int YW = 16, YWS = 20;               // luma window 16 x 16 (integer vector -4 .. +11); rows are whole dwords
-  constexpr int CW = 12, CWS = 14;               // chroma window 12 x 12 (chroma integer position -4 .. +7)
+  constexpr int CW = 12, CWS = 16;               // chroma window 12 x 12 (chroma integer position -4 .. +7); rows are whole dwords
   constexpr int WIN_N = YW * YWS + 2 * CW * CWS;
   constexpr int WIN_BYTES = ((WIN_N * (int)sizeof(ES) + 127) / 128) * 128 + 16;
   constexpr int IM_N = 16 * 8 + 8;               // luma intermediate 16 x 8 (chroma 2 x 11 x 4 fits inside)
@@ -329,8 +328,18 @@ __global__ __launch_bounds__(256) void k_inter_pipe(InterLaunch L) {
       const int r = cl + it * 4;
       const int fy = min(max(cy0 + ciy - 4 + r, 0), chh - 1);
       const Pix *row = ref_c + (size_t)fy * L.stride_uv;
+      ES px[CW];
 #pragma unroll
-      for (int c = 0; c < CW; c++) wc[r * CWS + c] = row[min(max(cx0 + cix - 4 + c, 0), cw - 1)];
+      for (int c = 0; c < CW; c++) px[c] = row[min(max(cx0 + cix - 4 + c, 0), cw - 1)];
+      uint32_t *wrow = reinterpret_cast<uint32_t *>(wc + r * CWS);
+      constexpr int PER = 4 / (int)sizeof(ES);
+#pragma unroll
+      for (int d = 0; d < CW / PER; d++) {
+        uint32_t u = 0;
+#pragma unroll
+        for (int k = 0; k < PER; k++) u |= (uint32_t)px[d * PER + k] << (k * 8 * (int)sizeof(ES));
+        wrow[d] = u;
+      }
     }
     int sc[4], pc[4], rc[4];
     load_row<4>(src_c + (size_t)(cy0 + cl) * L.stride_uv + cx0, sc);
