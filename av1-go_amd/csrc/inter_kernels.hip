@@ -192,30 +192,47 @@ __device__ __forceinline__ void mc_h16(const ES *win, int ws, int16_t *im, int l
 // The vertical displacements of one refinement round differ by less than a sample, so row `lane` of all of them reads
 // intermediate rows lane .. lane + 8: those nine rows (16 bytes each) are loaded ONCE per horizontal position (mc_rows9) and
 // every vertical candidate is a 9-tap sum over them — the 8 taps of its phase shifted by its integer part, a zero at the
-// other end (mc_v9).  k_inter_pipe is LDS-bound (LDS busy 85 % of the kernel by PMC); this cuts the reads of the vertical
-// pass from 8 per candidate to 9 per three candidates.
-__device__ __forceinline__ void mc_rows9(const int16_t *im, int lane, uint4 *rw) {
+// other end (mc_v9).  The first version of k_inter_pipe was LDS-bound (LDS busy 85 % of the kernel by PMC); this cut the
+// reads of the vertical pass from 8 per candidate to 9 per three candidates.
+// After the LDS diet the kernel is VALU-bound, so the vertical sums run on v_dot2_i32_i16: the nine rows are interleaved
+// once per horizontal position into row PAIRS per column, pr[kp][c] = (row 2kp, row 2kp + 1) of column c (row 9 = 0), and a
+// candidate is 5 dot2 per sample instead of 9 multiply-adds + 9 extracts (exact: int16 x int16 into int32).
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void mc_rows9(const int16_t *im, int lane, uint32_t (*pr)[8]) {
+  uint4 rw[10];
 #pragma unroll
   for (int k = 0; k < 9; k++) rw[k] = *reinterpret_cast<const uint4 *>(im + (lane + k) * 8);
+  rw[9] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+  for (int kp = 0; kp < 5; kp++) {
+    const uint32_t x[4] = { rw[2 * kp].x, rw[2 * kp].y, rw[2 * kp].z, rw[2 * kp].w };
+    const uint32_t y[4] = { rw[2 * kp + 1].x, rw[2 * kp + 1].y, rw[2 * kp + 1].z, rw[2 * kp + 1].w };
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+      pr[kp][2 * d] = __builtin_amdgcn_perm(y[d], x[d], 0x05040100u);       // (x.lo, y.lo)
+      pr[kp][2 * d + 1] = __builtin_amdgcn_perm(y[d], x[d], 0x07060302u);   // (x.hi, y.hi)
+    }
+  }
 }
-__device__ __forceinline__ void mc_v9(const uint4 *rw, int posy, const int16_t (*filt)[8], int bd, int *out) {
+__device__ __forceinline__ void mc_v9(const uint32_t (*pr)[8], int posy, const int16_t (*filt)[8], int bd, int *out) {
   const int oy = 4 + (posy >> 4) - 3;            // 0 or 1
-  int g[9];
+  int g[10];
 #pragma unroll
   for (int k = 0; k < 9; k++) {
     const int lo = k < 8 ? filt[posy & 15][k] : 0, hi = k > 0 ? filt[posy & 15][k - 1] : 0;
     g[k] = oy ? hi : lo;
   }
+  g[9] = 0;
   const int maxpix = (1 << bd) - 1;
-  int s[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+  int s[8] = { 1024, 1024, 1024, 1024, 1024, 1024, 1024, 1024 };
 #pragma unroll
-  for (int k = 0; k < 9; k++) {
-    const uint32_t w[4] = { rw[k].x, rw[k].y, rw[k].z, rw[k].w };
+  for (int kp = 0; kp < 5; kp++) {
+    const s16x2 gp = __builtin_bit_cast(s16x2, (uint32_t)(g[2 * kp] & 0xffff) | ((uint32_t)g[2 * kp + 1] << 16));
 #pragma unroll
-    for (int c = 0; c < 8; c++) s[c] += g[k] * (int)(int16_t)((w[c >> 1] >> ((c & 1) * 16)) & 0xffff);
+    for (int c = 0; c < 8; c++) s[c] = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, pr[kp][c]), gp, s[c], false);
   }
 #pragma unroll
-  for (int c = 0; c < 8; c++) out[c] = min(max((s[c] + 1024) >> 11, 0), maxpix);
+  for (int c = 0; c < 8; c++) out[c] = min(max(s[c] >> 11, 0), maxpix);
 }
 
 template <typename Pix>
@@ -291,13 +308,13 @@ __global__ __launch_bounds__(256) void k_inter_pipe(InterLaunch L) {
       const int fx = cx + (ix - 1) * step;
       mc_h16<ES>(wy, YWS, im, lane, fx * 2, kRegular8);
       AV1MI_GROUP_SYNC();
-      uint4 rw[9];
-      mc_rows9(im, lane, rw);
+      uint32_t pr[5][8];
+      mc_rows9(im, lane, pr);
 #pragma unroll 1
       for (int iy = 0; iy < 3; iy++) {
         if (ix == 1 && iy == 1) continue;
         const int fy = cy + (iy - 1) * step, k = iy * 3 + ix;
-        mc_v9(rw, fy * 2, kRegular8, bd, out);
+        mc_v9(pr, fy * 2, kRegular8, bd, out);
         const int sd = sad_of(out);
         const bool better = sd < best || (sd == best && rbest >= 0 && k < rbest);
         best = better ? sd : best; bfx = better ? fx : bfx; bfy = better ? fy : bfy; rbest = better ? k : rbest;
