@@ -42,6 +42,7 @@ __global__ __launch_bounds__(256) void k_me_int(InterLaunch L) {
   constexpr int MAXR = 16, WS = 64 + 2 * MAXR + 16;   // window row stride in bytes (multiple of 4)
   __shared__ __attribute__((aligned(16))) uint8_t win[(64 + 2 * MAXR) * WS];
   __shared__ __attribute__((aligned(16))) uint8_t srct[64 * 64];
+  __shared__ uint32_t s_best[64];                    // per 8x8 block: min of (SAD, rank)
   constexpr int sh = sizeof(Pix) == 1 ? 0 : 2;
   const int tid = threadIdx.x, R = L.range, R4 = (R + 3) & ~3, NC = 2 * R + 1;
   const int WDX = 64 + 2 * R4 + 4, WDY = 64 + 2 * R;        // window columns start at x - R4 (4-aligned), rows at y - R
@@ -49,29 +50,54 @@ __global__ __launch_bounds__(256) void k_me_int(InterLaunch L) {
   const int f = blockIdx.y, sb = blockIdx.x, sby = sb / sbw, sbx = sb % sbw;
   const Pix *src = reinterpret_cast<const Pix *>(L.src[0]) + (size_t)f * L.h * L.stride_y;
   const Pix *ref = reinterpret_cast<const Pix *>(L.ref[0]) + (size_t)f * L.h * L.stride_y;
-  for (int i = tid; i < WDY * WDX; i += 256) {
-    const int r = i / WDX, c = i - r * WDX;
-    const int fy = min(max(sby * 64 - R + r, 0), L.h - 1), fx = min(max(sbx * 64 - R4 + c, 0), L.w - 1);
-    win[r * WS + c] = (uint8_t)(ref[(size_t)fy * L.stride_y + fx] >> sh);
+  // staging, four samples per lane per step (the window starts on a 4-sample boundary and its width is a multiple of 4);
+  // groups that lie inside the plane are one vector load, the others clamp sample by sample (the spec's edge extension)
+  const int wg = WDX >> 2;
+  for (int i = tid; i < WDY * wg; i += 256) {
+    const int r = i / wg, c = (i - r * wg) * 4;
+    const int fy = min(max(sby * 64 - R + r, 0), L.h - 1), fx = sbx * 64 - R4 + c;
+    const Pix *row = ref + (size_t)fy * L.stride_y;
+    uint32_t u;
+    if (fx >= 0 && fx + 3 < L.w) {
+      if constexpr (sizeof(Pix) == 1) u = *reinterpret_cast<const uint32_t *>(row + fx);
+      else { const uint2 v = *reinterpret_cast<const uint2 *>(row + fx); u = ((v.x >> sh) & 0xff) | (((v.x >> (16 + sh)) & 0xff) << 8) | (((v.y >> sh) & 0xff) << 16) | (((v.y >> (16 + sh)) & 0xff) << 24); }
+    } else {
+      u = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) u |= (uint32_t)((row[min(max(fx + k, 0), L.w - 1)] >> sh) & 0xff) << (8 * k);
+    }
+    *reinterpret_cast<uint32_t *>(win + r * WS + c) = u;
   }
-  for (int i = tid; i < 64 * 64; i += 256) {
-    const int r = i >> 6, c = i & 63;
-    const int fy = min(sby * 64 + r, L.h - 1), fx = min(sbx * 64 + c, L.w - 1);
-    srct[i] = (uint8_t)(src[(size_t)fy * L.stride_y + fx] >> sh);
+  for (int i = tid; i < 64 * 16; i += 256) {
+    const int r = i >> 4, c = (i & 15) * 4;
+    const int fy = min(sby * 64 + r, L.h - 1), fx = sbx * 64 + c;
+    const Pix *row = src + (size_t)fy * L.stride_y;
+    uint32_t u;
+    if (fx + 3 < L.w) {
+      if constexpr (sizeof(Pix) == 1) u = *reinterpret_cast<const uint32_t *>(row + fx);
+      else { const uint2 v = *reinterpret_cast<const uint2 *>(row + fx); u = ((v.x >> sh) & 0xff) | (((v.x >> (16 + sh)) & 0xff) << 8) | (((v.y >> sh) & 0xff) << 16) | (((v.y >> (16 + sh)) & 0xff) << 24); }
+    } else {
+      u = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) u |= (uint32_t)((row[min(fx + k, L.w - 1)] >> sh) & 0xff) << (8 * k);
+    }
+    *reinterpret_cast<uint32_t *>(srct + r * 64 + c) = u;
   }
+  if (tid < 64) s_best[tid] = 0xFFFFFFFFu;
   __syncthreads();
   const int wave = tid >> 6, lane = tid & 63;
   const int bw = L.w / 8, bh = L.h / 8;
   const int NG = (2 * R4) / 4 + 1;                 // groups of four dx starting at -R4
+  const int per = NC * NG;                         // (dy, dx group) items per block
   int16_t *mvs = L.mvs + (size_t)f * bw * bh * 2;
-  for (int b = wave; b < 64; b += 4) {             // 16 blocks per wave
-    const int by = b >> 3, bx = b & 7;
-    const int fbx = sbx * 8 + bx, fby = sby * 8 + by;
-    if (fbx >= bw || fby >= bh) continue;
-    unsigned best = 0xFFFFFFFFu;
-    for (int t0 = 0; t0 < NC * NG; t0 += 64) {
-      const int t = t0 + lane;
-      if (t < NC * NG) {
+  // the 16 blocks of a wave form ONE item space (16 x per): with +-8 a block has 85 items, which alone would leave the
+  // second pass of a 64-lane wave two thirds empty; the per-block minimum is an LDS atomic instead of a wave reduction
+  for (int u0 = 0; u0 < 16 * per; u0 += 64) {
+    const int u = u0 + lane;
+    if (u < 16 * per) {
+      const int bi = u / per, t = u - bi * per, b = wave + 4 * bi;
+      const int by = b >> 3, bx = b & 7;
+      if (sbx * 8 + bx < bw && sby * 8 + by < bh) {
         const int dyi = t / NG, g = t - dyi * NG;  // dy = dyi - R, dx0 = -R4 + 4 g
         const uint8_t *p = win + (by * 8 + dyi) * WS + bx * 8 + 4 * g;
         const uint8_t *s = srct + (by * 8) * 64 + bx * 8;
@@ -85,6 +111,7 @@ __global__ __launch_bounds__(256) void k_me_int(InterLaunch L) {
           acc = __builtin_amdgcn_qsad_pk_u16_u8(w01, sr.x, acc);
           acc = __builtin_amdgcn_qsad_pk_u16_u8(w12, sr.y, acc);
         }
+        unsigned best = 0xFFFFFFFFu;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
           const int dx = -R4 + 4 * g + i, dy = dyi - R;
@@ -95,12 +122,16 @@ __global__ __launch_bounds__(256) void k_me_int(InterLaunch L) {
             best = min(best, key);
           }
         }
+        atomicMin(&s_best[b], best);
       }
     }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) best = min(best, (unsigned)__shfl_xor((int)best, o, 64));
-    if (lane == 0) {
-      const int rank = best & 1023;
+  }
+  __syncthreads();
+  if (tid < 64) {
+    const int by = tid >> 3, bx = tid & 7;
+    const int fbx = sbx * 8 + bx, fby = sby * 8 + by;
+    if (fbx < bw && fby < bh) {
+      const int rank = s_best[tid] & 1023;
       const int dy = rank ? (rank - 1) / NC - R : 0, dx = rank ? (rank - 1) % NC - R : 0;
       mvs[((size_t)fby * bw + fbx) * 2] = (int16_t)(dx * 8);
       mvs[((size_t)fby * bw + fbx) * 2 + 1] = (int16_t)(dy * 8);
