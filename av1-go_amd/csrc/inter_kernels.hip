@@ -319,15 +319,25 @@ __global__ __launch_bounds__(256) void k_inter_pipe(InterLaunch L) {
   int s[8], bp[8], out[8];
   load_row<8>(src_y + (size_t)(y + lane) * L.stride_y + x, s);
   AV1MI_GROUP_SYNC();
-  auto sad_of = [&](const int *o) {
-    int v = 0;
+  // rows are compared as packed pairs (v_sad_u16: two samples per instruction, both bit depths) and the running best
+  // prediction is kept packed: four selects per candidate; it is unpacked once after the search
+  uint32_t sp[4], bpp[4];
 #pragma unroll
-    for (int c = 0; c < 8; c++) v += abs(s[c] - o[c]);
-    return group_sum<8>(v);
+  for (int j = 0; j < 4; j++) sp[j] = (uint32_t)s[2 * j] | ((uint32_t)s[2 * j + 1] << 16);
+  auto pack4 = [&](const int *o, uint32_t *w) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) w[j] = (uint32_t)o[2 * j] | ((uint32_t)o[2 * j + 1] << 16);
+  };
+  auto sad_of = [&](const uint32_t *w) {
+    uint32_t v = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) v = __builtin_amdgcn_sad_u16(sp[j], w[j], v);
+    return group_sum<8>((int)v);
   };
   // candidate 0: the integer vector itself
   mc_row<8, ES>(wy, YWS, im, lane, 0, 0, kRegular8, bd, bp);
-  int best = sad_of(bp), bfx = 0, bfy = 0;     // fractional part in 1/8 samples relative to the integer vector
+  pack4(bp, bpp);
+  int best = sad_of(bpp), bfx = 0, bfy = 0;     // fractional part in 1/8 samples relative to the integer vector
   for (int step = 4; step >= 2; step >>= 1) {
     // the 8 neighbours of (cx, cy): column by column, one horizontal pass per column of candidates.  The oracle visits
     // them in raster order k = 0..8 with strict improvement, i.e. the winner is the minimum of (SAD, k) and the centre
@@ -346,15 +356,19 @@ __global__ __launch_bounds__(256) void k_inter_pipe(InterLaunch L) {
         if (ix == 1 && iy == 1) continue;
         const int fy = cy + (iy - 1) * step, k = iy * 3 + ix;
         mc_v9(pr, fy * 2, kRegular8, bd, out);
-        const int sd = sad_of(out);
+        uint32_t ow[4];
+        pack4(out, ow);
+        const int sd = sad_of(ow);
         const bool better = sd < best || (sd == best && rbest >= 0 && k < rbest);
         best = better ? sd : best; bfx = better ? fx : bfx; bfy = better ? fy : bfy; rbest = better ? k : rbest;
 #pragma unroll
-        for (int c = 0; c < 8; c++) bp[c] = better ? out[c] : bp[c];
+        for (int j = 0; j < 4; j++) bpp[j] = better ? ow[j] : bpp[j];
       }
       AV1MI_GROUP_SYNC();
     }
   }
+#pragma unroll
+  for (int j = 0; j < 4; j++) { bp[2 * j] = bpp[j] & 0xffff; bp[2 * j + 1] = bpp[j] >> 16; }
   const int mvx = imx * 8 + bfx, mvy = imy * 8 + bfy;   // final vector, 1/8 luma samples
   if (lane == 0) { mvs[0] = (int16_t)mvx; mvs[1] = (int16_t)mvy; }
   int rec[8];
