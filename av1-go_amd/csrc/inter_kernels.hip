@@ -143,6 +143,7 @@ __global__ __launch_bounds__(256) void k_me_int(InterLaunch L) {
 // 2-D sub-pel prediction of row `lane` of a B x B block from a window in LDS (origin = integer position - 4, i.e. the
 // window starts 4 samples left of / above the integer-vector block): posx/posy = displacement from the window's block
 // origin in 1/16 samples, in [-16, 15].  im: (B+7) x B int16 scratch of the group.  NL = lanes of the block.
+typedef short s16x2 __attribute__((ext_vector_type(2)));
 // N consecutive samples starting `ox` samples into a dword-aligned LDS row: aligned dword reads + funnel shift, so that the
 // row costs (N * sizeof(ES)) / 4 + 1 LDS reads instead of N (k_inter_pipe is LDS-bound).  ox in [0, 4 / sizeof(ES)).
 template <int N, typename ES> __device__ __forceinline__ void row_samples(const ES *row, int ox, int *v) {
@@ -203,18 +204,59 @@ __device__ __forceinline__ void mc_h16(const ES *win, int ws, int16_t *im, int l
   int fx[8];
 #pragma unroll
   for (int t = 0; t < 8; t++) fx[t] = filt[posx & 15][t];
+  constexpr int PER = 4 / (int)sizeof(ES), ND = 16 / PER;
 #pragma unroll
   for (int it = 0; it < 2; it++) {
     const int j = lane + it * 8;
-    int v[15];
-    row_samples<15, ES>(win + j * ws, ox, v);
+    // the row's 16 samples from ox on, as aligned dwords funnel-shifted by ox samples
+    const uint32_t *q = reinterpret_cast<const uint32_t *>(win + j * ws);
+    uint32_t w[ND + 1], a[ND];
+#pragma unroll
+    for (int i = 0; i <= ND; i++) w[i] = q[i];
+#pragma unroll
+    for (int i = 0; i < ND; i++) {
+      if constexpr (sizeof(ES) == 1) a[i] = __builtin_amdgcn_alignbyte(w[i + 1], w[i], ox);
+      else a[i] = __builtin_amdgcn_alignbit(w[i + 1], w[i], ox * 16);
+    }
+    int sum[8];
+    if constexpr (sizeof(ES) == 1) {
+      // 8 taps = two v_dot4_i32_i8 on the samples biased to signed bytes (p - 128), except tap 3 (it reaches 128, one more
+      // than a signed byte holds), which is a separate multiply-add on the unbiased sample.  The bias is paid back in the
+      // accumulator: sum over t != 3 of f_t * 128 = 128 * (128 - f_3).
+      uint32_t b[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) b[i] = a[i] ^ 0x80808080u;
+      const int F0 = (fx[0] & 255) | ((fx[1] & 255) << 8) | ((fx[2] & 255) << 16);
+      const int F1 = (fx[4] & 255) | ((fx[5] & 255) << 8) | ((fx[6] & 255) << 16) | ((fx[7] & 255) << 24);
+      const int acc0 = 4 + 128 * (128 - fx[3]);
+      uint32_t d[12];
+#pragma unroll
+      for (int c = 0; c < 12; c++) d[c] = (c & 3) ? __builtin_amdgcn_alignbyte(b[(c >> 2) + 1], b[c >> 2], c & 3) : b[c >> 2];
+#pragma unroll
+      for (int c = 0; c < 8; c++) {
+        const int p3 = (int)((a[(c + 3) >> 2] >> (((c + 3) & 3) * 8)) & 255);
+        sum[c] = __builtin_amdgcn_sdot4(F0, (int)d[c], __builtin_amdgcn_sdot4(F1, (int)d[c + 4], acc0 + fx[3] * p3, false), false);
+      }
+    } else {
+      // 10-bit: sample pairs (m, m + 1) for m = 0..14 (odd m by funnel shift), 8 taps = four v_dot2_i32_i16
+      uint32_t pm[15];
+#pragma unroll
+      for (int m = 0; m < 15; m++) pm[m] = (m & 1) ? __builtin_amdgcn_alignbit(a[(m + 1) >> 1], a[m >> 1], 16) : a[m >> 1];
+      s16x2 fp[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) fp[u] = __builtin_bit_cast(s16x2, (uint32_t)(fx[2 * u] & 0xffff) | ((uint32_t)fx[2 * u + 1] << 16));
+#pragma unroll
+      for (int c = 0; c < 8; c++) {
+        int acc = 4;
+#pragma unroll
+        for (int u = 0; u < 4; u++) acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, pm[c + 2 * u]), fp[u], acc, false);
+        sum[c] = acc;
+      }
+    }
     uint32_t o[4];
 #pragma unroll
     for (int c = 0; c < 8; c++) {
-      int sum = 0;
-#pragma unroll
-      for (int t = 0; t < 8; t++) sum += fx[t] * v[c + t];
-      const uint32_t h = (uint32_t)((sum + 4) >> 3) & 0xffff;
+      const uint32_t h = (uint32_t)(sum[c] >> 3) & 0xffff;
       o[c >> 1] = (c & 1) ? (o[c >> 1] | (h << 16)) : h;
     }
     *reinterpret_cast<uint4 *>(im + j * 8) = make_uint4(o[0], o[1], o[2], o[3]);
@@ -228,7 +270,6 @@ __device__ __forceinline__ void mc_h16(const ES *win, int ws, int16_t *im, int l
 // After the LDS diet the kernel is VALU-bound, so the vertical sums run on v_dot2_i32_i16: the nine rows are interleaved
 // once per horizontal position into row PAIRS per column, pr[kp][c] = (row 2kp, row 2kp + 1) of column c (row 9 = 0), and a
 // candidate is 5 dot2 per sample instead of 9 multiply-adds + 9 extracts (exact: int16 x int16 into int32).
-typedef short s16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void mc_rows9(const int16_t *im, int lane, uint32_t (*pr)[8]) {
   uint4 rw[10];
 #pragma unroll
