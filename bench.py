@@ -73,6 +73,21 @@ def cpu_baseline(pipe, seconds=12.0):
                       "restoration (same stages as the GPU step) in %.1f s" % (done, dt)}
 
 
+def quality(pipe, bd):
+    """PSNR-Y of the loop-filtered reconstruction against the source, on the frames the last step left in HBM (the metric's
+    second half, "PSNR-Y delta vs libaom", needs libaom on the box: absent here, so only the absolute value is reported)"""
+    peak = float((1 << bd) - 1)
+    if hasattr(pipe, "d_ref"):                     # closed GOPs: the last P frames of all segments
+        src = pipe.src[pipe.gop - 1][0]
+        rec = pipe.d_ref[0].download(src.shape, src.dtype)
+    else:
+        src = pipe.src[0]
+        rec = pipe.d["out_y"].download(src.shape, src.dtype)
+    mse = float(np.mean((rec.astype(np.float64) - src.astype(np.float64)) ** 2))
+    return {"psnr_y_db": 10.0 * np.log10(peak * peak / mse) if mse > 0 else None, "frames": int(src.shape[0]),
+            "vs_libaom_db": None, "note": "fixed qindex, no rate control; libaom is not available on this box"}
+
+
 def entropy_leg(ctx, pipe, args, launches=5, host_seconds=6.0):
     """The stage after the block pipeline, timed on the levels + modes the last step left in HBM: (a) the GPU tile entropy
     coder (K9), HIP events on the pipeline's stream; (b) the host coder of the same syntax (host/entropy.cpp, the stage
@@ -262,6 +277,7 @@ def main():
                            "avg_launch_ms": ms / n, "launches": n}
         out["kernels"] = {k: {"launches": v[0], "avg_ms": v[1] / v[0],
                               "algorithmic_GBps": alg[k] / (v[1] / v[0] * 1e-3) / 1e9 if k in alg else None} for k, v in prof.items()}
+        out["quality"] = quality(pipe, bd)
         if world == 1 and not args.workload.endswith("-gop"):
             out["entropy"] = entropy_leg(ctx, pipe, args)
         if world == 1 and not args.no_cpu_baseline and not args.workload.endswith("-gop"):
