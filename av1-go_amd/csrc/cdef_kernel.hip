@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void k_cdef(CdefLaunch L) {
   const Pix *sy = reinterpret_cast<const Pix *>(L.src[0]) + (size_t)f * L.h * L.stride_y;
   Pix *dy = reinterpret_cast<Pix *>(L.dst[0]) + (size_t)f * L.h * L.stride_y;
   const int cw = L.w / 2, chh = L.h / 2;
-  // every tap of this superblock inside the picture?  (then the tile holds no sentinel and the packed path applies)
+  // every tap of this superblock inside the picture?  (then the tile holds no 0xFFFF mark: vector staging, no mark handling)
   const bool interior = sbx > 0 && sby > 0 && sbx * 64 + 66 <= L.w && sby * 64 + 66 <= L.h;
   // stage luma 68x68 and chroma 36x36 x2 (local (0,0) = picture (sb*64-2, sb*64-2))
   if (interior) {
