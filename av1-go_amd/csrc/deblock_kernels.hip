@@ -1,6 +1,6 @@
 // deblock_kernels.hip — SURVEY.md §8a row K5: the AV1 deblocking loop filter as ONE gfx950 kernel per plane.
 //
-// A workgroup owns a TW x TH window of output samples.  It stages the window plus a 16-sample halo of the
+// A workgroup owns a TW x TH window of output samples.  It stages the window plus an 8-sample halo of the
 // UNFILTERED source plane in LDS (coalesced row loads, uint16 per sample), runs pass 0 (vertical edges) on
 // every edge that can reach the window or the rows pass 1 will read, then pass 1 (horizontal edges) on the
 // window's columns, and writes the window back as whole rows.  Source and destination planes differ, so
@@ -121,7 +121,9 @@ __device__ __forceinline__ int lf_edge(uint32_t cur, uint32_t prev, int pass, in
 
 template <typename Pix, int TW, int TH>
 __global__ __launch_bounds__(256) void k_deblock(DeblockLaunch L) {
-  constexpr int HALO = 16, LW = TW + 2 * HALO, LH = TH + 2 * HALO, LS = LW + 2;   // +2: odd dword row stride
+  // Halo of 8: an edge needs at most p6..q6 (13-tap filter) plus the flatness tests up to p6/q6; an edge whose filter can
+  // reach the window lies in [0, TW] x [0, TH], so source samples in [-8, TW + 8) x [-8, TH + 8) are all that is ever read
+  constexpr int HALO = 8, LW = TW + 2 * HALO, LH = TH + 2 * HALO, LS = LW + 2;   // +2: odd dword row stride
   constexpr int MW = LW / 4, MH = LH / 4;
   __shared__ uint16_t tile[LH * LS];
   __shared__ uint32_t mis[MH * MW];
@@ -158,14 +160,15 @@ __global__ __launch_bounds__(256) void k_deblock(DeblockLaunch L) {
     }
   }
   __syncthreads();
-  // pass 0: vertical edges at lx = 4*uc, uc in [3, TW/4+5], rows [4, TH+28)
+  // pass 0: vertical edges at lx = 4*uc, uc in [2, TW/4+2] (frame x in [0, TW]), all LH rows (pass 1 reads 7 rows beyond
+  // the window's first and last edge)
   {
-    constexpr int NU = TW / 4 + 3, NR = TH + 24;
+    constexpr int NU = TW / 4 + 1, NR = LH;
     // lanes of a wave walk DOWN one unit column (rows are an odd number of dwords apart: no bank conflicts), so the edge
     // decision — transform edge or not, filter length — is the same for nearly the whole wave instead of alternating lane
     // by lane with 8x8 transforms
     for (int t = tid; t < NU * NR; t += 256) {
-      const int uc = 3 + t / NR, ly = 4 + t % NR;
+      const int uc = 2 + t / NR, ly = t % NR;
       const int fx = X0 + 4 * uc, fy = Y0 + ly;
       if (fx <= 0 || fy < 0 || fy >= L.h) continue;
       int lvl = 0;
@@ -183,11 +186,11 @@ __global__ __launch_bounds__(256) void k_deblock(DeblockLaunch L) {
     }
   }
   __syncthreads();
-  // pass 1: horizontal edges at ly = 4*ur, ur in [3, TH/4+5], columns of the window
+  // pass 1: horizontal edges at ly = 4*ur, ur in [2, TH/4+2] (frame y in [0, TH]), columns of the window
   {
-    constexpr int NU = TH / 4 + 3;
+    constexpr int NU = TH / 4 + 1;
     for (int t = tid; t < NU * TW; t += 256) {
-      const int lx = HALO + t % TW, ur = 3 + t / TW;
+      const int lx = HALO + t % TW, ur = 2 + t / TW;
       const int fx = X0 + lx, fy = Y0 + 4 * ur;
       if (fy <= 0 || fx >= L.w) continue;
       int lvl = 0;
