@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void k_me_int(InterLaunch L) {
   __shared__ uint32_t s_best[64];                    // per 8x8 block: min of (SAD, rank)
   constexpr int sh = sizeof(Pix) == 1 ? 0 : 2;
   const int tid = threadIdx.x, R = L.range, R4 = (R + 3) & ~3, NC = 2 * R + 1;
-  const int WDX = 64 + 2 * R4 + 4, WDY = 64 + 2 * R;        // window columns start at x - R4 (4-aligned), rows at y - R
+  const int WDX = 64 + 2 * R4 + 4, WDY = 64 + 2 * R + 1;    // window columns start at x - R4 (4-aligned), rows at y - R; one more row for the unused half of the last dy pair
   const int sbw = (L.w + 63) / 64;
   const int f = blockIdx.y, sb = blockIdx.x, sby = sb / sbw, sbx = sb % sbw;
   const Pix *src = reinterpret_cast<const Pix *>(L.src[0]) + (size_t)f * L.h * L.stride_y;
@@ -88,38 +88,48 @@ __global__ __launch_bounds__(256) void k_me_int(InterLaunch L) {
   const int wave = tid >> 6, lane = tid & 63;
   const int bw = L.w / 8, bh = L.h / 8;
   const int NG = (2 * R4) / 4 + 1;                 // groups of four dx starting at -R4
-  const int per = NC * NG;                         // (dy, dx group) items per block
+  const int NP = (NC + 1) >> 1;                    // pairs of vertical displacements (the last pair may hold one)
+  const int per = NP * NG;                         // (dy pair, dx group) items per block
   int16_t *mvs = L.mvs + (size_t)f * bw * bh * 2;
-  // the 16 blocks of a wave form ONE item space (16 x per): with +-8 a block has 85 items, which alone would leave the
-  // second pass of a 64-lane wave two thirds empty; the per-block minimum is an LDS atomic instead of a wave reduction
+  // A lane scores TWO vertically adjacent displacements of four horizontal ones: they share seven of their eight window
+  // rows, so nine rows of three dwords are read for 32 QSADs instead of sixteen.  The 16 blocks of a wave form ONE item
+  // space (16 x per): with +-8 a block has 45 items, which alone would leave a 64-lane wave a third empty; the per-block
+  // minimum is an LDS atomic instead of a wave reduction.
   for (int u0 = 0; u0 < 16 * per; u0 += 64) {
     const int u = u0 + lane;
     if (u < 16 * per) {
       const int bi = u / per, t = u - bi * per, b = wave + 4 * bi;
       const int by = b >> 3, bx = b & 7;
       if (sbx * 8 + bx < bw && sby * 8 + by < bh) {
-        const int dyi = t / NG, g = t - dyi * NG;  // dy = dyi - R, dx0 = -R4 + 4 g
-        const uint8_t *p = win + (by * 8 + dyi) * WS + bx * 8 + 4 * g;
+        const int dp = t / NG, g = t - dp * NG;    // dy = 2 dp - R and 2 dp + 1 - R, dx0 = -R4 + 4 g
+        const uint8_t *p = win + (by * 8 + 2 * dp) * WS + bx * 8 + 4 * g;
         const uint8_t *s = srct + (by * 8) * 64 + bx * 8;
-        unsigned long long acc = 0;
+        uint2 sr[8];
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
-          const uint32_t *q = reinterpret_cast<const uint32_t *>(p + r * WS);
-          const uint2 sr = *reinterpret_cast<const uint2 *>(s + r * 64);
+        for (int r = 0; r < 8; r++) sr[r] = *reinterpret_cast<const uint2 *>(s + r * 64);
+        unsigned long long acc0 = 0, acc1 = 0;
+#pragma unroll
+        for (int r = 0; r < 9; r++) {
+          const uint32_t *q = reinterpret_cast<const uint32_t *>(p + r * WS);   // row 2 dp + r <= 2 R + 8: inside the window
           const unsigned long long w01 = (unsigned long long)q[0] | ((unsigned long long)q[1] << 32);
           const unsigned long long w12 = (unsigned long long)q[1] | ((unsigned long long)q[2] << 32);
-          acc = __builtin_amdgcn_qsad_pk_u16_u8(w01, sr.x, acc);
-          acc = __builtin_amdgcn_qsad_pk_u16_u8(w12, sr.y, acc);
+          if (r < 8) { acc0 = __builtin_amdgcn_qsad_pk_u16_u8(w01, sr[r].x, acc0); acc0 = __builtin_amdgcn_qsad_pk_u16_u8(w12, sr[r].y, acc0); }
+          if (r > 0) { acc1 = __builtin_amdgcn_qsad_pk_u16_u8(w01, sr[r - 1].x, acc1); acc1 = __builtin_amdgcn_qsad_pk_u16_u8(w12, sr[r - 1].y, acc1); }
         }
         unsigned best = 0xFFFFFFFFu;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-          const int dx = -R4 + 4 * g + i, dy = dyi - R;
-          if (dx >= -R && dx <= R) {
-            const unsigned sad = (unsigned)(acc >> (16 * i)) & 0xFFFFu;
-            // (0,0) ranks first, the others in raster order; ties keep the lower rank
-            const unsigned key = sad * 1024u + ((dx | dy) ? (unsigned)((dy + R) * NC + dx + R) + 1u : 0u);
-            best = min(best, key);
+        for (int h = 0; h < 2; h++) {
+          const int dyi = 2 * dp + h, dy = dyi - R;
+          const unsigned long long acc = h ? acc1 : acc0;
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const int dx = -R4 + 4 * g + i;
+            if (dx >= -R && dx <= R && dyi < NC) {
+              const unsigned sad = (unsigned)(acc >> (16 * i)) & 0xFFFFu;
+              // (0,0) ranks first, the others in raster order; ties keep the lower rank
+              const unsigned key = sad * 1024u + ((dx | dy) ? (unsigned)((dy + R) * NC + dx + R) + 1u : 0u);
+              best = min(best, key);
+            }
           }
         }
         atomicMin(&s_best[b], best);
