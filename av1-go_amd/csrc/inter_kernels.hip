@@ -154,6 +154,26 @@ __global__ __launch_bounds__(256) void k_me_int(InterLaunch L) {
 // window starts 4 samples left of / above the integer-vector block): posx/posy = displacement from the window's block
 // origin in 1/16 samples, in [-16, 15].  im: (B+7) x B int16 scratch of the group.  NL = lanes of the block.
 typedef short s16x2 __attribute__((ext_vector_type(2)));
+// One window row of N samples from plane row `row`, columns x0 .. x0 + N - 1, into the dword-aligned LDS row `dst`.
+// Inside the plane it is one unaligned vector load (the hardware takes any address) and N * sizeof(Pix) / 4 dword stores;
+// rows that stick out clamp sample by sample (the spec's edge extension).
+template <int N, typename Pix> __device__ __forceinline__ void stage_window_row(const Pix *row, int x0, int w, Pix *dst) {
+  constexpr int ND = N * (int)sizeof(Pix) / 4;
+  uint32_t u[ND];
+  if (x0 >= 0 && x0 + N <= w) __builtin_memcpy(u, row + x0, sizeof(u));
+  else {
+    constexpr int PER = 4 / (int)sizeof(Pix);
+#pragma unroll
+    for (int d = 0; d < ND; d++) {
+      u[d] = 0;
+#pragma unroll
+      for (int k = 0; k < PER; k++) u[d] |= (uint32_t)row[min(max(x0 + d * PER + k, 0), w - 1)] << (k * 8 * (int)sizeof(Pix));
+    }
+  }
+  uint32_t *q = reinterpret_cast<uint32_t *>(dst);
+#pragma unroll
+  for (int d = 0; d < ND; d++) q[d] = u[d];
+}
 // N consecutive samples starting `ox` samples into a dword-aligned LDS row: aligned dword reads + funnel shift, so that the
 // row costs (N * sizeof(ES)) / 4 + 1 LDS reads instead of N (k_inter_pipe is LDS-bound).  ox in [0, 4 / sizeof(ES)).
 template <int N, typename ES> __device__ __forceinline__ void row_samples(const ES *row, int ox, int *v) {
@@ -354,18 +374,7 @@ __global__ __launch_bounds__(256) void k_inter_pipe(InterLaunch L) {
     const int r = lane + it * 8;
     const int fy = min(max(y + imy - 4 + r, 0), L.h - 1);
     const Pix *row = ref_y + (size_t)fy * L.stride_y;
-    ES px[YW];
-#pragma unroll
-    for (int c = 0; c < YW; c++) px[c] = row[min(max(x + imx - 4 + c, 0), L.w - 1)];
-    uint32_t *wrow = reinterpret_cast<uint32_t *>(wy + r * YWS);      // packed dword stores
-    constexpr int PER = 4 / (int)sizeof(ES);
-#pragma unroll
-    for (int d = 0; d < YW / PER; d++) {
-      uint32_t u = 0;
-#pragma unroll
-      for (int k = 0; k < PER; k++) u |= (uint32_t)px[d * PER + k] << (k * 8 * (int)sizeof(ES));
-      wrow[d] = u;
-    }
+    stage_window_row<YW, Pix>(row, x + imx - 4, L.w, wy + r * YWS);
   }
   int s[8], bp[8], out[8];
   load_row<8>(src_y + (size_t)(y + lane) * L.stride_y + x, s);
@@ -441,18 +450,7 @@ __global__ __launch_bounds__(256) void k_inter_pipe(InterLaunch L) {
       const int r = cl + it * 4;
       const int fy = min(max(cy0 + ciy - 4 + r, 0), chh - 1);
       const Pix *row = ref_c + (size_t)fy * L.stride_uv;
-      ES px[CW];
-#pragma unroll
-      for (int c = 0; c < CW; c++) px[c] = row[min(max(cx0 + cix - 4 + c, 0), cw - 1)];
-      uint32_t *wrow = reinterpret_cast<uint32_t *>(wc + r * CWS);
-      constexpr int PER = 4 / (int)sizeof(ES);
-#pragma unroll
-      for (int d = 0; d < CW / PER; d++) {
-        uint32_t u = 0;
-#pragma unroll
-        for (int k = 0; k < PER; k++) u |= (uint32_t)px[d * PER + k] << (k * 8 * (int)sizeof(ES));
-        wrow[d] = u;
-      }
+      stage_window_row<CW, Pix>(row, cx0 + cix - 4, cw, wc + r * CWS);
     }
     int sc[4], pc[4], rc[4];
     load_row<4>(src_c + (size_t)(cy0 + cl) * L.stride_uv + cx0, sc);
