@@ -235,14 +235,15 @@ __device__ inline uint2 step(Enc &e, const uint2 v, uint32_t op) {   // returns 
   e.low = (e.low + add) << d;      // <= 17 + 31 + 15 bits
   e.rng = nrng << d;
   e.pend += d;
-  if (e.pend >= 32) {
-    e.pend -= 32;
-    const uint64_t w = e.low >> (16 + e.pend);
-    e.low &= ((uint64_t)1 << (16 + e.pend)) - 1;
-    if (w >> 32) ripple(e);
-    if (e.n < e.cap) e.out[e.n] = __builtin_bswap32((uint32_t)w);
-    e.n++;
-  }
+  // flush of 32 finished bits as straight-line code: selects instead of a branch (in a wave of 64 coders some lane flushes at
+  // almost every step, so the branch would be taken anyway), only the store itself and the rare ripple are predicated
+  const bool fl = e.pend >= 32;
+  e.pend = fl ? e.pend - 32 : e.pend;
+  const uint64_t w = e.low >> (16 + e.pend);
+  e.low = fl ? e.low & (((uint64_t)1 << (16 + e.pend)) - 1) : e.low;
+  if (fl && (w >> 32)) ripple(e);
+  if (fl && e.n < e.cap) e.out[e.n] = __builtin_bswap32((uint32_t)w);
+  e.n += fl;
   // adaptation in inverse form: i_k -= i_k >> rate for k >= s (c_k moves up), i_k += (32768 - i_k) >> rate for k < s
   const uint32_t cnt = v.y >> 16;
   const unsigned short rate = (unsigned short)(5 + (cnt > 15) + (cnt > 31));
@@ -282,12 +283,14 @@ __global__ void __launch_bounds__(64) k_ent_code(EntropyLaunch L) {
     const uint4 nxt = src[nq < last ? nq : last];            // next 8 ops, in flight while these are coded
     const uint32_t wd[4] = { cur.x, cur.y, cur.z, cur.w };
 #pragma unroll
-    for (int k = 0; k < 8; k++)
-      if (base + k < nops) {
-        const uint32_t op = (wd[k >> 1] >> ((k & 1) * 16)) & 0xFFFF, id = (op & OP_RAW) ? 0u : op >> 8;   // raw ops read CDF 0 and leave it alone
-        const uint2 nv = step(e, m[id], op);
-        if (!(op & OP_RAW)) m[id] = nv;
-      }
+    for (int k = 0; k < 8; k++) {
+      // lanes past the end of their list code a no-op (zero raw bits leave the coder state as it is): no branch per op
+      const uint32_t op = base + k < nops ? (wd[k >> 1] >> ((k & 1) * 16)) & 0xFFFF : OP_RAW;
+      const bool raw = (op & OP_RAW) != 0;
+      const uint32_t id = raw ? 0u : op >> 8;            // raw ops read CDF 0 and write it back unchanged
+      const uint2 v = m[id], nv = step(e, v, op);
+      m[id] = make_uint2(raw ? v.x : nv.x, raw ? v.y : nv.y);
+    }
     cur = nxt;
   }
   if (live) {
