@@ -282,14 +282,23 @@ __global__ void __launch_bounds__(64) k_ent_code(EntropyLaunch L) {
     const int nq = (base >> 3) + 1;
     const uint4 nxt = src[nq < last ? nq : last];            // next 8 ops, in flight while these are coded
     const uint32_t wd[4] = { cur.x, cur.y, cur.z, cur.w };
+    // lanes past the end of their list code a no-op (zero raw bits leave the coder state as it is): no branch per op.
+    // The CDF of op k + 1 is requested BEFORE op k's arithmetic (LDS keeps program order, so it returns the value from
+    // before op k's write-back); if it is the CDF op k adapts, the adapted value is forwarded instead.
+    auto op_at = [&](int k) -> uint32_t { return base + k < nops ? (wd[k >> 1] >> ((k & 1) * 16)) & 0xFFFF : OP_RAW; };
+    uint32_t op = op_at(0), id = (op & OP_RAW) ? 0u : op >> 8;     // raw ops read CDF 0 and write it back unchanged
+    uint2 v = m[id];
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-      // lanes past the end of their list code a no-op (zero raw bits leave the coder state as it is): no branch per op
-      const uint32_t op = base + k < nops ? (wd[k >> 1] >> ((k & 1) * 16)) & 0xFFFF : OP_RAW;
+      const uint32_t opn = k < 7 ? op_at(k + 1) : OP_RAW, idn = (opn & OP_RAW) ? 0u : opn >> 8;
+      uint2 early = v;
+      if (k < 7) early = m[idn];
       const bool raw = (op & OP_RAW) != 0;
-      const uint32_t id = raw ? 0u : op >> 8;            // raw ops read CDF 0 and write it back unchanged
-      const uint2 v = m[id], nv = step(e, v, op);
-      m[id] = make_uint2(raw ? v.x : nv.x, raw ? v.y : nv.y);
+      const uint2 nv = step(e, v, op);
+      const uint2 wv = make_uint2(raw ? v.x : nv.x, raw ? v.y : nv.y);
+      m[id] = wv;
+      v = idn == id ? wv : early;
+      op = opn; id = idn;
     }
     cur = nxt;
   }
