@@ -59,9 +59,12 @@ __global__ __launch_bounds__(256) void k_lr(LrLaunch L) {
   // stage (bh + 6) rows x (bw + 8) columns of source samples: local row 0 == y0 - 3, local column 0 == X0 - 4 (4-aligned)
   const bool xin = X0 >= 4 && X0 + bw + 4 <= L.w && !(bw & 3);   // no horizontal clamping, whole 4-sample groups
   if (xin) {
+    // full-width bands (every band of a picture whose width is a multiple of 64) get compile-time divisors: an integer
+    // division by a runtime value is ~25 VALU instructions, and this kernel is VALU-bound
+    const bool full = bw == MAXW;
     const int ng = (bw + 8) / 4;
     for (int i = tid; i < (bh + 6) * ng; i += 256) {
-      const int r = i / ng, g = i - r * ng;
+      const int r = full ? i / ((MAXW + 8) / 4) : i / ng, g = i - r * ng;
       int y = min(max(y0 - 3 + r, 0), L.h - 1);
       const Pix *p = cdef;
       if (y < sstart) { y = max(sstart - 2, y); p = dbl; }
@@ -99,8 +102,9 @@ __global__ __launch_bounds__(256) void k_lr(LrLaunch L) {
     if (!(bw & 3)) {
       // four outputs per lane: ten source samples read once; the vertical pass reads four int16 per tap as one 8-byte word
       const int q4 = bw / 4;
+      const bool full = bw == MAXW;
       for (int i = tid; i < (bh + 6) * q4; i += 256) {
-        const int r = i / q4, c = (i - r * q4) * 4;
+        const int r = full ? i / (MAXW / 4) : i / q4, c = (i - r * q4) * 4;
         const uint16_t *p = src + r * SS + c + 1;
         int v[10];
 #pragma unroll
@@ -118,7 +122,7 @@ __global__ __launch_bounds__(256) void k_lr(LrLaunch L) {
       }
       __syncthreads();
       for (int i = tid; i < bh * q4; i += 256) {
-        const int r = i / q4, c = (i - r * q4) * 4;
+        const int r = full ? i / (MAXW / 4) : i / q4, c = (i - r * q4) * 4;
         int sum[4] = { 0, 0, 0, 0 };
 #pragma unroll
         for (int t = 0; t < 7; t++) {
