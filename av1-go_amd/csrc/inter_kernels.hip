@@ -395,7 +395,9 @@ __global__ __launch_bounds__(256) void k_inter_pipe(InterLaunch L) {
     return group_sum<8>((int)v);
   };
   // candidate 0: the integer vector itself
-  mc_row<8, ES>(wy, YWS, im, lane, 0, 0, kRegular8, bd, bp);
+  // (phase 0 of the 8-tap filter is the identity: taps 0 0 0 128 0 0 0 0, and (128 p + 4) >> 3 = 16 p, (128 * 16 p + 1024) >> 11
+  // = p exactly — so the integer position is a copy of the window's centre)
+  row_samples<8, ES>(wy + (lane + 4) * YWS + 4, 0, bp);
   pack4(bp, bpp);
   int best = sad_of(bpp), bfx = 0, bfy = 0;     // fractional part in 1/8 samples relative to the integer vector
   for (int step = 4; step >= 2; step >>= 1) {
