@@ -35,6 +35,10 @@ INTRA_BLK_DTYPE = np.dtype([("x", "<u2"), ("y", "<u2"), ("mode", "u1"), ("angle_
                             ("reserved", "u1", (5,))])
 assert INTRA_BLK_DTYPE.itemsize == 16 and TXB_DTYPE.itemsize == 16
 
+CFL_BLK_DTYPE = np.dtype([("x", "<u2"), ("y", "<u2"), ("max_luma_w", "<u2"), ("max_luma_h", "<u2"), ("alpha_q3", "i1"),
+                          ("reserved", "u1", (7,))])
+assert CFL_BLK_DTYPE.itemsize == 16
+
 MC_BLK_DTYPE = np.dtype([("x", "<u2"), ("y", "<u2"), ("mvx", "<i2"), ("mvy", "<i2"), ("filt_x", "u1"), ("filt_y", "u1"),
                          ("reserved", "u1", (6,))])
 assert MC_BLK_DTYPE.itemsize == 16
@@ -215,6 +219,10 @@ class Context:
     def intra_pred_list(self, tx_size, d_ref, ref_stride, d_dst, dst_stride, bd, d_list, nblocks):
         self._chk(self.lib.av1mi_intra_pred_list(self.h, tx_size, C.c_void_p(d_ref.ptr), ref_stride, C.c_void_p(d_dst.ptr),
                                                  dst_stride, bd, C.c_void_p(d_list.ptr), nblocks))
+
+    def cfl_pred_list(self, tx_size, d_luma, luma_stride, d_dst, dst_stride, bd, d_list, nblocks):
+        self._chk(self.lib.av1mi_cfl_pred_list(self.h, tx_size, C.c_void_p(d_luma.ptr), luma_stride, C.c_void_p(d_dst.ptr), dst_stride,
+                                               bd, C.c_void_p(d_list.ptr), nblocks))
 
     # ---- K4
     def mc_list(self, size_id, d_ref, ref_stride, plane_w, plane_h, d_dst, dst_stride, bd, d_list, nblocks):

@@ -25,6 +25,12 @@ struct IntraLaunch {
   const av1mi_intra_blk *blocks;
 };
 hipError_t launch_intra_pred(int tx_size, const IntraLaunch &L, hipStream_t s);
+struct CflLaunch {
+  const void *luma; void *dst;
+  int luma_stride, dst_stride, bd, nblocks;
+  const av1mi_cfl_blk *blocks;
+};
+hipError_t launch_cfl_pred(int tx_size, const CflLaunch &L, hipStream_t s);
 
 // K5: one plane, source -> destination (different allocations)
 struct DeblockLaunch {

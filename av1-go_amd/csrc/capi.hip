@@ -304,6 +304,22 @@ int av1mi_intra_pred_list(av1mi_ctx *ctx, int tx_size, const void *d_ref, int re
   return AV1MI_OK;
 }
 
+int av1mi_cfl_pred_list(av1mi_ctx *ctx, int tx_size, const void *d_luma, int luma_stride, void *d_dst, int dst_stride, int bd,
+                        const av1mi_cfl_blk *d_list, int nblocks) {
+  BIND(ctx);
+  if (bd != 8 && bd != 10) return fail(ctx, AV1MI_E_INVAL, "bit depth %d not supported (8 or 10)", bd);
+  if (tx_size < 0 || tx_size >= AV1MI_TX_SIZES_ALL || av1mi::tx_width(tx_size) > 32 || av1mi::tx_height(tx_size) > 32)
+    return fail(ctx, AV1MI_E_INVAL, "chroma-from-luma is defined for blocks up to 32x32 (tx_size %d)", tx_size);
+  if (nblocks < 0) return fail(ctx, AV1MI_E_INVAL, "nblocks %d < 0", nblocks);
+  if (nblocks == 0) return AV1MI_OK;
+  if (!d_luma || !d_dst || !d_list) return fail(ctx, AV1MI_E_INVAL, "null device pointer");
+  if (luma_stride <= 0 || dst_stride <= 0 || (dst_stride & 3)) return fail(ctx, AV1MI_E_INVAL, "bad strides %d/%d", luma_stride, dst_stride);
+  av1mi::CflLaunch L;
+  L.luma = d_luma; L.dst = d_dst; L.luma_stride = luma_stride; L.dst_stride = dst_stride; L.bd = bd; L.nblocks = nblocks; L.blocks = d_list;
+  { ProfScope ps(ctx, AV1MI_K_INTRA_PRED); HIP_TRY(ctx, av1mi::launch_cfl_pred(tx_size, L, ctx->stream)); }
+  return AV1MI_OK;
+}
+
 int av1mi_mc_list(av1mi_ctx *ctx, int size_id, const void *d_ref, int ref_stride, int plane_w, int plane_h, void *d_dst,
                   int dst_stride, int bd, const av1mi_mc_blk *d_list, int nblocks) {
   BIND(ctx);

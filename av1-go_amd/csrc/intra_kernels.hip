@@ -62,4 +62,70 @@ hipError_t launch_intra_pred(int tx_size, const IntraLaunch &L, hipStream_t s) {
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------ chroma from luma
+// Spec 7.11.5, 4:2:0.  Block = BH lanes of one wave, lane = row: two luma rows of 2 BW samples -> BW sums, the block average
+// by cross-lane sums, then the row of the DC prediction in d_dst is corrected in place.  Restated in oracle/av1o_intra.c
+// (av1o_cfl_predict); the reference has no counterpart.
+template <int BW, int BH, typename Pix>
+__global__ __launch_bounds__(256) void k_cfl_pred(CflLaunch L) {
+  constexpr int NB = 256 / BH;
+  const int grp = threadIdx.x / BH, lane = threadIdx.x % BH;
+  const int b = blockIdx.x * NB + grp;
+  if (b >= L.nblocks) return;
+  const av1mi_cfl_blk d = L.blocks[b];
+  const Pix *luma = reinterpret_cast<const Pix *>(L.luma);
+  const int ly = min(2 * (d.y + lane), (int)d.max_luma_h - 2);
+  const Pix *r0 = luma + (size_t)ly * L.luma_stride, *r1 = r0 + L.luma_stride;
+  int Lq[BW], rowsum = 0;
+  const bool inside = 2 * (d.x + BW) <= (int)d.max_luma_w;
+  if (inside) {
+    Pix a[2 * BW], c[2 * BW];
+    __builtin_memcpy(a, r0 + 2 * d.x, sizeof(a));
+    __builtin_memcpy(c, r1 + 2 * d.x, sizeof(c));
+#pragma unroll
+    for (int j = 0; j < BW; j++) Lq[j] = ((int)a[2 * j] + a[2 * j + 1] + c[2 * j] + c[2 * j + 1]) << 1;
+  } else {
+#pragma unroll
+    for (int j = 0; j < BW; j++) {
+      const int lx = min(2 * (d.x + j), (int)d.max_luma_w - 2);
+      Lq[j] = ((int)r0[lx] + r0[lx + 1] + r1[lx] + r1[lx + 1]) << 1;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < BW; j++) rowsum += Lq[j];
+  int total = group_sum<(BH > 16 ? 16 : BH)>(rowsum);
+  if constexpr (BH == 32) total += __shfl_xor(total, 16, 64);      // the two 16-lane halves of the block
+  constexpr int lg = (BW == 4 ? 2 : BW == 8 ? 3 : BW == 16 ? 4 : 5) + (BH == 4 ? 2 : BH == 8 ? 3 : BH == 16 ? 4 : 5);
+  const int avg = (total + (1 << (lg - 1))) >> lg;
+  Pix *dst = reinterpret_cast<Pix *>(L.dst) + (size_t)(d.y + lane) * L.dst_stride + d.x;
+  const int maxpix = (1 << L.bd) - 1, alpha = d.alpha_q3;
+  Pix dc[BW];
+  __builtin_memcpy(dc, dst, sizeof(dc));
+  int out[BW];
+#pragma unroll
+  for (int j = 0; j < BW; j++) {
+    const int v = alpha * (Lq[j] - avg), m = v < 0 ? -v : v, sl = (m + 32) >> 6;
+    out[j] = min(max((int)dc[j] + (v < 0 ? -sl : sl), 0), maxpix);
+  }
+#pragma unroll
+  for (int c = 0; c < BW; c += 4) store4(dst + c, out + c);
+}
+template <int BW, int BH> static void launch_cfl_one(const CflLaunch &L, hipStream_t s) {
+  constexpr int NB = 256 / BH;
+  const int grid = (L.nblocks + NB - 1) / NB;
+  if (L.bd == 8) hipLaunchKernelGGL((k_cfl_pred<BW, BH, uint8_t>), dim3(grid), dim3(256), 0, s, L);
+  else hipLaunchKernelGGL((k_cfl_pred<BW, BH, uint16_t>), dim3(grid), dim3(256), 0, s, L);
+}
+hipError_t launch_cfl_pred(int tx_size, const CflLaunch &L, hipStream_t s) {
+  if (L.nblocks <= 0) return hipSuccess;
+  switch (tx_size) {   // CfL exists for chroma blocks up to 32x32
+#define X(id, w, h) case id: launch_cfl_one<w, h>(L, s); break;
+    X(0, 4, 4) X(1, 8, 8) X(2, 16, 16) X(3, 32, 32) X(5, 4, 8) X(6, 8, 4) X(7, 8, 16) X(8, 16, 8) X(9, 16, 32) X(10, 32, 16)
+    X(13, 4, 16) X(14, 16, 4) X(15, 8, 32) X(16, 32, 8)
+#undef X
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
 }  // namespace av1mi

@@ -138,6 +138,19 @@ typedef struct av1mi_intra_blk {
 int av1mi_intra_pred_list(av1mi_ctx *ctx, int tx_size, const void *d_ref, int ref_stride, void *d_dst, int dst_stride,
                           int bd, const av1mi_intra_blk *d_list, int nblocks);
 
+/* ---- K3, chroma-from-luma (AV1 spec §7.11.5; SURVEY.md §8f rank 4 "remaining intra modes"), 4:2:0.  For every listed
+ * chroma block (tx_size up to 32x32) d_dst already holds the DC prediction; the block becomes
+ *   Clip1(dc + Round2Signed(alpha_q3 * (L - avg L), 6)),  L = (2x2 sum of the reconstructed luma) << 1,
+ * with luma coordinates limited to max_luma_w - 2 / max_luma_h - 2 (the spec's MaxLumaW / MaxLumaH).  alpha_q3 in -16..16. */
+typedef struct av1mi_cfl_blk {
+  uint16_t x, y;                 /* chroma block position in the chroma plane; x multiple of 4 */
+  uint16_t max_luma_w, max_luma_h;
+  int8_t alpha_q3;
+  uint8_t reserved[7];
+} av1mi_cfl_blk;
+int av1mi_cfl_pred_list(av1mi_ctx *ctx, int tx_size, const void *d_luma, int luma_stride, void *d_dst, int dst_stride, int bd,
+                        const av1mi_cfl_blk *d_list, int nblocks);
+
 /* ---- K4: sub-pel motion compensation (AV1 spec §7.11.3.4; single reference, unscaled, no compound) of a list
  * of blocks of one size.  size_id uses the TX_SIZE numbering for w x h (0 4x4 .. 4 64x64, 5 4x8 ...).  Each block
  * at (x, y) of the plane (x multiple of 4) is predicted from d_ref displaced by (mvx, mvy) in 1/16-sample units of

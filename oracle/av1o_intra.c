@@ -303,3 +303,47 @@ int av1o_intra_predict(const void *ref, int ref_stride, int bd, int bw, int bh, 
   }
   return 0;
 }
+
+
+/*
+ * Chroma-from-luma prediction, 4:2:0: AV1 spec 7.11.5 (predict chroma from luma process) == libaom cfl_predict_block
+ * (cfl_luma_subsampling_420_*, subtract average, cfl_predict_*).  `luma` is the reconstructed luma plane, `dst` the chroma
+ * plane whose block at (x, y), bw x bh (each 4..32), already holds the DC prediction; it is overwritten with
+ *   Clip1(dc + Round2Signed(alpha_q3 * (L[i][j] - Round2(sum L, log2 bw + log2 bh)), 6)),
+ *   L[i][j] = (sum of the 2x2 luma samples at (2(y+i), 2(x+j))) << 1,
+ * luma coordinates limited to max_luma_w - 2 / max_luma_h - 2 (the spec's MaxLumaW / MaxLumaH: the part of the luma
+ * block that has been reconstructed; beyond it the last available 2x2 group is repeated).
+ */
+int av1o_cfl_predict(const void *luma, int luma_stride, void *dst, int dst_stride, int bd, int x, int y, int bw, int bh,
+                     int alpha_q3, int max_luma_w, int max_luma_h) {
+  int32_t L[32 * 32];
+  int64_t sum = 0;
+  int i, j, lg = 0;
+  const int maxpix = (1 << bd) - 1;
+  if (bw < 4 || bh < 4 || bw > 32 || bh > 32 || (bw & (bw - 1)) || (bh & (bh - 1)) || alpha_q3 < -16 || alpha_q3 > 16) return -1;
+  if (max_luma_w < 2 || max_luma_h < 2) return -1;
+  for (i = bw * bh; i > 1; i >>= 1) lg++;
+  for (i = 0; i < bh; i++)
+    for (j = 0; j < bw; j++) {
+      int ly = 2 * (y + i), lx = 2 * (x + j), t = 0, dy, dx;
+      if (ly > max_luma_h - 2) ly = max_luma_h - 2;
+      if (lx > max_luma_w - 2) lx = max_luma_w - 2;
+      for (dy = 0; dy < 2; dy++)
+        for (dx = 0; dx < 2; dx++)
+          t += bd == 8 ? ((const uint8_t *)luma)[(size_t)(ly + dy) * luma_stride + lx + dx]
+                       : ((const uint16_t *)luma)[(size_t)(ly + dy) * luma_stride + lx + dx];
+      L[i * bw + j] = t << 1;
+      sum += L[i * bw + j];
+    }
+  {
+    const int avg = (int)((sum + ((int64_t)1 << (lg - 1))) >> lg);
+    for (i = 0; i < bh; i++)
+      for (j = 0; j < bw; j++) {
+        const int v = alpha_q3 * (L[i * bw + j] - avg);
+        const int sl = v >= 0 ? (v + 32) >> 6 : -((-v + 32) >> 6);
+        if (bd == 8) { uint8_t *p = (uint8_t *)dst + (size_t)(y + i) * dst_stride + x + j; *p = (uint8_t)av1o_clampi(*p + sl, 0, maxpix); }
+        else { uint16_t *p = (uint16_t *)dst + (size_t)(y + i) * dst_stride + x + j; *p = (uint16_t)av1o_clampi(*p + sl, 0, maxpix); }
+      }
+  }
+  return 0;
+}

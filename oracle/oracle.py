@@ -321,3 +321,15 @@ def entropy_encode_frame(w, h, key, tile, lev_y, lev_u, lev_v, modes_y=None, mod
     if n == C.c_size_t(-1).value:
         raise ValueError("av1o_entropy_encode_frame: capacity")
     return out[:n].tobytes()
+
+
+def cfl_predict(luma, dc_plane, bd, x, y, bw, bh, alpha_q3, max_luma_w=None, max_luma_h=None):
+    """chroma-from-luma (4:2:0): returns a copy of dc_plane with the block at (x, y) replaced by the CfL prediction"""
+    dt = np.uint8 if bd == 8 else np.uint16
+    luma = np.ascontiguousarray(luma, dt)
+    out = np.ascontiguousarray(dc_plane, dt).copy()
+    rc = lib().av1o_cfl_predict(luma.ctypes.data_as(C.c_void_p), luma.shape[1], out.ctypes.data_as(C.c_void_p), out.shape[1], bd, x, y,
+                                bw, bh, alpha_q3, max_luma_w or luma.shape[1], max_luma_h or luma.shape[0])
+    if rc:
+        raise ValueError("av1o_cfl_predict rc=%d" % rc)
+    return out

@@ -79,3 +79,42 @@ def test_intra_pred_every_angle_8x8_16x16(ctx, O, av1mi):
             d_l.free(); d_dst.free()
             assert (got == exp).all(), ((bw, bh), O.INTRA_MODE_NAMES[m], d, ft, dis)
         d_ref.free()
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_cfl_pred_matches_oracle(ctx, O, av1mi, bd):
+    """chroma-from-luma (spec 7.11.5) for every chroma transform size up to 32x32, all alphas, with and without the
+    MaxLumaW / MaxLumaH limits, many blocks per launch"""
+    rng = np.random.default_rng(90 + bd)
+    dt = np.uint8 if bd == 8 else np.uint16
+    LH, LW = 256, 384
+    luma = rng.integers(0, 1 << bd, (LH, LW)).astype(dt)
+    sizes = {0: (4, 4), 1: (8, 8), 2: (16, 16), 3: (32, 32), 5: (4, 8), 6: (8, 4), 7: (8, 16), 8: (16, 8), 9: (16, 32), 10: (32, 16),
+             13: (4, 16), 14: (16, 4), 15: (8, 32), 16: (32, 8)}
+    d_luma = ctx.to_device(luma)
+    for ts, (bw, bh) in sizes.items():
+        dc = rng.integers(0, 1 << bd, (LH // 2, LW // 2)).astype(dt)
+        nbx, nby = (LW // 2) // bw, (LH // 2) // bh
+        n = min(nbx * nby, 40)
+        sel = rng.choice(nbx * nby, n, replace=False)
+        lst = np.zeros(n, av1mi.CFL_BLK_DTYPE)
+        exp = dc.copy()
+        for i, s in enumerate(sel):
+            by, bx = divmod(int(s), nbx)
+            x, y = bx * bw, by * bh
+            alpha = int(rng.integers(-16, 17))
+            mw, mh = LW, LH
+            if i % 3 == 0:        # only part of the luma block is available
+                mw = max(2, 2 * x + int(rng.integers(1, bw + 1)) * 2 - 2 * (i % 2))
+                mh = max(2, 2 * y + int(rng.integers(1, bh + 1)) * 2)
+            lst[i] = (x, y, mw, mh, alpha, 0)
+            exp = O.cfl_predict(luma, exp, bd, x, y, bw, bh, alpha, mw, mh)
+        d_dst, d_l = ctx.to_device(dc), ctx.to_device(lst)
+        ctx.cfl_pred_list(ts, d_luma, LW, d_dst, LW // 2, bd, d_l, n)
+        got = d_dst.download(dc.shape, dt)
+        d_dst.free(); d_l.free()
+        assert (got == exp).all(), ((bw, bh), bd)
+    d = ctx.alloc(64)
+    with pytest.raises(av1mi.Av1miError, match="up to 32x32"):
+        ctx.cfl_pred_list(4, d_luma, LW, d, 64, bd, d, 1)
+    d.free(); d_luma.free()

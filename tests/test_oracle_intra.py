@@ -115,3 +115,35 @@ def test_paeth_and_smooth_against_numpy(O):
         sm = O.intra_predict(p, 72, 72, bw, bh, 9, 0, 10, bw, bw, bh, bh).astype(int)
         assert sm.min() >= min(top.min(), left.min()) and sm.max() <= max(top.max(), left.max())
         assert sm[0, 0] == (255 * top[0] + 1 * left[-1] + 255 * left[0] + 1 * top[-1] + 256) >> 9
+
+
+def test_cfl_prediction_properties(O):
+    """chroma-from-luma (spec 7.11.5) against an independent numpy restatement, plus what the definition implies:
+    alpha = 0 leaves the DC prediction alone, flat luma does too, the sign of alpha mirrors the correction"""
+    rng = np.random.default_rng(21)
+    for bd in (8, 10):
+        dt = np.uint8 if bd == 8 else np.uint16
+        luma = rng.integers(0, 1 << bd, (96, 128)).astype(dt)
+        dc = np.full((48, 64), 100 << (bd - 8), dt)
+        for (bw, bh) in ((4, 4), (8, 8), (16, 8), (4, 16), (32, 32), (32, 8)):
+            for alpha in (-16, -5, 0, 3, 16):
+                x, y = 8, 4
+                got = O.cfl_predict(luma, dc, bd, x, y, bw, bh, alpha)
+                blk = luma[2 * y:2 * (y + bh), 2 * x:2 * (x + bw)].astype(np.int64)
+                L = (blk[0::2, 0::2] + blk[0::2, 1::2] + blk[1::2, 0::2] + blk[1::2, 1::2]) << 1
+                avg = (L.sum() + (bw * bh) // 2) // (bw * bh)
+                v = alpha * (L - avg)
+                sl = np.where(v >= 0, (v + 32) >> 6, -((-v + 32) >> 6))
+                exp = dc.copy()
+                exp[y:y + bh, x:x + bw] = np.clip(dc[y:y + bh, x:x + bw].astype(np.int64) + sl, 0, (1 << bd) - 1)
+                assert (got == exp).all(), (bd, bw, bh, alpha)
+                if alpha == 0:
+                    assert (got == dc).all()
+        flat = np.full_like(luma, 77)
+        assert (O.cfl_predict(flat, dc, bd, 0, 0, 8, 8, 9) == dc).all()
+        # availability: beyond max_luma_w / max_luma_h the last 2x2 group repeats
+        got = O.cfl_predict(luma, dc, bd, 0, 0, 16, 16, 7, max_luma_w=20, max_luma_h=12)
+        ext = luma.copy().astype(np.int64)
+        ext[:, 20:] = np.tile(ext[:, 18:20], (1, 54))
+        ext[12:, :] = np.tile(ext[10:12, :], (42, 1))
+        assert (got == O.cfl_predict(ext.astype(dt), dc, bd, 0, 0, 16, 16, 7)).all()
