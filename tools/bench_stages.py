@@ -89,7 +89,19 @@ def main():
         d_m = ctx.to_device(mc)
         ms = timed(ctx, lambda: ctx.mc_list(1, d_plane, W, W, F * H, d_dst, W, bd, d_m, n))["mc"]
         add("K4", "k_mc 8x8", ms, n * 64 * 2 * b, "%d-bit, 8-tap regular, random 1/16 vectors, %d blocks" % (bd, n))
-        for x in (d_l, d_dst, d_m, d_plane):
+        # K3+: chroma-from-luma on every 8x8 chroma block of F half-size planes (luma = the same random plane)
+        cw, chh = W // 2, F * H // 2
+        cys, cxs = np.mgrid[0:chh:8, 0:cw:8]
+        nc = cys.size
+        cfl = np.zeros(nc, av1mi.CFL_BLK_DTYPE)
+        cfl["x"], cfl["y"], cfl["max_luma_w"], cfl["max_luma_h"] = cxs.ravel(), cys.ravel() % 65536, W, min(F * H, 65535)
+        cfl["alpha_q3"] = rng.integers(-16, 17, nc)
+        keep = cys.ravel() * 2 + 16 <= 65535           # the descriptor holds 16-bit coordinates
+        cfl = cfl[keep]
+        d_c, d_cd = ctx.to_device(cfl), ctx.alloc(cw * chh * b)
+        ms = timed(ctx, lambda: ctx.cfl_pred_list(1, d_plane, W, d_cd, cw, bd, d_c, len(cfl)))["intra_pred"]
+        add("K3+", "k_cfl_pred 8x8", ms, len(cfl) * 64 * (2 * b + 4 * b), "%d-bit chroma-from-luma, %d blocks" % (bd, len(cfl)))
+        for x in (d_l, d_dst, d_m, d_plane, d_c, d_cd):
             x.free()
         # K5 / K6 / K7 / fused pipelines / K9 through the segment pipeline's buffers
         pipe = pipeline.IntraPipeline(ctx, 1920, 1080, bd, F, 128, entropy_tile=64 if bd == 8 else 0)
