@@ -169,7 +169,7 @@ __device__ __forceinline__ void fast_pred_row(const T *edge, int r, int bd, int 
     for (int c = 0; c < B; c++) {
       const int bs = b0 + (c << up), bc = min(bs, max_base_x - 1);
       const int v = (above[bc] * (32 - shift) + above[bc + 1] * shift + 16) >> 5;
-      out[c] = bs < max_base_x ? v : vmax;
+      out[c] = vmax ^ ((vmax ^ v) & ((bs - max_base_x) >> 31));      // bs < max_base_x ? v : vmax, as an integer mask
     }
   } else if constexpr (MODE == D113_PRED || MODE == D135_PRED || MODE == D157_PRED) {
     constexpr int dx = ct_derivative(180 - a), dy = ct_derivative(a - 90);
@@ -178,12 +178,14 @@ __device__ __forceinline__ void fast_pred_row(const T *edge, int r, int bd, int 
     for (int c = 0; c < B; c++) {
       const int x = (c << 6) - (r + 1) * dx, y = (r << 6) - (c + 1) * dy;
       const int base_x = x >> (6 - upa), base_y = y >> (6 - upl);
-      const bool use_above = base_x >= -(1 << upa);
+      // all ones where the sample projects onto the left edge: an integer mask, not a lane-mask register pair (the compiler
+      // hoisted those out of the candidates and spilled them to VGPR lanes, paying v_readlane + hazard nops per use)
+      const int use_left = (base_x + (1 << upa)) >> 31;
       const int ia = max(base_x, -2), il = max(base_y, -2);
       const int sha = ((x * (1 << upa)) & 0x3F) >> 1, shl = ((y * (1 << upl)) & 0x3F) >> 1;
       const int va = (above[ia] * (32 - sha) + above[ia + 1] * sha + 16) >> 5;
       const int vl = (left[il] * (32 - shl) + left[il + 1] * shl + 16) >> 5;
-      out[c] = use_above ? va : vl;
+      out[c] = va ^ ((va ^ vl) & use_left);
     }
   } else if constexpr (MODE == D203_PRED) {
     constexpr int dy = ct_derivative(270 - a);
@@ -195,7 +197,7 @@ __device__ __forceinline__ void fast_pred_row(const T *edge, int r, int bd, int 
       const int y = (c + 1) * dy;
       const int bs = (y >> (6 - up)) + (r << up), shift = ((y << up) & 0x3F) >> 1, bc = min(bs, max_base_y - 1);
       const int v = (left[bc] * (32 - shift) + left[bc + 1] * shift + 16) >> 5;
-      out[c] = bs < max_base_y ? v : vmax;
+      out[c] = vmax ^ ((vmax ^ v) & ((bs - max_base_y) >> 31));      // bs < max_base_y ? v : vmax
     }
   } else if constexpr (MODE == DC_PRED) {
     // lane r contributes above[r] + left[r]; the B lanes of the block sum by xor-shuffles
