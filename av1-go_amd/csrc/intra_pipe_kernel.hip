@@ -134,14 +134,17 @@ __global__ __launch_bounds__(256, BS == 8 ? 3 : 1) void k_intra_pipe(IntraPipeLa
   constexpr int CS = BS / 2, N = 64 / BS, TPW = 256 / BS;
   using ES = Pix;                                      // LDS sample type: 1 byte for 8-bit content, 2 for 10-bit
   constexpr int ELY = fast_edge_len(BS), ELC = fast_edge_len(CS);
-  constexpr int EDGE_N = ELY > 2 * ELC ? ELY : 2 * ELC;   // luma and chroma blocks alternate: one region
-  // entries per tile: line buffers + bottom-right samples (Y, U, V), edge region, two mode maps (one byte each)
-  constexpr int CTX_N = (64 + 64 + N * N) + 2 * (32 + 32 + N * N) + EDGE_N;
-  constexpr int CTX_BYTES_RAW = CTX_N * (int)sizeof(ES) + 2 * N * N;
+  constexpr int T32_PER_TILE = BS * (BS + 4);          // int32 transpose buffer of the residual tail
+  // luma and chroma blocks alternate: one edge region — and it doubles as the transpose buffer: the edge arrays are dead
+  // once the candidates have been compared (group sync), the residual tail then transposes through the same bytes
+  constexpr int EDGE_RAW = (ELY > 2 * ELC ? ELY : 2 * ELC) * (int)sizeof(ES);
+  constexpr int EDGE_BYTES = ((EDGE_RAW > T32_PER_TILE * 4 ? EDGE_RAW : T32_PER_TILE * 4) + 15) / 16 * 16;
+  // bytes per tile: line buffers + bottom-right samples (Y, U, V), edge / transpose region, two mode maps (one byte each)
+  constexpr int LINE_BYTES = ((64 + 64 + N * N) + 2 * (32 + 32 + N * N)) * (int)sizeof(ES);
+  static_assert(LINE_BYTES % 16 == 0, "the edge / transpose region must stay 16-byte aligned");
+  constexpr int CTX_BYTES_RAW = LINE_BYTES + EDGE_BYTES + 2 * N * N;
   // per-tile strides padded so that the tiles of a wave (which run in lockstep at equal offsets) start 4 banks apart
   constexpr int CTX_BYTES = ((CTX_BYTES_RAW + 127) / 128) * 128 + 16;
-  constexpr int T32_PER_TILE = ((BS * (BS + 4) + 31) / 32) * 32 + 8;
-  __shared__ __attribute__((aligned(16))) int32_t tbufs[TPW * T32_PER_TILE];
   __shared__ __attribute__((aligned(16))) unsigned char ctxb[TPW * CTX_BYTES];
 
   const int grp = threadIdx.x / BS, lane = threadIdx.x % BS;
@@ -158,10 +161,10 @@ __global__ __launch_bounds__(256, BS == 8 ? 3 : 1) void k_intra_pipe(IntraPipeLa
   ES *cu = u + pl * (64 + N * N);
   Cp.above = cu; Cp.left = cu + 32; Cp.br = cu + 64; u += 2 * (64 + N * N);
   Y.edge = u;
-  Cp.edge = u + pl * ELC; u += EDGE_N;
-  uint8_t *mode_y = reinterpret_cast<uint8_t *>(u), *mode_c = mode_y + N * N;
-  Y.tbuf = tbufs + grp * T32_PER_TILE;
+  Cp.edge = u + pl * ELC;
+  Y.tbuf = reinterpret_cast<int32_t *>(u);
   Cp.tbuf = Y.tbuf + pl * (CS * (CS + 4));
+  uint8_t *mode_y = reinterpret_cast<uint8_t *>(u) + EDGE_BYTES, *mode_c = mode_y + N * N;
 
   const Pix *src_y = reinterpret_cast<const Pix *>(L.src[0]) + (size_t)f * L.h * L.stride_y;
   Pix *rec_y = reinterpret_cast<Pix *>(L.rec[0]) + (size_t)f * L.h * L.stride_y;
