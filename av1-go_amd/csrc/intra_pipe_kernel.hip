@@ -57,7 +57,7 @@ __device__ __forceinline__ unsigned morton2(unsigned x, unsigned y) {
 template <typename ES> struct TileCtx {
   ES *above;       // [tile width]  last reconstructed sample of each column
   ES *left;        // [tile height] last reconstructed sample of each row
-  ES *br;          // [n*n] bottom-right sample of each coded block
+  ES *tl;          // [n] per block row: the top-left neighbour sample of the NEXT block of that row (see code_block)
   ES *edge;        // raw + derived edge arrays, fast_edge_len(B) entries
   int32_t *tbuf;   // B x (B+4) transpose buffer
 };
@@ -79,7 +79,7 @@ __device__ __forceinline__ int code_block(const TileCtx<Pix> &C, int lane, int b
   using ES = Pix;
   const int x = bx * B, y = by * B;
   auto fetch = [&](int yy, int xx) -> int {
-    if (yy < 0) return xx < 0 ? C.br[(by - 1) * n + bx - 1] : C.above[x + xx];
+    if (yy < 0) return xx < 0 ? C.tl[by] : C.above[x + xx];
     return C.left[y + yy];
   };
   int s[B], bp[B];
@@ -120,9 +120,12 @@ __device__ __forceinline__ int code_block(const TileCtx<Pix> &C, int lane, int b
   // neighbour context for the blocks to come
   C.left[y + lane] = (ES)rec[B - 1];
   if (lane == B - 1) {
+    // Before this block's bottom row replaces it, above[x + B - 1] still holds sample (x + B - 1, y - 1): the top-left
+    // neighbour of the block to the right.  In z-order the blocks of one block row are coded left to right (the order is
+    // monotone in x for fixed y), so one entry per block row is enough — no n x n map of bottom-right samples.
+    C.tl[by] = C.above[x + B - 1];
 #pragma unroll
     for (int c = 0; c < B; c++) C.above[x + c] = (ES)rec[c];
-    C.br[by * n + bx] = (ES)rec[B - 1];
   }
   AV1MI_GROUP_SYNC();
   STAMP(4);
@@ -139,10 +142,10 @@ __global__ __launch_bounds__(256, BS == 8 ? 3 : 1) void k_intra_pipe(IntraPipeLa
   // once the candidates have been compared (group sync), the residual tail then transposes through the same bytes
   constexpr int EDGE_RAW = (ELY > 2 * ELC ? ELY : 2 * ELC) * (int)sizeof(ES);
   constexpr int EDGE_BYTES = ((EDGE_RAW > T32_PER_TILE * 4 ? EDGE_RAW : T32_PER_TILE * 4) + 15) / 16 * 16;
-  // bytes per tile: line buffers + bottom-right samples (Y, U, V), edge / transpose region, two mode maps (one byte each)
-  constexpr int LINE_BYTES = ((64 + 64 + N * N) + 2 * (32 + 32 + N * N)) * (int)sizeof(ES);
-  static_assert(LINE_BYTES % 16 == 0, "the edge / transpose region must stay 16-byte aligned");
-  constexpr int CTX_BYTES_RAW = LINE_BYTES + EDGE_BYTES + 2 * N * N;
+  // bytes per tile: line buffers + one top-left sample per block row (Y, U, V), edge / transpose region, four mode lines
+  constexpr int LINE_N = ((64 + 64 + N) + 2 * (32 + 32 + N) + 15) / 16 * 16;
+  constexpr int LINE_BYTES = LINE_N * (int)sizeof(ES);
+  constexpr int CTX_BYTES_RAW = LINE_BYTES + EDGE_BYTES + 4 * N;
   // per-tile strides padded so that the tiles of a wave (which run in lockstep at equal offsets) start 4 banks apart
   constexpr int CTX_BYTES = ((CTX_BYTES_RAW + 127) / 128) * 128 + 16;
   __shared__ __attribute__((aligned(16))) unsigned char ctxb[TPW * CTX_BYTES];
@@ -156,15 +159,18 @@ __global__ __launch_bounds__(256, BS == 8 ? 3 : 1) void k_intra_pipe(IntraPipeLa
 
   ES *u = reinterpret_cast<ES *>(ctxb + grp * CTX_BYTES);
   TileCtx<ES> Y, Cp;   // Cp: this lane's chroma plane (U for the lower half of the group, V for the upper)
-  Y.above = u; Y.left = u + 64; Y.br = u + 128; u += 128 + N * N;
+  Y.above = u; Y.left = u + 64; Y.tl = u + 128;
   const int pl = lane / CS, cl = lane % CS;
-  ES *cu = u + pl * (64 + N * N);
-  Cp.above = cu; Cp.left = cu + 32; Cp.br = cu + 64; u += 2 * (64 + N * N);
+  ES *cu = u + 128 + N + pl * (64 + N);
+  Cp.above = cu; Cp.left = cu + 32; Cp.tl = cu + 64;
+  u += LINE_N;
   Y.edge = u;
   Cp.edge = u + pl * ELC;
   Y.tbuf = reinterpret_cast<int32_t *>(u);
   Cp.tbuf = Y.tbuf + pl * (CS * (CS + 4));
-  uint8_t *mode_y = reinterpret_cast<uint8_t *>(u) + EDGE_BYTES, *mode_c = mode_y + N * N;
+  // modes of the most recent block of every block column / row (luma, chroma): the top neighbour of a block is the latest
+  // block of its column, the left neighbour the latest of its row (z-order is monotone along both)
+  uint8_t *col_my = reinterpret_cast<uint8_t *>(u) + EDGE_BYTES, *row_my = col_my + N, *col_mc = row_my + N, *row_mc = col_mc + N;
 
   const Pix *src_y = reinterpret_cast<const Pix *>(L.src[0]) + (size_t)f * L.h * L.stride_y;
   Pix *rec_y = reinterpret_cast<Pix *>(L.rec[0]) + (size_t)f * L.h * L.stride_y;
@@ -188,8 +194,8 @@ __global__ __launch_bounds__(256, BS == 8 ? 3 : 1) void k_intra_pipe(IntraPipeLa
     const bool have_tr = have_top && (int)bx + 1 < N && fx + 1 < bw && morton2(bx + 1, by - 1) < k;
     const bool have_bl = have_left && (int)by + 1 < N && fy + 1 < bh && morton2(bx - 1, by + 1) < k;
     int ft = 0, ftc = 0;
-    if (have_top) { const int m = mode_y[(by - 1) * N + bx], mc = mode_c[(by - 1) * N + bx]; ft |= m >= 9 && m <= 11; ftc |= mc >= 9 && mc <= 11; }
-    if (have_left) { const int m = mode_y[by * N + bx - 1], mc = mode_c[by * N + bx - 1]; ft |= m >= 9 && m <= 11; ftc |= mc >= 9 && mc <= 11; }
+    if (have_top) { const int m = col_my[bx], mc = col_mc[bx]; ft |= m >= 9 && m <= 11; ftc |= mc >= 9 && mc <= 11; }
+    if (have_left) { const int m = row_my[by], mc = row_mc[by]; ft |= m >= 9 && m <= 11; ftc |= mc >= 9 && mc <= 11; }
     const size_t blk = (size_t)fy * bw + fx;
     {
 #ifdef AV1MI_EXP_TILED   // timing experiment only (wrong pixels): planes addressed as if block-tiled, 64 contiguous bytes per block
@@ -200,7 +206,7 @@ __global__ __launch_bounds__(256, BS == 8 ? 3 : 1) void k_intra_pipe(IntraPipeLa
       const int m = code_block<BS, BS, Pix>(Y, lane, bx, by, N, have_top ? BS : 0, have_tr ? BS : 0, have_left ? BS : 0,
                                              have_bl ? BS : 0, ft, L.dc_q, L.ac_q, src_y + off, rec_y + off,
                                              lev_y + blk * BS * BS + lane * BS STAMP_PASS);
-      if (lane == 0) { modes_y[blk] = (uint8_t)m; mode_y[by * N + bx] = (uint8_t)m; }
+      if (lane == 0) { modes_y[blk] = (uint8_t)m; col_my[bx] = row_my[by] = (uint8_t)m; }
     }
     {
 #ifdef AV1MI_EXP_TILED
@@ -211,7 +217,7 @@ __global__ __launch_bounds__(256, BS == 8 ? 3 : 1) void k_intra_pipe(IntraPipeLa
       const int m = code_block<CS, BS, Pix>(Cp, cl, bx, by, N, have_top ? CS : 0, have_tr ? CS : 0, have_left ? CS : 0,
                                              have_bl ? CS : 0, ftc, L.dc_q, L.ac_q, src_c + off, rec_c + off,
                                              lev_c + blk * CS * CS + cl * CS STAMP_PASS);
-      if (lane == 0) { modes_uv[blk] = (uint8_t)m; mode_c[by * N + bx] = (uint8_t)m; }
+      if (lane == 0) { modes_uv[blk] = (uint8_t)m; col_mc[bx] = row_mc[by] = (uint8_t)m; }
     }
     AV1MI_GROUP_SYNC();
     STAMP(5);
