@@ -79,7 +79,7 @@ class EntropyJob(C.Structure):
                 ("d_out", C.c_void_p), ("out_cap", C.c_size_t), ("d_frame_off", C.c_void_p)]
 
 
-N_KERNEL_KINDS = 15   # enum av1mi_kernel_kind
+N_KERNEL_KINDS = 16   # enum av1mi_kernel_kind
 _lib = None
 
 

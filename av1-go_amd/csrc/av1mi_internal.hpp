@@ -81,7 +81,8 @@ struct InterLaunch {
   int16_t *mvs; uint8_t *skip;
   int w, h, stride_y, stride_uv, bd, nframes, dc_q, ac_q, range;
 };
-hipError_t launch_inter(const InterLaunch &L, hipStream_t s);
+hipError_t launch_me_int(const InterLaunch &L, hipStream_t s);
+hipError_t launch_inter_pipe(const InterLaunch &L, hipStream_t s);
 
 int tx_width(int tx_size);
 int tx_height(int tx_size);

@@ -239,7 +239,7 @@ int av1mi_prof_get(av1mi_ctx *ctx, int kind, int *launches, double *total_ms) {
 }
 const char *av1mi_kernel_kind_name(int kind) {
   static const char *n[AV1MI_K_KINDS] = { "fwd_txfm", "inv_txfm", "quantize", "dequantize", "intra_pred", "mc", "deblock",
-                                          "cdef", "loop_restoration", "intra_pipeline", "inter_pipeline", "misc", "entropy_code", "entropy_pack", "entropy_tokens" };
+                                          "cdef", "loop_restoration", "intra_pipeline", "inter_pipeline", "misc", "entropy_code", "entropy_pack", "entropy_tokens", "me_integer" };
   return kind < 0 || kind >= AV1MI_K_KINDS ? "?" : n[kind];
 }
 
@@ -441,7 +441,9 @@ int av1mi_inter_encode(av1mi_ctx *ctx, const av1mi_inter_job *j) {
   L.mvs = j->d_mvs; L.skip = j->d_skip;
   L.w = j->width; L.h = j->height; L.stride_y = j->stride_y; L.stride_uv = j->stride_uv; L.bd = j->bit_depth; L.nframes = j->nframes;
   L.dc_q = av1mi_dc_q(j->qindex, j->bit_depth); L.ac_q = av1mi_ac_q(j->qindex, j->bit_depth); L.range = j->search_range;
-  { ProfScope ps(ctx, AV1MI_K_INTER_PIPE); HIP_TRY(ctx, av1mi::launch_inter(L, ctx->stream)); }
+  // one event pair per kernel, so that either can be the bench's roofline kernel and be matched with rocprofv3's per-kernel stats
+  { ProfScope ps(ctx, AV1MI_K_ME_INT); HIP_TRY(ctx, av1mi::launch_me_int(L, ctx->stream)); }
+  { ProfScope ps(ctx, AV1MI_K_INTER_PIPE); HIP_TRY(ctx, av1mi::launch_inter_pipe(L, ctx->stream)); }
   return AV1MI_OK;
 }
 

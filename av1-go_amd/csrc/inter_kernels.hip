@@ -466,18 +466,21 @@ __global__ __launch_bounds__(256) void k_inter_pipe(InterLaunch L) {
   if (lane == 0) L.skip[(size_t)f * bw * bh + blk] = nz == 0;
 }
 
-hipError_t launch_inter(const InterLaunch &L, hipStream_t s) {
+// integer search: writes L.mvs (whole-sample vectors), which k_inter_pipe then refines
+hipError_t launch_me_int(const InterLaunch &L, hipStream_t s) {
   if (L.nframes <= 0) return hipSuccess;
   const int sbs = ((L.w + 63) / 64) * ((L.h + 63) / 64);
+  const dim3 g1(sbs, L.nframes);
+  if (L.bd == 8) hipLaunchKernelGGL(k_me_int<uint8_t>, g1, dim3(256), 0, s, L);
+  else hipLaunchKernelGGL(k_me_int<uint16_t>, g1, dim3(256), 0, s, L);
+  return hipGetLastError();
+}
+hipError_t launch_inter_pipe(const InterLaunch &L, hipStream_t s) {
+  if (L.nframes <= 0) return hipSuccess;
   const long long blocks = (long long)L.nframes * (L.w / 8) * (L.h / 8);
-  const dim3 g1(sbs, L.nframes), g2((unsigned)((blocks + 31) / 32));
-  if (L.bd == 8) {
-    hipLaunchKernelGGL(k_me_int<uint8_t>, g1, dim3(256), 0, s, L);
-    hipLaunchKernelGGL(k_inter_pipe<uint8_t>, g2, dim3(256), 0, s, L);
-  } else {
-    hipLaunchKernelGGL(k_me_int<uint16_t>, g1, dim3(256), 0, s, L);
-    hipLaunchKernelGGL(k_inter_pipe<uint16_t>, g2, dim3(256), 0, s, L);
-  }
+  const dim3 g2((unsigned)((blocks + 31) / 32));
+  if (L.bd == 8) hipLaunchKernelGGL(k_inter_pipe<uint8_t>, g2, dim3(256), 0, s, L);
+  else hipLaunchKernelGGL(k_inter_pipe<uint16_t>, g2, dim3(256), 0, s, L);
   return hipGetLastError();
 }
 

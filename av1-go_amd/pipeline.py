@@ -274,7 +274,10 @@ class GopPipeline:
 
     def algorithmic_bytes(self):
         b, per_frame = self.bps, self.samples / self.gop
-        return {"intra_pipeline": (2 * b + 2) * per_frame, "inter_pipeline": (3 * b + 2) * per_frame, "deblock": 2 * b * per_frame / 3.0,
+        # k_me_int reads the luma source and the luma reference (2b per LUMA sample = 2/3 of the frame's samples); k_inter_pipe
+        # reads source + reference, writes reconstruction + int16 levels ((3b + 2) per sample)
+        return {"intra_pipeline": (2 * b + 2) * per_frame, "inter_pipeline": (3 * b + 2) * per_frame, "me_integer": 2 * b * per_frame * 2.0 / 3.0,
+                "deblock": 2 * b * per_frame / 3.0,
                 "cdef": 2 * b * per_frame, "loop_restoration": 2 * b * per_frame / 3.0, "entropy_code": 2 * per_frame}
 
     def close(self):

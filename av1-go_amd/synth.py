@@ -5,6 +5,9 @@ Texture: xorshift32-hashed noise (seed 0xA51C0DE), 3x3 box blur twice, plus a di
 (8-bit scale) noise from seed 0xA51C0DE + t.  Chroma: same at half resolution, seeds +1, +2.
 Ranges: 8-bit [16,235]; 10-bit [64,940] in uint16.  Nothing is read from disk.
 """
+import os
+from concurrent.futures import ThreadPoolExecutor
+
 import numpy as np
 
 SEED = 0xA51C0DE
@@ -61,7 +64,19 @@ def frames(w, h, n, bd=8, first=0):
     ty = texture(w, h, SEED, first + n)
     tu = texture(w // 2, h // 2, SEED + 1, first + n)
     tv = texture(w // 2, h // 2, SEED + 2, first + n)
-    Y = np.stack([plane(ty, w, h, first + t, SEED, bd) for t in range(n)])
-    U = np.stack([plane(tu, w // 2, h // 2, first + t, SEED + 1, bd, 0.5) for t in range(n)])
-    V = np.stack([plane(tv, w // 2, h // 2, first + t, SEED + 2, bd, 0.5) for t in range(n)])
+    dt = np.uint8 if bd == 8 else np.uint16
+    Y, U, V = np.empty((n, h, w), dt), np.empty((n, h // 2, w // 2), dt), np.empty((n, h // 2, w // 2), dt)
+
+    def one(t):
+        Y[t] = plane(ty, w, h, first + t, SEED, bd)
+        U[t] = plane(tu, w // 2, h // 2, first + t, SEED + 1, bd, 0.5)
+        V[t] = plane(tv, w // 2, h // 2, first + t, SEED + 2, bd, 0.5)
+
+    workers = min(n, os.cpu_count() or 1, 16)
+    if workers > 1 and n * w * h >= (1 << 24):     # frames are independent; numpy releases the GIL inside the array ops
+        with ThreadPoolExecutor(workers) as ex:
+            list(ex.map(one, range(n)))
+    else:
+        for t in range(n):
+            one(t)
     return Y, U, V

@@ -5,7 +5,10 @@ One "step" = one closed-GOP segment of --frames synthetic frames through the dev
 already resident in HBM.  N ranks (one per GPU, launched by torch.distributed.run) each process their
 own segments: no data-path collective, scaling is weak.  Rank 0 prints ONE JSON line.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 1080p8|4k10] [--frames F]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 4k10-gop|1080p8-gop|4k10|1080p8] [--segments S | --frames F]
+
+Default workload = the configuration BASELINE.json's metric ("encoded 4K30 frames/sec") is quoted on: configs[3], 4K 10-bit,
+closed GOPs of 30 frames (1 key + 29 P), every stage of the block pipeline + the three in-loop filters on one GPU.
 """
 import argparse
 import json
@@ -27,10 +30,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="1080p8", choices=["1080p8", "4k10", "1080p8-gop", "4k10-gop"],
-                    help="1080p8 = BASELINE config 2 (intra-only, the default); 4k10 = 4K 10-bit intra-only; *-gop = closed GOPs of 30 "
-                         "frames, 1 key + 29 P (configs 3/4)")
-    ap.add_argument("--frames", type=int, default=0, help="frames per step (segment length); 0 = default")
+    ap.add_argument("--workload", default="4k10-gop", choices=["1080p8", "4k10", "1080p8-gop", "4k10-gop"],
+                    help="4k10-gop (default) = BASELINE configs[3], the 4K30 10-bit full pipeline the metric is quoted on: closed GOPs "
+                         "of 30 frames, 1 key + 29 P; 1080p8-gop = configs[2]; 1080p8 = configs[1] (intra-only); 4k10 = 4K intra-only")
+    ap.add_argument("--frames", type=int, default=0, help="intra-only workloads: frames per step (segment length); 0 = default")
+    ap.add_argument("--segments", type=int, default=0, help="*-gop workloads: closed GOPs coded in lockstep per step; 0 = default")
     ap.add_argument("--qindex", type=int, default=128)
     ap.add_argument("--entropy", default="none", choices=["none", "gpu", "gpu-async"],
                     help="gpu = the tile entropy coder (K9) runs inside the timed step; none (default) = BASELINE config 2 as "
@@ -71,6 +75,49 @@ def cpu_baseline(pipe, seconds=12.0):
     return {"value": done / dt, "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": "%d frames of the same segment through the oracle's intra encoder loop + deblock + CDEF + loop "
                       "restoration (same stages as the GPU step) in %.1f s" % (done, dt)}
+
+
+def cpu_baseline_gop(pipe, p_frames=2):
+    """Closed-GOP workloads: the oracle chain (kind "port") on this box's host cores, one GOP per worker thread, each coding
+    the key frame and the first `p_frames` P frames of its GOP through the same stages as the GPU step (encoder loop +
+    deblocking + CDEF + loop restoration; the P frames reference the worker's own loop-filtered reconstruction).  A GOP is
+    serial in itself, so the whole-GOP rate follows from the two per-frame costs: 30 frames / (t_key + 29 t_P), times the
+    number of workers — the sample is bounded to a few frames per worker because one 4K P frame is ~10 s of CPU work."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as O
+    O.build()
+    cores = min(os.cpu_count() or 1, 16)
+    k, gop = pipe.key, pipe.gop
+    h, w = pipe.height, pipe.width
+
+    def filters(r, skip8):
+        dbl = [O.deblock_plane(r["rec_y"], pipe.bd, 0, k.mi_y), O.deblock_plane(r["rec_u"], pipe.bd, 1, k.mi_c),
+               O.deblock_plane(r["rec_v"], pipe.bd, 1, k.mi_c)]
+        cdef = O.cdef_frame(dbl[0], dbl[1], dbl[2], pipe.bd, k.cdef_damping, k.cdef_sb, skip8)
+        return [O.lr_plane(cdef[0], dbl[0], pipe.bd, 0, k.lr_unit, k.lr_units_y), O.lr_plane(cdef[1], dbl[1], pipe.bd, 1, k.lr_unit, k.lr_units_c),
+                O.lr_plane(cdef[2], dbl[2], pipe.bd, 1, k.lr_unit, k.lr_units_c)]
+
+    def one(worker):
+        s = worker % pipe.segments
+        t0 = time.perf_counter()
+        src = [pipe.src[0][i][s] for i in range(3)]
+        ref = filters(O.intra_encode_frame(src[0], src[1], src[2], pipe.bd, 8, pipe.qindex), np.zeros((h // 8, w // 8), np.uint8))
+        t1 = time.perf_counter()
+        for t in range(1, 1 + p_frames):
+            src = [pipe.src[t][i][s] for i in range(3)]
+            r = O.inter_encode_frame(src, ref, pipe.bd, pipe.qindex, pipe.range)
+            ref = filters(r, r["skip"].reshape(h // 8, w // 8))
+        return t1 - t0, (time.perf_counter() - t1) / p_frames
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        res = list(ex.map(one, range(cores)))
+    wall = time.perf_counter() - t0
+    t_key, t_p = float(np.mean([r[0] for r in res])), float(np.mean([r[1] for r in res]))
+    return {"value": cores * gop / (t_key + (gop - 1) * t_p), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "%d workers x (key frame + %d P frames) of the same GOPs through the oracle's encoder loops + deblock + CDEF + loop "
+                      "restoration in %.1f s wall: %.2f s per key frame, %.2f s per P frame per core; value = cores x %d / (t_key + %d t_P)"
+                      % (cores, p_frames, wall, t_key, t_p, gop, gop - 1)}
 
 
 def quality(pipe, bd):
@@ -135,15 +182,16 @@ def entropy_leg(ctx, pipe, args, launches=5, host_seconds=6.0):
 
 
 PMC_KERNEL = {"intra_pipeline": "k_intra_pipe", "deblock": "k_deblock", "cdef": "k_cdef", "loop_restoration": "k_lr",
-              "inter_pipeline": "k_inter_pipe"}
+              "inter_pipeline": "k_inter_pipe", "me_integer": "k_me_int"}
 
 
 def pmc_traffic(kind, workload, frames):
     """HBM bytes per launch of the kernel behind `kind` from the committed rocprofv3 PMC passes (profiles/, made by
     tools/prof_pmc.sh + tools/pmc_to_json.py on the same command): reads = 2 x FETCH_SIZE (gfx950 tallies a 128-B read
     request as 64 B; confirmed on this box for 8- and 16-byte-per-lane streams, see "calibration" in the file) + WRITE_SIZE,
-    scaled to this run's frames per step.  None when no matching profile is committed (PMC cannot be read live)."""
-    tag = {"1080p8": "1080p8_intra"}.get(workload)
+    scaled to this run's frames per LAUNCH (intra-only: the segment; closed GOPs: one frame of every GOP in lockstep).
+    None when no matching profile is committed (PMC cannot be read live)."""
+    tag = {"1080p8": "1080p8_intra", "4k10-gop": "4k10_gop"}.get(workload)
     if tag is None:
         return None
     path = os.path.join(ROOT, "profiles", "pmc_%s_latest.json" % tag)
@@ -224,7 +272,9 @@ def main():
     ctx = av1mi.Context(local_rank)
     if args.workload.endswith("-gop"):
         gop = 30
-        segs = max(1, frames // 2)               # GOPs coded in lockstep per step
+        # GOPs coded in lockstep per step (the t-th frames of all of them share a launch): 12 x 2040 tiles at 4K = 3 waves per
+        # SIMD for the coding kernels, their occupancy limit; 24 x 510 at 1080p likewise.  --frames F keeps its old meaning (F/2 GOPs).
+        segs = args.segments or (max(1, args.frames // 2) if args.frames else (24 if bd == 8 else 12))
         frames = segs * gop
         pipe = pipeline.GopPipeline(ctx, W, H, bd, segs, gop, args.qindex, first_frame=segment_of_rank(rank, frames),
                                     entropy_tile=args.entropy_tile if args.entropy != "none" else 0, entropy_async=args.entropy == "gpu-async")
@@ -273,15 +323,15 @@ def main():
         n, ms = prof[dom]
         ach = alg[dom] / (ms / n * 1e-3) / 1e9
         out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                           "frac": ach / HBM_PEAK_GBPS, "traffic": pmc_traffic(dom, args.workload, frames), "algorithmic_bytes_per_launch": alg[dom],
+                           "frac": ach / HBM_PEAK_GBPS, "traffic": pmc_traffic(dom, args.workload, pipe.segments if args.workload.endswith("-gop") else frames), "algorithmic_bytes_per_launch": alg[dom],
                            "avg_launch_ms": ms / n, "launches": n}
         out["kernels"] = {k: {"launches": v[0], "avg_ms": v[1] / v[0],
                               "algorithmic_GBps": alg[k] / (v[1] / v[0] * 1e-3) / 1e9 if k in alg else None} for k, v in prof.items()}
         out["quality"] = quality(pipe, bd)
         if world == 1 and not args.workload.endswith("-gop"):
             out["entropy"] = entropy_leg(ctx, pipe, args)
-        if world == 1 and not args.no_cpu_baseline and not args.workload.endswith("-gop"):
-            out["cpu_baseline"] = cpu_baseline(pipe)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_gop(pipe) if args.workload.endswith("-gop") else cpu_baseline(pipe)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

@@ -80,7 +80,7 @@ int av1mi_timer_end(av1mi_ctx *ctx, float *elapsed_ms);
 enum av1mi_kernel_kind {
   AV1MI_K_FWD_TXFM, AV1MI_K_INV_TXFM, AV1MI_K_QUANT, AV1MI_K_DEQUANT, AV1MI_K_INTRA_PRED, AV1MI_K_MC,
   AV1MI_K_DEBLOCK, AV1MI_K_CDEF, AV1MI_K_LR, AV1MI_K_INTRA_PIPE, AV1MI_K_INTER_PIPE, AV1MI_K_MISC, AV1MI_K_ENTROPY,
-  AV1MI_K_ENTROPY_PACK, AV1MI_K_ENTROPY_TOKENS, AV1MI_K_KINDS
+  AV1MI_K_ENTROPY_PACK, AV1MI_K_ENTROPY_TOKENS, AV1MI_K_ME_INT, AV1MI_K_KINDS
 };
 int av1mi_prof_enable(av1mi_ctx *ctx, int on);
 int av1mi_prof_reset(av1mi_ctx *ctx);

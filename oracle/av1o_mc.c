@@ -63,6 +63,10 @@ int av1o_mc_filter_index(int type, int dim) {
   return type;
 }
 
+/* tests switch the whole-sample shortcut off to check it against the filter path */
+static int mc_fast_path = 1;
+void av1o_mc_set_fast_path(int on) { mc_fast_path = on; }
+
 /*
  * Predict a w x h block at (x, y) of a plane from the reference plane `ref` (plane_w x plane_h, stride in samples),
  * displaced by (mvx, mvy) in 1/16-sample units of THIS plane.  filt_x / filt_y: interpolation filter types.
@@ -80,6 +84,20 @@ int av1o_mc_block(const void *ref, int stride, int plane_w, int plane_h, int bd,
   const int16_t *fx = av1o_subpel_filters[av1o_mc_filter_index(filt_x, w)][px];
   const int16_t *fy = av1o_subpel_filters[av1o_mc_filter_index(filt_y, h)][py];
   const int round0 = 3, round1 = 11;
+  if (px == 0 && py == 0 && mc_fast_path) {
+    /* whole-sample position: phase 0 of every filter family is {0,0,0,128,0,0,0,0}, so both stages are exact
+     * (Round2(128 v, 3) = 16 v, Round2(128 * 16 v, 11) = v): the prediction is the edge-clamped copy.  Same result as the
+     * general path below (tests/test_oracle_mc.py checks it); it only keeps the integer search of the encoder loop and
+     * the CPU baseline from paying 2 x 8 taps per sample for a copy. */
+    for (int r = 0; r < h; r++) {
+      const int ry = av1o_clampi(y0 + r, 0, plane_h - 1);
+      for (int c = 0; c < w; c++) {
+        const int rx = av1o_clampi(x0 + c, 0, plane_w - 1);
+        pred[r * w + c] = bd == 8 ? ((const uint8_t *)ref)[(size_t)ry * stride + rx] : ((const uint16_t *)ref)[(size_t)ry * stride + rx];
+      }
+    }
+    return 0;
+  }
   for (int r = 0; r < h + 7; r++) {
     const int ry = av1o_clampi(y0 + r - 3, 0, plane_h - 1);
     for (int c = 0; c < w; c++) {

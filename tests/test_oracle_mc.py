@@ -15,6 +15,16 @@ def test_filter_bank_identities(O):
 
 
 def test_integer_mv_is_a_copy_with_edge_clamp(O):
+    """both ways: through the two filter stages (phase 0 is exact) and through the oracle's whole-sample shortcut"""
+    for fast in (0, 1):
+        O.lib().av1o_mc_set_fast_path(fast)
+        try:
+            _integer_mv_cases(O)
+        finally:
+            O.lib().av1o_mc_set_fast_path(1)
+
+
+def _integer_mv_cases(O):
     rng = np.random.default_rng(1)
     for bd in (8, 10):
         ref = rng.integers(0, 1 << bd, (72, 96)).astype(np.uint8 if bd == 8 else np.uint16)

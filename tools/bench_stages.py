@@ -119,7 +119,8 @@ def main():
         pipe.close()
         gp = pipeline.GopPipeline(ctx, 1920, 1080, bd, F, 2, 128)
         t = timed(ctx, gp.step, reps=3)
-        add("pipe", "k_me_int + k_inter_pipe", t["inter_pipeline"], gp.algorithmic_bytes()["inter_pipeline"], "%d-bit %d P frames" % (bd, F))
+        add("pipe", "k_me_int", t["me_integer"], gp.algorithmic_bytes()["me_integer"], "%d-bit %d P frames, +-8 integer search" % (bd, F))
+        add("pipe", "k_inter_pipe", t["inter_pipeline"], gp.algorithmic_bytes()["inter_pipeline"], "%d-bit %d P frames, sub-pel refinement + residual coding" % (bd, F))
         gp.close()
     ctx.close()
     if a.json:
