@@ -337,6 +337,8 @@ __device__ __forceinline__ void mc_v9(const uint32_t (*pr)[8], int posy, const i
   for (int c = 0; c < 8; c++) out[c] = min(max(s[c] >> 11, 0), maxpix);
 }
 
+__host__ __device__ constexpr int cmax3(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
+
 template <typename Pix>
 __global__ __launch_bounds__(256) void k_inter_pipe(InterLaunch L) {
   using ES = Pix;
@@ -344,13 +346,27 @@ __global__ __launch_bounds__(256) void k_inter_pipe(InterLaunch L) {
   constexpr int GPW = 32;                        // groups (blocks) per workgroup
   constexpr int YW = 16, YWS = 20;               // luma window 16 x 16 (integer vector -4 .. +11); rows are whole dwords
   constexpr int CW = 12, CWS = 16;               // chroma window 12 x 12 (chroma integer position -4 .. +7); rows are whole dwords
-  constexpr int WIN_N = YW * YWS + 2 * CW * CWS;
-  constexpr int WIN_BYTES = ((WIN_N * (int)sizeof(ES) + 127) / 128) * 128 + 16;
-  constexpr int IM_N = 16 * 8 + 8;               // luma intermediate 16 x 8 (chroma 2 x 11 x 4 fits inside)
-  constexpr int T_N = ((8 * 12 + 31) / 32) * 32 + 8;
-  __shared__ __attribute__((aligned(16))) unsigned char winb[GPW * WIN_BYTES];
-  __shared__ __attribute__((aligned(16))) int16_t imb[GPW * IM_N];
-  __shared__ __attribute__((aligned(16))) int32_t tb[GPW * T_N];
+  // ONE LDS region per group, reused by the phases of a block (each ends with a group sync before the next one writes):
+  //   luma search     window (YW x YWS samples) | intermediate (16 x 8 int16)
+  //   luma residual   transpose buffer (8 x 12 int32) over the dead window / intermediate
+  //   chroma          two windows (CW x CWS samples) | intermediates (2 x (11 x 4 + 4) int16); then the two transpose buffers
+  //                   (2 x 32 int32) over the dead windows
+  // Separate arrays cost 66 KB per workgroup at 10 bits = 2 waves per SIMD; the shared region is 33 KB = the 4 waves the VGPRs allow.
+  constexpr int YWIN_BYTES = YW * YWS * (int)sizeof(ES), CWIN_BYTES = 2 * CW * CWS * (int)sizeof(ES);
+  constexpr int IMY_BYTES = 16 * 8 * 2, IMC_BYTES = 2 * (11 * 4 + 4) * 2, TY_BYTES = 8 * 12 * 4, TC_BYTES = 2 * 32 * 4;
+  constexpr int REG_RAW = cmax3(YWIN_BYTES + IMY_BYTES, CWIN_BYTES + IMC_BYTES, TY_BYTES > TC_BYTES ? TY_BYTES : TC_BYTES);
+  // per-group stride = 16 bytes past a multiple of 128: the groups of a wave run in lockstep at equal offsets and so start 4 banks apart
+  constexpr int REG_BYTES = ((REG_RAW + 127) / 128) * 128 + 16;
+  static_assert(YWIN_BYTES % 16 == 0 && CWIN_BYTES % 16 == 0, "intermediates and transpose buffers need 16-byte alignment");
+  __shared__ __attribute__((aligned(16))) unsigned char regb[GPW * REG_BYTES];
+  // the two filter families this policy uses, copied next to the windows: a lane's taps depend on its block's vector, and a
+  // per-lane indexed read of __constant__ memory is a vector memory load (hundreds of cycles) in front of every candidate
+  __shared__ __attribute__((aligned(16))) int16_t s_filt[2][16][8];
+  if (threadIdx.x < 128) {
+    const int t = threadIdx.x;
+    reinterpret_cast<uint32_t *>(s_filt)[t] = t < 64 ? reinterpret_cast<const uint32_t *>(kRegular8)[t] : reinterpret_cast<const uint32_t *>(kRegular4)[t - 64];
+  }
+  __syncthreads();
 
   const int grp = threadIdx.x >> 3, lane = threadIdx.x & 7;
   const int bw = L.w / 8, bh = L.h / 8;
@@ -358,9 +374,10 @@ __global__ __launch_bounds__(256) void k_inter_pipe(InterLaunch L) {
   if (blk_all >= (long long)L.nframes * bw * bh) return;
   const int f = (int)(blk_all / (bw * bh)), blk = (int)(blk_all % (bw * bh)), by = blk / bw, bx = blk % bw;
   const int x = bx * 8, y = by * 8;
-  ES *wy = reinterpret_cast<ES *>(winb + grp * WIN_BYTES);
-  int16_t *im = imb + grp * IM_N;
-  int32_t *T = tb + grp * T_N;
+  unsigned char *reg = regb + grp * REG_BYTES;
+  ES *wy = reinterpret_cast<ES *>(reg);
+  int16_t *im = reinterpret_cast<int16_t *>(reg + YWIN_BYTES);
+  int32_t *T = reinterpret_cast<int32_t *>(reg);
 
   const Pix *src_y = reinterpret_cast<const Pix *>(L.src[0]) + (size_t)f * L.h * L.stride_y;
   const Pix *ref_y = reinterpret_cast<const Pix *>(L.ref[0]) + (size_t)f * L.h * L.stride_y;
@@ -409,7 +426,7 @@ __global__ __launch_bounds__(256) void k_inter_pipe(InterLaunch L) {
 #pragma unroll 1
     for (int ix = 0; ix < 3; ix++) {
       const int fx = cx + (ix - 1) * step;
-      mc_h16<ES>(wy, YWS, im, lane, fx * 2, kRegular8);
+      mc_h16<ES>(wy, YWS, im, lane, fx * 2, s_filt[0]);
       AV1MI_GROUP_SYNC();
       uint32_t pr[5][8];
       mc_rows9(im, lane, pr);
@@ -417,7 +434,7 @@ __global__ __launch_bounds__(256) void k_inter_pipe(InterLaunch L) {
       for (int iy = 0; iy < 3; iy++) {
         if (ix == 1 && iy == 1) continue;
         const int fy = cy + (iy - 1) * step, k = iy * 3 + ix;
-        mc_v9(pr, fy * 2, kRegular8, bd, out);
+        mc_v9(pr, fy * 2, s_filt[0], bd, out);
         uint32_t ow[4];
         pack4(out, ow);
         const int sd = sad_of(ow);
@@ -446,7 +463,9 @@ __global__ __launch_bounds__(256) void k_inter_pipe(InterLaunch L) {
     Pix *rec_c = reinterpret_cast<Pix *>(L.rec[1 + pl]) + (size_t)f * chh * L.stride_uv;
     // the vector in 1/16 chroma samples is the luma vector in 1/8 luma samples
     const int cix = mvx >> 4, ciy = mvy >> 4;         // integer chroma displacement (floor)
-    ES *wc = wy + YW * YWS + pl * CW * CWS;
+    ES *wc = wy + pl * CW * CWS;
+    int16_t *imc = reinterpret_cast<int16_t *>(reg + CWIN_BYTES) + pl * (11 * 4 + 4);
+    AV1MI_GROUP_SYNC();                               // the luma transpose buffer has been read: the region is free
 #pragma unroll
     for (int it = 0; it < 3; it++) {
       const int r = cl + it * 4;
@@ -457,7 +476,7 @@ __global__ __launch_bounds__(256) void k_inter_pipe(InterLaunch L) {
     int sc[4], pc[4], rc[4];
     load_row<4>(src_c + (size_t)(cy0 + cl) * L.stride_uv + cx0, sc);
     AV1MI_GROUP_SYNC();
-    mc_row<4, ES>(wc, CWS, im + pl * (11 * 4 + 4), cl, mvx & 15, mvy & 15, kRegular4, bd, pc);
+    mc_row<4, ES>(wc, CWS, imc, cl, mvx & 15, mvy & 15, s_filt[1], bd, pc);
     nz |= code_residual<4, Pix>(T + pl * 32, cl, sc, pc, L.dc_q, L.ac_q,
                                 L.lev[1 + pl] + (size_t)f * cw * chh + (size_t)blk * 16 + cl * 4, rc);
     store_row<4>(rec_c + (size_t)(cy0 + cl) * L.stride_uv + cx0, rc);
