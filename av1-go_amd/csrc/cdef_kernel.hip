@@ -114,20 +114,24 @@ __global__ __launch_bounds__(256) void k_cdef(CdefLaunch L) {
     for (int i = tid; i < 68 * 18; i += 256) {
       const int r = i / 18, g = i - r * 18;
       const Pix *q = sy + (size_t)(sby * 64 - 2 + r) * L.stride_y + sbx * 64 - 4 + g * 4;
-      int v[4];
-      if constexpr (sizeof(Pix) == 1) { const uint32_t u = *reinterpret_cast<const uint32_t *>(q); v[0] = u & 255; v[1] = (u >> 8) & 255; v[2] = (u >> 16) & 255; v[3] = u >> 24; }
-      else { const uint2 u = *reinterpret_cast<const uint2 *>(q); v[0] = u.x & 0xffff; v[1] = u.x >> 16; v[2] = u.y & 0xffff; v[3] = u.y >> 16; }
-#pragma unroll
-      for (int k = 0; k < 4; k++) { const int c = g * 4 + k - 2; if (c >= 0 && c < 68) ty[r * YS + c] = (uint16_t)v[k]; }
+      // the four samples as two uint16 pairs = two dword stores: samples 0,1 go to tile columns 4g - 2, 4g - 1 and samples
+      // 2,3 to 4g, 4g + 1 (even columns, even row stride: dword aligned); the first pair of a row and the last lie outside
+      uint32_t lo, hi;
+      if constexpr (sizeof(Pix) == 1) { const uint32_t u = *reinterpret_cast<const uint32_t *>(q); lo = __builtin_amdgcn_perm(0u, u, 0x0c010c00u); hi = __builtin_amdgcn_perm(0u, u, 0x0c030c02u); }
+      else { const uint2 u = *reinterpret_cast<const uint2 *>(q); lo = u.x; hi = u.y; }
+      uint32_t *d = reinterpret_cast<uint32_t *>(ty + r * YS + g * 4 - 2);
+      if (g > 0) d[0] = lo;
+      if (g < 17) d[1] = hi;
     }
     for (int i = tid; i < 2 * 36 * 10; i += 256) {
       const int pl = i / 360, j = i - pl * 360, r = j / 10, g = j - r * 10;
       const Pix *q = reinterpret_cast<const Pix *>(L.src[1 + pl]) + (size_t)f * chh * L.stride_uv + (size_t)(sby * 32 - 2 + r) * L.stride_uv + sbx * 32 - 4 + g * 4;
-      int v[4];
-      if constexpr (sizeof(Pix) == 1) { const uint32_t u = *reinterpret_cast<const uint32_t *>(q); v[0] = u & 255; v[1] = (u >> 8) & 255; v[2] = (u >> 16) & 255; v[3] = u >> 24; }
-      else { const uint2 u = *reinterpret_cast<const uint2 *>(q); v[0] = u.x & 0xffff; v[1] = u.x >> 16; v[2] = u.y & 0xffff; v[3] = u.y >> 16; }
-#pragma unroll
-      for (int k = 0; k < 4; k++) { const int c = g * 4 + k - 2; if (c >= 0 && c < 36) tc[pl][r * CSZ + c] = (uint16_t)v[k]; }
+      uint32_t lo, hi;
+      if constexpr (sizeof(Pix) == 1) { const uint32_t u = *reinterpret_cast<const uint32_t *>(q); lo = __builtin_amdgcn_perm(0u, u, 0x0c010c00u); hi = __builtin_amdgcn_perm(0u, u, 0x0c030c02u); }
+      else { const uint2 u = *reinterpret_cast<const uint2 *>(q); lo = u.x; hi = u.y; }
+      uint32_t *d = reinterpret_cast<uint32_t *>(tc[pl] + r * CSZ + g * 4 - 2);
+      if (g > 0) d[0] = lo;
+      if (g < 9) d[1] = hi;
     }
   } else {
     for (int i = tid; i < 68 * 68; i += 256) {

@@ -39,7 +39,12 @@ __constant__ int16_t kRegular4[16][8] = {
 // aligned dwords) and issues two QSADs with the row's two source dwords, which all lanes read from the same LDS address.
 template <typename Pix>
 __global__ __launch_bounds__(256) void k_me_int(InterLaunch L) {
-  constexpr int MAXR = 16, WS = 64 + 2 * MAXR + 16;   // window row stride in bytes (multiple of 4)
+  // window row stride in bytes: 35 dwords.  Consecutive lanes walk (dy pair, dx group): 5 consecutive dwords per dy pair, pairs
+  // two rows apart.  The window reads are ds_read2_b32 (32 banks per 32-lane group): with 28-dword rows two rows are 24 banks
+  // apart and pairs p and p + 4 land on the same banks (SQ_LDS_BANK_CONFLICT = 55 % of the LDS cycles); 2 x 35 = 6 mod 32 puts
+  // the six or seven pairs of a group on distinct banks.
+  constexpr int MAXR = 16, WS = 140;
+  static_assert(WS >= 64 + 2 * MAXR + 4 && WS % 4 == 0, "window row must hold tile + range and be whole dwords");
   __shared__ __attribute__((aligned(16))) uint8_t win[(64 + 2 * MAXR) * WS];
   __shared__ __attribute__((aligned(16))) uint8_t srct[64 * 64];
   __shared__ uint32_t s_best[64];                    // per 8x8 block: min of (SAD, rank)
@@ -95,13 +100,17 @@ __global__ __launch_bounds__(256) void k_me_int(InterLaunch L) {
   // rows, so nine rows of three dwords are read for 32 QSADs instead of sixteen.  The 16 blocks of a wave form ONE item
   // space (16 x per): with +-8 a block has 45 items, which alone would leave a 64-lane wave a third empty; the per-block
   // minimum is an LDS atomic instead of a wave reduction.
+  // item -> (block, dy pair, dx group) by reciprocal multiplication: u < 16 x 144 and (u + 0.5) / per is never closer than
+  // 0.5 / per to an integer, far outside float rounding, so the truncation is the exact quotient (an integer division by a
+  // run-time divisor is ~25 instructions, and there are two per item)
+  const float inv_per = 1.0f / (float)per, inv_ng = 1.0f / (float)NG;
   for (int u0 = 0; u0 < 16 * per; u0 += 64) {
     const int u = u0 + lane;
     if (u < 16 * per) {
-      const int bi = u / per, t = u - bi * per, b = wave + 4 * bi;
+      const int bi = (int)(((float)u + 0.5f) * inv_per), t = u - bi * per, b = wave + 4 * bi;
       const int by = b >> 3, bx = b & 7;
       if (sbx * 8 + bx < bw && sby * 8 + by < bh) {
-        const int dp = t / NG, g = t - dp * NG;    // dy = 2 dp - R and 2 dp + 1 - R, dx0 = -R4 + 4 g
+        const int dp = (int)(((float)t + 0.5f) * inv_ng), g = t - dp * NG;    // dy = 2 dp - R and 2 dp + 1 - R, dx0 = -R4 + 4 g
         const uint8_t *p = win + (by * 8 + 2 * dp) * WS + bx * 8 + 4 * g;
         const uint8_t *s = srct + (by * 8) * 64 + bx * 8;
         uint2 sr[8];
@@ -116,21 +125,24 @@ __global__ __launch_bounds__(256) void k_me_int(InterLaunch L) {
           if (r < 8) { acc0 = __builtin_amdgcn_qsad_pk_u16_u8(w01, sr[r].x, acc0); acc0 = __builtin_amdgcn_qsad_pk_u16_u8(w12, sr[r].y, acc0); }
           if (r > 0) { acc1 = __builtin_amdgcn_qsad_pk_u16_u8(w01, sr[r - 1].x, acc1); acc1 = __builtin_amdgcn_qsad_pk_u16_u8(w12, sr[r - 1].y, acc1); }
         }
+        // key = SAD << 10 | rank: (0,0) ranks first (0), the others in raster order (1 + (dy + R) NC + dx + R < 1024); ties keep
+        // the lower rank.  Branch-free: a displacement outside +-R gets rank ~0, which turns its key into ~0 under the OR.
+        // dx_i = 4 g - R4 + i is in range for i in [imin, imax]; the second row of the pair exists when 2 dp + 1 < NC.
+        const int imin = R4 - R - 4 * g, imax = R4 + R - 4 * g;
+        const unsigned rank0 = (unsigned)(2 * dp * NC + 4 * g - R4 + R + 1);
+        const unsigned inv_h1 = (unsigned)((NC - 2 - 2 * dp) >> 31);
         unsigned best = 0xFFFFFFFFu;
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
-          const int dyi = 2 * dp + h, dy = dyi - R;
-          const unsigned long long acc = h ? acc1 : acc0;
-#pragma unroll
-          for (int i = 0; i < 4; i++) {
-            const int dx = -R4 + 4 * g + i;
-            if (dx >= -R && dx <= R && dyi < NC) {
-              const unsigned sad = (unsigned)(acc >> (16 * i)) & 0xFFFFu;
-              // (0,0) ranks first, the others in raster order; ties keep the lower rank
-              const unsigned key = sad * 1024u + ((dx | dy) ? (unsigned)((dy + R) * NC + dx + R) + 1u : 0u);
-              best = min(best, key);
-            }
-          }
+        for (int i = 0; i < 4; i++) {
+          const unsigned inv = (unsigned)(((i - imin) | (imax - i)) >> 31);
+          const unsigned s0 = (unsigned)(acc0 >> (16 * i)) & 0xFFFFu, s1 = (unsigned)(acc1 >> (16 * i)) & 0xFFFFu;
+          best = min(best, min((s0 << 10) | (rank0 + i) | inv, (s1 << 10) | (rank0 + NC + i) | inv | inv_h1));
+        }
+        // the zero vector: dy index R = row R & 1 of pair R >> 1, dx index R4 = sample 0 of group R4 >> 2
+        {
+          const unsigned sz = (unsigned)((R & 1) ? acc1 : acc0) & 0xFFFFu;
+          const unsigned not_zero_item = (dp == (R >> 1) && g == (R4 >> 2)) ? 0u : 0xFFFFFFFFu;
+          best = min(best, (sz << 10) | not_zero_item);
         }
         atomicMin(&s_best[b], best);
       }
@@ -191,24 +203,28 @@ template <int N, typename ES> __device__ __forceinline__ void row_samples(const 
   for (int i = 0; i < N; i++) v[i] = (a[i / PER] >> ((i % PER) * 8 * (int)sizeof(ES))) & (sizeof(ES) == 1 ? 255u : 0xffffu);
 }
 
-template <int B, typename ES>
+// T0, T1: the filter family's non-zero taps are T0 .. T1 - 1 (the 4-tap families of blocks <= 4 wide: 2 .. 5; the other taps
+// are exactly 0, so leaving them out changes nothing but the work: 7 intermediate rows of 4 taps instead of 11 of 8).
+template <int B, typename ES, int T0 = 0, int T1 = 8>
 __device__ __forceinline__ void mc_row(const ES *win, int ws, int16_t *im, int lane, int posx, int posy, const int16_t (*filt)[8], int bd,
                                        int *out) {
   const int ox = 4 + (posx >> 4) - 3, oy = 4 + (posy >> 4) - 3;   // window column / row of tap 0 of sample (0,0)
-  int fx[8], fy[8];
+  constexpr int NT = T1 - T0, NR = B + NT - 1, PER = 4 / (int)sizeof(ES);
+  int fx[NT], fy[NT];
 #pragma unroll
-  for (int t = 0; t < 8; t++) { fx[t] = filt[posx & 15][t]; fy[t] = filt[posy & 15][t]; }
+  for (int t = 0; t < NT; t++) { fx[t] = filt[posx & 15][T0 + t]; fy[t] = filt[posy & 15][T0 + t]; }
 #pragma unroll
-  for (int it = 0; it < (2 * B + 6) / B; it++) {   // B + 7 intermediate rows over B lanes
-    const int j = lane + it * B;
-    if (j < B + 7) {
-      int v[B + 7];
-      row_samples<B + 7, ES>(win + (oy + j) * ws, ox, v);
+  for (int it = 0; it < (NR + B - 1) / B; it++) {   // intermediate rows T0 .. T0 + NR - 1 over B lanes
+    const int j = T0 + lane + it * B;
+    if (j < T0 + NR) {
+      int v[NR];
+      const int o = ox + T0;                        // first sample of the row that a non-zero tap touches
+      row_samples<NR, ES>(win + (oy + j) * ws + (o & ~(PER - 1)), o & (PER - 1), v);
 #pragma unroll
       for (int c = 0; c < B; c++) {
         int s = 0;
 #pragma unroll
-        for (int t = 0; t < 8; t++) s += fx[t] * v[c + t];
+        for (int t = 0; t < NT; t++) s += fx[t] * v[c + t];
         im[j * B + c] = (int16_t)((s + 4) >> 3);
       }
     }
@@ -219,7 +235,7 @@ __device__ __forceinline__ void mc_row(const ES *win, int ws, int16_t *im, int l
   for (int c = 0; c < B; c++) {
     int s = 0;
 #pragma unroll
-    for (int t = 0; t < 8; t++) s += fy[t] * (int)im[(lane + t) * B + c];
+    for (int t = 0; t < NT; t++) s += fy[t] * (int)im[(lane + T0 + t) * B + c];
     out[c] = min(max((s + 1024) >> 11, 0), maxpix);
   }
   AV1MI_GROUP_SYNC();
@@ -232,8 +248,10 @@ template <typename ES>
 __device__ __forceinline__ void mc_h16(const ES *win, int ws, int16_t *im, int lane, int posx, const int16_t (*filt)[8]) {
   const int ox = 4 + (posx >> 4) - 3;            // 0 or 1
   int fx[8];
+  if constexpr (sizeof(ES) == 1) {
 #pragma unroll
-  for (int t = 0; t < 8; t++) fx[t] = filt[posx & 15][t];
+    for (int t = 0; t < 8; t++) fx[t] = filt[posx & 15][t];
+  }
   constexpr int PER = 4 / (int)sizeof(ES), ND = 16 / PER;
 #pragma unroll
   for (int it = 0; it < 2; it++) {
@@ -272,9 +290,9 @@ __device__ __forceinline__ void mc_h16(const ES *win, int ws, int16_t *im, int l
       uint32_t pm[15];
 #pragma unroll
       for (int m = 0; m < 15; m++) pm[m] = (m & 1) ? __builtin_amdgcn_alignbit(a[(m + 1) >> 1], a[m >> 1], 16) : a[m >> 1];
-      s16x2 fp[4];
-#pragma unroll
-      for (int u = 0; u < 4; u++) fp[u] = __builtin_bit_cast(s16x2, (uint32_t)(fx[2 * u] & 0xffff) | ((uint32_t)fx[2 * u + 1] << 16));
+      // the tap row is 8 int16 = the four (even, odd) tap pairs as they lie in memory
+      const uint4 fq = *reinterpret_cast<const uint4 *>(filt[posx & 15]);
+      const s16x2 fp[4] = { __builtin_bit_cast(s16x2, fq.x), __builtin_bit_cast(s16x2, fq.y), __builtin_bit_cast(s16x2, fq.z), __builtin_bit_cast(s16x2, fq.w) };
 #pragma unroll
       for (int c = 0; c < 8; c++) {
         int acc = 4;
@@ -288,6 +306,24 @@ __device__ __forceinline__ void mc_h16(const ES *win, int ws, int16_t *im, int l
     for (int c = 0; c < 8; c++) {
       const uint32_t h = (uint32_t)(sum[c] >> 3) & 0xffff;
       o[c >> 1] = (c & 1) ? (o[c >> 1] | (h << 16)) : h;
+    }
+    *reinterpret_cast<uint4 *>(im + j * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+}
+// mc_h16 for a whole-sample horizontal position (posx = 0): phase 0 is the identity, (128 p + 4) >> 3 = 16 p exactly.
+template <typename ES>
+__device__ __forceinline__ void mc_h16_copy(const ES *win, int ws, int16_t *im, int lane) {
+#pragma unroll
+  for (int it = 0; it < 2; it++) {
+    const int j = lane + it * 8;
+    uint32_t o[4];
+    if constexpr (sizeof(ES) == 2) {
+      const uint4 a = *reinterpret_cast<const uint4 *>(win + j * ws + 4);        // samples 4 .. 11 of the row, two per dword
+      o[0] = a.x << 4; o[1] = a.y << 4; o[2] = a.z << 4; o[3] = a.w << 4;         // p < 2^12: no carry between the halves
+    } else {
+      const uint2 a = *reinterpret_cast<const uint2 *>(win + j * ws + 4);
+      o[0] = __builtin_amdgcn_perm(0u, a.x, 0x0c010c00u) << 4; o[1] = __builtin_amdgcn_perm(0u, a.x, 0x0c030c02u) << 4;
+      o[2] = __builtin_amdgcn_perm(0u, a.y, 0x0c010c00u) << 4; o[3] = __builtin_amdgcn_perm(0u, a.y, 0x0c030c02u) << 4;
     }
     *reinterpret_cast<uint4 *>(im + j * 8) = make_uint4(o[0], o[1], o[2], o[3]);
   }
@@ -318,18 +354,15 @@ __device__ __forceinline__ void mc_rows9(const int16_t *im, int lane, uint32_t (
 }
 __device__ __forceinline__ void mc_v9(const uint32_t (*pr)[8], int posy, const int16_t (*filt)[8], int bd, int *out) {
   const int oy = 4 + (posy >> 4) - 3;            // 0 or 1
-  int g[10];
-#pragma unroll
-  for (int k = 0; k < 9; k++) {
-    const int lo = k < 8 ? filt[posy & 15][k] : 0, hi = k > 0 ? filt[posy & 15][k - 1] : 0;
-    g[k] = oy ? hi : lo;
-  }
-  g[9] = 0;
+  // the nine taps over rows lane .. lane + 8 as five pairs: the row of 8 taps as it lies in memory (oy = 0: pairs P0..P3, 0),
+  // or moved up by one row (oy = 1: (0,t0) (t1,t2) (t3,t4) (t5,t6) (t7,0)) — one funnel shift per pair
+  const uint4 fq = *reinterpret_cast<const uint4 *>(filt[posy & 15]);
+  const uint32_t P[6] = { 0u, fq.x, fq.y, fq.z, fq.w, 0u };
   const int maxpix = (1 << bd) - 1;
   int s[8] = { 1024, 1024, 1024, 1024, 1024, 1024, 1024, 1024 };
 #pragma unroll
   for (int kp = 0; kp < 5; kp++) {
-    const s16x2 gp = __builtin_bit_cast(s16x2, (uint32_t)(g[2 * kp] & 0xffff) | ((uint32_t)g[2 * kp + 1] << 16));
+    const s16x2 gp = __builtin_bit_cast(s16x2, oy ? __builtin_amdgcn_alignbit(P[kp + 1], P[kp], 16) : P[kp + 1]);
 #pragma unroll
     for (int c = 0; c < 8; c++) s[c] = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, pr[kp][c]), gp, s[c], false);
   }
@@ -426,7 +459,9 @@ __global__ __launch_bounds__(256) void k_inter_pipe(InterLaunch L) {
 #pragma unroll 1
     for (int ix = 0; ix < 3; ix++) {
       const int fx = cx + (ix - 1) * step;
-      mc_h16<ES>(wy, YWS, im, lane, fx * 2, s_filt[0]);
+      // half-pel round, centre column: every block of the wave is at a whole-sample horizontal position
+      if (step == 4 && ix == 1) mc_h16_copy<ES>(wy, YWS, im, lane);
+      else mc_h16<ES>(wy, YWS, im, lane, fx * 2, s_filt[0]);
       AV1MI_GROUP_SYNC();
       uint32_t pr[5][8];
       mc_rows9(im, lane, pr);
@@ -476,7 +511,7 @@ __global__ __launch_bounds__(256) void k_inter_pipe(InterLaunch L) {
     int sc[4], pc[4], rc[4];
     load_row<4>(src_c + (size_t)(cy0 + cl) * L.stride_uv + cx0, sc);
     AV1MI_GROUP_SYNC();
-    mc_row<4, ES>(wc, CWS, imc, cl, mvx & 15, mvy & 15, s_filt[1], bd, pc);
+    mc_row<4, ES, 2, 6>(wc, CWS, imc, cl, mvx & 15, mvy & 15, s_filt[1], bd, pc);
     nz |= code_residual<4, Pix>(T + pl * 32, cl, sc, pc, L.dc_q, L.ac_q,
                                 L.lev[1 + pl] + (size_t)f * cw * chh + (size_t)blk * 16 + cl * 4, rc);
     store_row<4>(rec_c + (size_t)(cy0 + cl) * L.stride_uv + cx0, rc);
