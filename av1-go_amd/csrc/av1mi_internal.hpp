@@ -6,6 +6,23 @@
 
 namespace av1mi {
 
+// XCD-aware block order (cdna_hip_programming.md T1).  The dispatcher deals consecutive workgroup ids to the 8 XCDs in turn, and
+// each XCD has its own L2: with a plain raster grid every neighbour of a tile (left, right, above, below) runs on another XCD,
+// so the halo rows and columns that adjacent tiles share are fetched through several L2s (the filter kernels read 3-4x their
+// algorithmic bytes by FETCH_SIZE).  The remap gives the ids that share an XCD (id % 8) one contiguous run of `nwg / 8` tiles in
+// raster order, bijective for any nwg; it is an affinity hint only, nothing depends on where a block actually runs.
+__device__ __forceinline__ unsigned xcd_swizzle(unsigned bid, unsigned nwg) {
+  const unsigned q = nwg >> 3, r = nwg & 7u, xcd = bid & 7u;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+// raster tile index -> (x, y, z) of a gx x gy x gz grid
+struct Tile3 { int x, y, z; };
+__device__ __forceinline__ Tile3 xcd_tile(unsigned gx, unsigned gy, unsigned gz) {
+  const unsigned t = xcd_swizzle(blockIdx.x, gx * gy * gz);
+  const unsigned z = t / (gx * gy), rem = t - z * gx * gy, y = rem / gx;
+  return { (int)(rem - y * gx), (int)y, (int)z };
+}
+
 // One transform launch: either a block list or an implicit grid of equal blocks.
 struct TxLaunch {
   int32_t *coef;            // int32 coefficients (K2: in, K1: out)

@@ -100,7 +100,8 @@ __global__ __launch_bounds__(256) void k_cdef(CdefLaunch L) {
   __shared__ __attribute__((aligned(16))) int16_t offy[64], offc[64];   // tap offsets per direction for the two tile strides
   const int tid = threadIdx.x;
   if (tid < 64) cdef_fill_offsets<YS>(offy, tid); else if (tid < 128) cdef_fill_offsets<CSZ>(offc, tid - 64);
-  const int sbx = blockIdx.x, sby = blockIdx.y, f = blockIdx.z;
+  const Tile3 tl = xcd_tile((L.w + 63) / 64, (L.h + 63) / 64, L.nframes);
+  const int sbx = tl.x, sby = tl.y, f = tl.z;
   const int bd = L.bd, cs = bd - 8;
   const Pix *sy = reinterpret_cast<const Pix *>(L.src[0]) + (size_t)f * L.h * L.stride_y;
   Pix *dy = reinterpret_cast<Pix *>(L.dst[0]) + (size_t)f * L.h * L.stride_y;
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(256) void k_cdef(CdefLaunch L) {
 }
 
 hipError_t launch_cdef(const CdefLaunch &L, hipStream_t s) {
-  const dim3 grid((L.w + 63) / 64, (L.h + 63) / 64, L.nframes);
+  const dim3 grid((unsigned)(((L.w + 63) / 64) * ((L.h + 63) / 64) * L.nframes));   // 1-D: k_cdef orders the tiles itself (xcd_tile)
   if (L.bd == 8) hipLaunchKernelGGL(k_cdef<uint8_t>, grid, dim3(256), 0, s, L);
   else hipLaunchKernelGGL(k_cdef<uint16_t>, grid, dim3(256), 0, s, L);
   return hipGetLastError();

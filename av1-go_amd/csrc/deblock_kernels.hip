@@ -128,10 +128,11 @@ __global__ __launch_bounds__(256) void k_deblock(DeblockLaunch L) {
   __shared__ uint16_t tile[LH * LS];
   __shared__ uint32_t mis[MH * MW];
   const int tid = threadIdx.x;
-  const int X0 = blockIdx.x * TW - HALO, Y0 = blockIdx.y * TH - HALO;   // frame coords of LDS (0,0)
-  // frame blockIdx.z of a stack of frames: planes are stacked vertically, mode info per frame or shared
-  const Pix *src = reinterpret_cast<const Pix *>(L.src) + (size_t)blockIdx.z * L.h * L.src_stride;
-  const uint32_t *mi = L.mi + (size_t)blockIdx.z * L.mi_frame_stride;
+  const Tile3 tl = xcd_tile((L.w + TW - 1) / TW, (L.h + TH - 1) / TH, L.nframes);
+  const int X0 = tl.x * TW - HALO, Y0 = tl.y * TH - HALO;   // frame coords of LDS (0,0)
+  // frame tl.z of a stack of frames: planes are stacked vertically, mode info per frame or shared
+  const Pix *src = reinterpret_cast<const Pix *>(L.src) + (size_t)tl.z * L.h * L.src_stride;
+  const uint32_t *mi = L.mi + (size_t)tl.z * L.mi_frame_stride;
   const int cols = L.w >> 2, rows = L.h >> 2;
   // mode-info units (0xFFFFFFFF outside the plane)
   for (int i = tid; i < MH * MW; i += 256) {
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(256) void k_deblock(DeblockLaunch L) {
   }
   __syncthreads();
   // write the window, 4 samples per lane per step
-  Pix *dst = reinterpret_cast<Pix *>(L.dst) + (size_t)blockIdx.z * L.h * L.dst_stride;
+  Pix *dst = reinterpret_cast<Pix *>(L.dst) + (size_t)tl.z * L.h * L.dst_stride;
   for (int i = tid; i < TH * (TW / 4); i += 256) {
     const int wy = i / (TW / 4), wx = (i % (TW / 4)) * 4;
     const int fy = Y0 + HALO + wy, fx = X0 + HALO + wx;
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(256) void k_deblock(DeblockLaunch L) {
 
 hipError_t launch_deblock(const DeblockLaunch &L, hipStream_t s) {
   constexpr int TW = 64, TH = 64;
-  const dim3 grid((L.w + TW - 1) / TW, (L.h + TH - 1) / TH, L.nframes);
+  const dim3 grid((unsigned)(((L.w + TW - 1) / TW) * ((L.h + TH - 1) / TH) * L.nframes));   // 1-D: the kernel orders the tiles (xcd_tile)
   if (L.bd == 8) hipLaunchKernelGGL((k_deblock<uint8_t, TW, TH>), grid, dim3(256), 0, s, L);
   else hipLaunchKernelGGL((k_deblock<uint16_t, TW, TH>), grid, dim3(256), 0, s, L);
   return hipGetLastError();

@@ -52,7 +52,8 @@ __global__ __launch_bounds__(256) void k_me_int(InterLaunch L) {
   const int tid = threadIdx.x, R = L.range, R4 = (R + 3) & ~3, NC = 2 * R + 1;
   const int WDX = 64 + 2 * R4 + 4, WDY = 64 + 2 * R + 1;    // window columns start at x - R4 (4-aligned), rows at y - R; one more row for the unused half of the last dy pair
   const int sbw = (L.w + 63) / 64;
-  const int f = blockIdx.y, sb = blockIdx.x, sby = sb / sbw, sbx = sb % sbw;
+  const Tile3 tl = xcd_tile(sbw, (L.h + 63) / 64, L.nframes);
+  const int f = tl.z, sby = tl.y, sbx = tl.x;
   const Pix *src = reinterpret_cast<const Pix *>(L.src[0]) + (size_t)f * L.h * L.stride_y;
   const Pix *ref = reinterpret_cast<const Pix *>(L.ref[0]) + (size_t)f * L.h * L.stride_y;
   // staging, four samples per lane per step (the window starts on a 4-sample boundary and its width is a multiple of 4);
@@ -403,7 +404,8 @@ __global__ __launch_bounds__(256) void k_inter_pipe(InterLaunch L) {
 
   const int grp = threadIdx.x >> 3, lane = threadIdx.x & 7;
   const int bw = L.w / 8, bh = L.h / 8;
-  const long long blk_all = (long long)blockIdx.x * GPW + grp;
+  // workgroups in XCD-aware order: vertically adjacent block rows (their windows overlap by 8 of 16 rows) share an L2
+  const long long blk_all = (long long)xcd_swizzle(blockIdx.x, gridDim.x) * GPW + grp;
   if (blk_all >= (long long)L.nframes * bw * bh) return;
   const int f = (int)(blk_all / (bw * bh)), blk = (int)(blk_all % (bw * bh)), by = blk / bw, bx = blk % bw;
   const int x = bx * 8, y = by * 8;
@@ -524,7 +526,7 @@ __global__ __launch_bounds__(256) void k_inter_pipe(InterLaunch L) {
 hipError_t launch_me_int(const InterLaunch &L, hipStream_t s) {
   if (L.nframes <= 0) return hipSuccess;
   const int sbs = ((L.w + 63) / 64) * ((L.h + 63) / 64);
-  const dim3 g1(sbs, L.nframes);
+  const dim3 g1((unsigned)(sbs * L.nframes));   // 1-D: the kernel orders the tiles (xcd_tile)
   if (L.bd == 8) hipLaunchKernelGGL(k_me_int<uint8_t>, g1, dim3(256), 0, s, L);
   else hipLaunchKernelGGL(k_me_int<uint16_t>, g1, dim3(256), 0, s, L);
   return hipGetLastError();

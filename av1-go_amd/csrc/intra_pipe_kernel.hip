@@ -152,7 +152,8 @@ __global__ __launch_bounds__(256, BS == 8 ? 3 : 1) void k_intra_pipe(IntraPipeLa
 
   const int grp = threadIdx.x / BS, lane = threadIdx.x % BS;
   const int sbw = (L.w + 63) / 64, sbh = (L.h + 63) / 64;
-  const long long tile = (long long)blockIdx.x * TPW + grp;
+  // workgroups in XCD-aware order (av1mi_internal.hpp): horizontally adjacent tiles share 128-byte lines of every plane row
+  const long long tile = (long long)xcd_swizzle(blockIdx.x, gridDim.x) * TPW + grp;
   if (tile >= (long long)L.nframes * sbw * sbh) return;
   const int f = (int)(tile / (sbw * sbh)), sb = (int)(tile % (sbw * sbh)), sby = sb / sbw, sbx = sb % sbw;
   const int bw = L.w / BS, bh = L.h / BS;

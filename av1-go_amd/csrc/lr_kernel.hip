@@ -36,7 +36,8 @@ __global__ __launch_bounds__(256) void k_lr(LrLaunch L) {
   const int tid = threadIdx.x, bd = L.bd, ss = L.ss;
   const int SH = 64 >> ss, off = 8 >> ss;
   const int tw = L.unit_size < 64 ? L.unit_size : 64;
-  const int X0 = blockIdx.x * tw, stripe = blockIdx.y, f = blockIdx.z;
+  const Tile3 tl = xcd_tile((L.w + tw - 1) / tw, (L.h + off + SH - 1) / SH, L.nframes);
+  const int X0 = tl.x * tw, stripe = tl.y, f = tl.z;
   const int sstart = stripe * SH - off, send = sstart + SH - 1;
   const int y0 = max(sstart, 0), y1 = min(send, L.h - 1);    // rows this workgroup writes
   if (y0 > y1 || X0 >= L.w) return;
@@ -100,46 +101,76 @@ __global__ __launch_bounds__(256) void k_lr(LrLaunch L) {
     hf[3] = 128 - 2 * (U[4] + U[5] + U[6]);
     const int offset = 1 << (bd + 3), limit = (1 << (bd + 5)) - 1;
     if (!(bw & 3)) {
-      // four outputs per lane: ten source samples read once; the vertical pass reads four int16 per tap as one 8-byte word
+      // Both passes on v_dot2_i32_i16 (two taps per instruction; samples and the clipped intermediate fit int16, the sums are
+      // exact in int32).  Horizontal: four outputs per lane from six aligned dwords of the source row (window columns
+      // c .. c + 11, the taps of output k start at column c + 1 + k): outputs 1 and 3 use the dwords as they are, outputs 0 and
+      // 2 the same dwords funnel-shifted by one sample.  Tap pairs (h0,h1) (h2,h3) (h4,h5) (h6,0).
+      typedef short s16x2 __attribute__((ext_vector_type(2)));
+      auto pk = [](int a, int b) { return __builtin_bit_cast(s16x2, (uint32_t)(a & 0xffff) | ((uint32_t)b << 16)); };
+      const s16x2 H0 = pk(hf[0], hf[1]), H1 = pk(hf[2], hf[3]), H2 = pk(hf[4], hf[5]), H3 = pk(hf[6], 0);
       const int q4 = bw / 4;
       const bool full = bw == MAXW;
       for (int i = tid; i < (bh + 6) * q4; i += 256) {
         const int r = full ? i / (MAXW / 4) : i / q4, c = (i - r * q4) * 4;
-        const uint16_t *p = src + r * SS + c + 1;
-        int v[10];
+        const uint2 *p = reinterpret_cast<const uint2 *>(src + r * SS + c);
+        const uint2 a = p[0], b = p[1], e = p[2];
+        const uint32_t d[6] = { a.x, a.y, b.x, b.y, e.x, e.y };
+        uint32_t A[6];
 #pragma unroll
-        for (int t = 0; t < 10; t++) v[t] = p[t];
+        for (int m = 1; m < 6; m++) A[m] = __builtin_amdgcn_alignbit(d[m], d[m - 1], 16);   // columns (c + 2m - 1, c + 2m)
         int o[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-          int sum = 0;
-#pragma unroll
-          for (int t = 0; t < 7; t++) sum += hf[t] * v[k + t];
-          o[k] = min(max((sum + 4) >> 3, -offset), limit - offset);
+          // output k: columns c + 1 + k .. c + 7 + k
+          const uint32_t *w = (k & 1) ? d + (k + 1) / 2 : A + k / 2 + 1;
+          int sum = 4;
+          sum = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, w[0]), H0, sum, false);
+          sum = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, w[1]), H1, sum, false);
+          sum = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, w[2]), H2, sum, false);
+          sum = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, w[3]), H3, sum, false);
+          o[k] = min(max(sum >> 3, -offset), limit - offset);
         }
         uint2 w; w.x = (uint32_t)(o[0] & 0xffff) | ((uint32_t)o[1] << 16); w.y = (uint32_t)(o[2] & 0xffff) | ((uint32_t)o[3] << 16);
         *reinterpret_cast<uint2 *>(inter + r * MAXW + c) = w;
       }
       __syncthreads();
-      for (int i = tid; i < bh * q4; i += 256) {
-        const int r = full ? i / (MAXW / 4) : i / q4, c = (i - r * q4) * 4;
-        int sum[4] = { 0, 0, 0, 0 };
+      // Vertical: a lane produces rows 2 rp and 2 rp + 1 of four columns from intermediate rows 2 rp .. 2 rp + 7, interleaved
+      // once into row pairs per column; the even row pairs its taps (v0,v1) (v2,v3) (v4,v5) (v6,0), the odd row the same
+      // row pairs with the taps moved up by one row: (0,v0) (v1,v2) (v3,v4) (v5,v6).
+      const s16x2 VE[4] = { pk(vf[0], vf[1]), pk(vf[2], vf[3]), pk(vf[4], vf[5]), pk(vf[6], 0) };
+      const s16x2 VO[4] = { pk(0, vf[0]), pk(vf[1], vf[2]), pk(vf[3], vf[4]), pk(vf[5], vf[6]) };
+      const int hp = (bh + 1) >> 1;
+      for (int i = tid; i < hp * q4; i += 256) {
+        const int rp = full ? i / (MAXW / 4) : i / q4, c = (i - rp * q4) * 4, r = 2 * rp;
+        int se[4] = { 1024, 1024, 1024, 1024 }, so[4] = { 1024, 1024, 1024, 1024 };
 #pragma unroll
-        for (int t = 0; t < 7; t++) {
-          const uint2 w = *reinterpret_cast<const uint2 *>(inter + (r + t) * MAXW + c);
-          sum[0] += vf[t] * (int16_t)(w.x & 0xffff); sum[1] += vf[t] * (int16_t)(w.x >> 16);
-          sum[2] += vf[t] * (int16_t)(w.y & 0xffff); sum[3] += vf[t] * (int16_t)(w.y >> 16);
+        for (int j = 0; j < 4; j++) {
+          // rows r + 2j, r + 2j + 1 (the last pair of an odd-height block reads one row past the intermediate: inside the
+          // scratch buffer, and only the odd output row, which is not stored then, depends on it)
+          const uint2 x = *reinterpret_cast<const uint2 *>(inter + (r + 2 * j) * MAXW + c);
+          const uint2 y = *reinterpret_cast<const uint2 *>(inter + (r + 2 * j + 1) * MAXW + c);
+          const uint32_t pr[4] = { __builtin_amdgcn_perm(y.x, x.x, 0x05040100u), __builtin_amdgcn_perm(y.x, x.x, 0x07060302u),
+                                   __builtin_amdgcn_perm(y.y, x.y, 0x05040100u), __builtin_amdgcn_perm(y.y, x.y, 0x07060302u) };
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            se[k] = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, pr[k]), VE[j], se[k], false);
+            so[k] = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, pr[k]), VO[j], so[k], false);
+          }
         }
-        int o[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) o[k] = min(max((sum[k] + 1024) >> 11, 0), maxpix);
-        Pix *d = out + (size_t)(y0 + r) * L.stride + X0 + c;
-        if (((uintptr_t)d & (4 * sizeof(Pix) - 1)) == 0) {
-          if constexpr (sizeof(Pix) == 1) *reinterpret_cast<uint32_t *>(d) = (uint32_t)o[0] | ((uint32_t)o[1] << 8) | ((uint32_t)o[2] << 16) | ((uint32_t)o[3] << 24);
-          else { uint2 u; u.x = (uint32_t)o[0] | ((uint32_t)o[1] << 16); u.y = (uint32_t)o[2] | ((uint32_t)o[3] << 16); *reinterpret_cast<uint2 *>(d) = u; }
-        } else {
+        for (int half = 0; half < 2; half++) {
+          if (r + half >= bh) break;
+          int o[4];
 #pragma unroll
-          for (int k = 0; k < 4; k++) d[k] = (Pix)o[k];
+          for (int k = 0; k < 4; k++) o[k] = min(max((half ? so[k] : se[k]) >> 11, 0), maxpix);
+          Pix *d = out + (size_t)(y0 + r + half) * L.stride + X0 + c;
+          if (((uintptr_t)d & (4 * sizeof(Pix) - 1)) == 0) {
+            if constexpr (sizeof(Pix) == 1) *reinterpret_cast<uint32_t *>(d) = (uint32_t)o[0] | ((uint32_t)o[1] << 8) | ((uint32_t)o[2] << 16) | ((uint32_t)o[3] << 24);
+            else { uint2 u; u.x = (uint32_t)o[0] | ((uint32_t)o[1] << 16); u.y = (uint32_t)o[2] | ((uint32_t)o[3] << 16); *reinterpret_cast<uint2 *>(d) = u; }
+          } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) d[k] = (Pix)o[k];
+          }
         }
       }
       return;
@@ -228,7 +259,7 @@ __global__ __launch_bounds__(256) void k_lr(LrLaunch L) {
 hipError_t launch_lr(const LrLaunch &L, hipStream_t s) {
   const int SH = 64 >> L.ss, off = 8 >> L.ss;
   const int tw = L.unit_size < 64 ? L.unit_size : 64;
-  const dim3 grid((L.w + tw - 1) / tw, (L.h + off + SH - 1) / SH, L.nframes);
+  const dim3 grid((unsigned)(((L.w + tw - 1) / tw) * ((L.h + off + SH - 1) / SH) * L.nframes));   // 1-D: the kernel orders the tiles (xcd_tile)
   if (L.bd == 8) hipLaunchKernelGGL(k_lr<uint8_t>, grid, dim3(256), 0, s, L);
   else hipLaunchKernelGGL(k_lr<uint16_t>, grid, dim3(256), 0, s, L);
   return hipGetLastError();

@@ -52,3 +52,17 @@ def test_inter_1080p_frame(ctx, O):
     exp = O.inter_encode_frame((Y[1], U[1], V[1]), ref, 8, q, 8)
     for k in KEYS:
         assert (got[k][0] == exp[k]).all(), k
+
+
+def test_inter_4k_10bit_frame(ctx, O):
+    """BASELINE configs[3] size, the bench's default workload: one 3840x2160 10-bit P frame — integer search, sub-pel
+    refinement, vectors, skip flags, levels and reconstruction — equals the oracle's inter encoder loop bit for bit"""
+    w, h, q = 3840, 2160, 128
+    Y, U, V = synth.frames(w, h, 2, 10, first=11)
+    ref = _ref_from_intra(O, Y[0], U[0], V[0], 10, q)
+    got = ctx.inter_encode_arrays((Y[1:], U[1:], V[1:]), tuple(r[None] for r in ref), 10, q, 8)
+    exp = O.inter_encode_frame((Y[1], U[1], V[1]), ref, 10, q, 8)
+    for k in KEYS:
+        assert (got[k][0] == exp[k]).all(), (k, np.argwhere(got[k][0] != exp[k])[:4])
+    mv = got["mvs"][0]
+    assert np.mean((mv[:, 0] == 10) & (mv[:, 1] == 6)) > 0.5      # the clip moves by (1.25, 0.75) px per frame
