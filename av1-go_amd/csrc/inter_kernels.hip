@@ -353,22 +353,28 @@ __device__ __forceinline__ void mc_rows9(const int16_t *im, int lane, uint32_t (
     }
   }
 }
-__device__ __forceinline__ void mc_v9(const uint32_t (*pr)[8], int posy, const int16_t (*filt)[8], int bd, int *out) {
+// `filt32` holds the taps times 32: (32 s + 32768) >> 16 == (s + 1024) >> 11 exactly, and the result is then the high half of
+// the accumulator — one v_perm takes the high halves of two sums, shift and pack in one instruction (the products stay far
+// inside int32: |intermediate| < 2^15, sum of |taps| x 32 < 2^13).  Returns row `lane` of the prediction as four packed pairs.
+__device__ __forceinline__ void mc_v9(const uint32_t (*pr)[8], int posy, const int16_t (*filt32)[8], int bd, uint32_t *ow) {
   const int oy = 4 + (posy >> 4) - 3;            // 0 or 1
   // the nine taps over rows lane .. lane + 8 as five pairs: the row of 8 taps as it lies in memory (oy = 0: pairs P0..P3, 0),
   // or moved up by one row (oy = 1: (0,t0) (t1,t2) (t3,t4) (t5,t6) (t7,0)) — one funnel shift per pair
-  const uint4 fq = *reinterpret_cast<const uint4 *>(filt[posy & 15]);
+  const uint4 fq = *reinterpret_cast<const uint4 *>(filt32[posy & 15]);
   const uint32_t P[6] = { 0u, fq.x, fq.y, fq.z, fq.w, 0u };
-  const int maxpix = (1 << bd) - 1;
-  int s[8] = { 1024, 1024, 1024, 1024, 1024, 1024, 1024, 1024 };
+  int s[8] = { 32768, 32768, 32768, 32768, 32768, 32768, 32768, 32768 };
 #pragma unroll
   for (int kp = 0; kp < 5; kp++) {
     const s16x2 gp = __builtin_bit_cast(s16x2, oy ? __builtin_amdgcn_alignbit(P[kp + 1], P[kp], 16) : P[kp + 1]);
 #pragma unroll
     for (int c = 0; c < 8; c++) s[c] = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, pr[kp][c]), gp, s[c], false);
   }
+  const s16x2 zero = { 0, 0 }, top = { (short)((1 << bd) - 1), (short)((1 << bd) - 1) };
 #pragma unroll
-  for (int c = 0; c < 8; c++) out[c] = min(max(s[c] >> 11, 0), maxpix);
+  for (int j = 0; j < 4; j++) {
+    const s16x2 v = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm((uint32_t)s[2 * j + 1], (uint32_t)s[2 * j], 0x07060302u));
+    ow[j] = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_elementwise_max(v, zero), top));
+  }
 }
 
 __host__ __device__ constexpr int cmax3(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
@@ -395,10 +401,11 @@ __global__ __launch_bounds__(256) void k_inter_pipe(InterLaunch L) {
   __shared__ __attribute__((aligned(16))) unsigned char regb[GPW * REG_BYTES];
   // the two filter families this policy uses, copied next to the windows: a lane's taps depend on its block's vector, and a
   // per-lane indexed read of __constant__ memory is a vector memory load (hundreds of cycles) in front of every candidate
-  __shared__ __attribute__((aligned(16))) int16_t s_filt[2][16][8];
+  __shared__ __attribute__((aligned(16))) int16_t s_filt[3][16][8];   // regular 8-tap, regular 4-tap, regular 8-tap x 32 (mc_v9)
   if (threadIdx.x < 128) {
     const int t = threadIdx.x;
     reinterpret_cast<uint32_t *>(s_filt)[t] = t < 64 ? reinterpret_cast<const uint32_t *>(kRegular8)[t] : reinterpret_cast<const uint32_t *>(kRegular4)[t - 64];
+    s_filt[2][t >> 3][t & 7] = (int16_t)(kRegular8[t >> 3][t & 7] * 32);
   }
   __syncthreads();
 
@@ -428,7 +435,7 @@ __global__ __launch_bounds__(256) void k_inter_pipe(InterLaunch L) {
     const Pix *row = ref_y + (size_t)fy * L.stride_y;
     stage_window_row<YW, Pix>(row, x + imx - 4, L.w, wy + r * YWS);
   }
-  int s[8], bp[8], out[8];
+  int s[8], bp[8];
   load_row<8>(src_y + (size_t)(y + lane) * L.stride_y + x, s);
   AV1MI_GROUP_SYNC();
   // rows are compared as packed pairs (v_sad_u16: two samples per instruction, both bit depths) and the running best
@@ -457,7 +464,8 @@ __global__ __launch_bounds__(256) void k_inter_pipe(InterLaunch L) {
     // them in raster order k = 0..8 with strict improvement, i.e. the winner is the minimum of (SAD, k) and the centre
     // keeps ties; that order is reproduced with an explicit rank.
     const int cx = bfx, cy = bfy;
-    int rbest = -1;                                  // rank of the current best inside this round (-1: the centre)
+    // (SAD, rank) as one key: rank 0 = the centre (it keeps ties), k + 1 = the neighbour visited k-th in raster order
+    unsigned bestkey = (unsigned)best << 4;
 #pragma unroll 1
     for (int ix = 0; ix < 3; ix++) {
       const int fx = cx + (ix - 1) * step;
@@ -471,17 +479,21 @@ __global__ __launch_bounds__(256) void k_inter_pipe(InterLaunch L) {
       for (int iy = 0; iy < 3; iy++) {
         if (ix == 1 && iy == 1) continue;
         const int fy = cy + (iy - 1) * step, k = iy * 3 + ix;
-        mc_v9(pr, fy * 2, s_filt[0], bd, out);
         uint32_t ow[4];
-        pack4(out, ow);
-        const int sd = sad_of(ow);
-        const bool better = sd < best || (sd == best && rbest >= 0 && k < rbest);
-        best = better ? sd : best; bfx = better ? fx : bfx; bfy = better ? fy : bfy; rbest = better ? k : rbest;
+        mc_v9(pr, fy * 2, s_filt[2], bd, ow);
+        const unsigned key = ((unsigned)sad_of(ow) << 4) | (unsigned)(k + 1);
+        const bool better = key < bestkey;
+        bestkey = min(bestkey, key);
 #pragma unroll
         for (int j = 0; j < 4; j++) bpp[j] = better ? ow[j] : bpp[j];
       }
       AV1MI_GROUP_SYNC();
     }
+    // the round's winner back from its key
+    const int rk = (int)(bestkey & 15u), kk = rk - 1, wy_ = (kk * 11) >> 5, wx_ = kk - 3 * wy_;   // kk / 3 for kk in 0..8
+    best = (int)(bestkey >> 4);
+    bfx = rk ? cx + (wx_ - 1) * step : cx;
+    bfy = rk ? cy + (wy_ - 1) * step : cy;
   }
 #pragma unroll
   for (int j = 0; j < 4; j++) { bp[2 * j] = bpp[j] & 0xffff; bp[2 * j + 1] = bpp[j] >> 16; }
