@@ -119,13 +119,36 @@ __device__ __forceinline__ int lf_edge(uint32_t cur, uint32_t prev, int pass, in
   return base == 4 ? 4 : base == 8 ? 8 : 14;
 }
 
+// One edge line of compile-time filter length: reads only the 2 x HALF samples that length can look at (p3..q3 for 8, p6..q6
+// for 14), filters, and writes back the 2 x M it can modify, unconditionally.  `step` = element stride across the edge (1 for
+// vertical edges, the tile's row stride for horizontal ones).  The run-time-length form paid 16 loads and 12 predicated stores
+// (each a compare + exec-mask round trip) per line whatever the length.
+template <int LEN>
+__device__ __forceinline__ void lf_line(uint16_t *p, int step, LfThr t, int bd) {
+  constexpr int HALF = LEN == 14 ? 7 : LEN == 8 ? 4 : LEN == 6 ? 3 : 2, M = LEN == 14 ? 6 : LEN == 8 ? 3 : 2;
+  int px[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) px[k] = (k >= 8 - HALF && k < 8 + HALF) ? (int)p[(k - 8) * step] : 0;
+  lf_filter(px, LEN, t, bd);
+#pragma unroll
+  for (int k = 8 - M; k < 8 + M; k++) p[(k - 8) * step] = (uint16_t)px[k];
+}
+// lanes of a wave almost always share the length (it depends on the transform sizes on both sides of the edge): a chain of
+// uniform branches, each body specialised
+__device__ __forceinline__ void lf_line_any(uint16_t *p, int step, int len, LfThr t, int bd) {
+  if (len == 8) lf_line<8>(p, step, t, bd);
+  else if (len == 4) lf_line<4>(p, step, t, bd);
+  else if (len == 6) lf_line<6>(p, step, t, bd);
+  else lf_line<14>(p, step, t, bd);
+}
+
 template <typename Pix, int TW, int TH>
 __global__ __launch_bounds__(256) void k_deblock(DeblockLaunch L) {
   // Halo of 8: an edge needs at most p6..q6 (13-tap filter) plus the flatness tests up to p6/q6; an edge whose filter can
   // reach the window lies in [0, TW] x [0, TH], so source samples in [-8, TW + 8) x [-8, TH + 8) are all that is ever read
   constexpr int HALO = 8, LW = TW + 2 * HALO, LH = TH + 2 * HALO, LS = LW + 2;   // +2: odd dword row stride
   constexpr int MW = LW / 4, MH = LH / 4;
-  __shared__ uint16_t tile[LH * LS];
+  __shared__ __attribute__((aligned(16))) uint16_t tile[LH * LS];
   __shared__ uint32_t mis[MH * MW];
   const int tid = threadIdx.x;
   const Tile3 tl = xcd_tile((L.w + TW - 1) / TW, (L.h + TH - 1) / TH, L.nframes);
@@ -148,12 +171,14 @@ __global__ __launch_bounds__(256) void k_deblock(DeblockLaunch L) {
     const Pix *row = src + (size_t)fy * L.src_stride;
     uint16_t *d = tile + ly * LS + lx;
     if (fx >= 0 && fx + 3 < L.w) {
+      // four samples = two uint16 pairs = two dword stores (rows are an even number of samples, lx a multiple of 4)
+      uint32_t *d32 = reinterpret_cast<uint32_t *>(d);
       if constexpr (sizeof(Pix) == 1) {
         const uint32_t u = *reinterpret_cast<const uint32_t *>(row + fx);
-        d[0] = u & 255; d[1] = (u >> 8) & 255; d[2] = (u >> 16) & 255; d[3] = u >> 24;
+        d32[0] = __builtin_amdgcn_perm(0u, u, 0x0c010c00u); d32[1] = __builtin_amdgcn_perm(0u, u, 0x0c030c02u);
       } else {
         const uint2 u = *reinterpret_cast<const uint2 *>(row + fx);
-        d[0] = u.x & 0xffff; d[1] = u.x >> 16; d[2] = u.y & 0xffff; d[3] = u.y >> 16;
+        d32[0] = u.x; d32[1] = u.y;
       }
     } else {
 #pragma unroll
@@ -175,15 +200,8 @@ __global__ __launch_bounds__(256) void k_deblock(DeblockLaunch L) {
       int lvl = 0;
       const int len = lf_edge(mis[(ly >> 2) * MW + uc], mis[(ly >> 2) * MW + uc - 1], 0, fx, L.is_chroma, lvl);
       if (!len) continue;
-      uint16_t *p = tile + ly * LS + 4 * uc;
-      int px[16];
-#pragma unroll
-      for (int k = 0; k < 16; k++) px[k] = p[k - 8];
-      lf_filter(px, len, lf_limits(lvl, L.sharpness), L.bd);
-      // write only what this length can modify: a neighbouring edge 4 samples away owns the rest
-      const int m = len == 14 ? 6 : len == 8 ? 3 : 2;
-#pragma unroll
-      for (int k = 2; k < 14; k++) if (k >= 8 - m && k < 8 + m) p[k - 8] = (uint16_t)px[k];
+      // (lf_line writes only what its length can modify: a neighbouring edge 4 samples away owns the rest)
+      lf_line_any(tile + ly * LS + 4 * uc, 1, len, lf_limits(lvl, L.sharpness), L.bd);
     }
   }
   __syncthreads();
@@ -197,14 +215,7 @@ __global__ __launch_bounds__(256) void k_deblock(DeblockLaunch L) {
       int lvl = 0;
       const int len = lf_edge(mis[ur * MW + (lx >> 2)], mis[(ur - 1) * MW + (lx >> 2)], 1, fy, L.is_chroma, lvl);
       if (!len) continue;
-      uint16_t *p = tile + (4 * ur) * LS + lx;
-      int px[16];
-#pragma unroll
-      for (int k = 0; k < 16; k++) px[k] = p[(k - 8) * LS];
-      lf_filter(px, len, lf_limits(lvl, L.sharpness), L.bd);
-      const int m = len == 14 ? 6 : len == 8 ? 3 : 2;
-#pragma unroll
-      for (int k = 2; k < 14; k++) if (k >= 8 - m && k < 8 + m) p[(k - 8) * LS] = (uint16_t)px[k];
+      lf_line_any(tile + (4 * ur) * LS + lx, LS, len, lf_limits(lvl, L.sharpness), L.bd);
     }
   }
   __syncthreads();
@@ -214,14 +225,11 @@ __global__ __launch_bounds__(256) void k_deblock(DeblockLaunch L) {
     const int wy = i / (TW / 4), wx = (i % (TW / 4)) * 4;
     const int fy = Y0 + HALO + wy, fx = X0 + HALO + wx;
     if (fy >= L.h || fx >= L.w) continue;   // w, h are multiples of 4
-    const uint16_t *s = tile + (HALO + wy) * LS + HALO + wx;
+    const uint32_t *s32 = reinterpret_cast<const uint32_t *>(tile + (HALO + wy) * LS + HALO + wx);
+    const uint32_t lo = s32[0], hi = s32[1];
     Pix *o = dst + (size_t)fy * L.dst_stride + fx;
-    if constexpr (sizeof(Pix) == 1)
-      *reinterpret_cast<uint32_t *>(o) = (uint32_t)s[0] | ((uint32_t)s[1] << 8) | ((uint32_t)s[2] << 16) | ((uint32_t)s[3] << 24);
-    else {
-      uint2 u; u.x = (uint32_t)s[0] | ((uint32_t)s[1] << 16); u.y = (uint32_t)s[2] | ((uint32_t)s[3] << 16);
-      *reinterpret_cast<uint2 *>(o) = u;
-    }
+    if constexpr (sizeof(Pix) == 1) *reinterpret_cast<uint32_t *>(o) = __builtin_amdgcn_perm(hi, lo, 0x06040200u);
+    else *reinterpret_cast<uint2 *>(o) = make_uint2(lo, hi);
   }
 }
 
