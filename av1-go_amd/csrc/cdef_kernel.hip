@@ -110,29 +110,60 @@ __global__ __launch_bounds__(256) void k_cdef(CdefLaunch L) {
   const bool interior = sbx > 0 && sby > 0 && sbx * 64 + 66 <= L.w && sby * 64 + 66 <= L.h;
   // stage luma 68x68 and chroma 36x36 x2 (local (0,0) = picture (sb*64-2, sb*64-2))
   if (interior) {
-    // no bounds to check: 4-sample aligned loads starting 4 samples left of the block (18 per row), the tile keeps only
-    // the 2-sample halo, so local column = aligned column - 2
-    for (int i = tid; i < 68 * 18; i += 256) {
-      const int r = i / 18, g = i - r * 18;
-      const Pix *q = sy + (size_t)(sby * 64 - 2 + r) * L.stride_y + sbx * 64 - 4 + g * 4;
-      // the four samples as two uint16 pairs = two dword stores: samples 0,1 go to tile columns 4g - 2, 4g - 1 and samples
-      // 2,3 to 4g, 4g + 1 (even columns, even row stride: dword aligned); the first pair of a row and the last lie outside
-      uint32_t lo, hi;
-      if constexpr (sizeof(Pix) == 1) { const uint32_t u = *reinterpret_cast<const uint32_t *>(q); lo = __builtin_amdgcn_perm(0u, u, 0x0c010c00u); hi = __builtin_amdgcn_perm(0u, u, 0x0c030c02u); }
-      else { const uint2 u = *reinterpret_cast<const uint2 *>(q); lo = u.x; hi = u.y; }
-      uint32_t *d = reinterpret_cast<uint32_t *>(ty + r * YS + g * 4 - 2);
-      if (g > 0) d[0] = lo;
-      if (g < 17) d[1] = hi;
+    // no bounds to check: 4-sample aligned loads starting 4 samples left of the block (18 per row luma, 10 chroma); the tile
+    // keeps only the 2-sample halo, so local column = aligned column - 2.  The four samples are two uint16 pairs = two dword
+    // stores: samples 0,1 go to tile columns 4g - 2, 4g - 1 and samples 2,3 to 4g, 4g + 1 (even columns, even row stride);
+    // the first pair of a row and the last lie outside.  All of a lane's loads (5 luma + 3 chroma items) are issued before
+    // its first LDS store, so their latencies overlap instead of adding up.
+    constexpr int NY = 68 * 18, NC = 2 * 36 * 10, KY = (NY + 255) / 256, KC = (NC + 255) / 256;
+    uint2 vy[KY], vc[KC];
+#pragma unroll
+    for (int k = 0; k < KY; k++) {
+      const int i = tid + 256 * k;
+      if (i < NY) {
+        const int r = i / 18, g = i - r * 18;
+        const Pix *q = sy + (size_t)(sby * 64 - 2 + r) * L.stride_y + sbx * 64 - 4 + g * 4;
+        if constexpr (sizeof(Pix) == 1) vy[k].x = *reinterpret_cast<const uint32_t *>(q);
+        else vy[k] = *reinterpret_cast<const uint2 *>(q);
+      }
     }
-    for (int i = tid; i < 2 * 36 * 10; i += 256) {
-      const int pl = i / 360, j = i - pl * 360, r = j / 10, g = j - r * 10;
-      const Pix *q = reinterpret_cast<const Pix *>(L.src[1 + pl]) + (size_t)f * chh * L.stride_uv + (size_t)(sby * 32 - 2 + r) * L.stride_uv + sbx * 32 - 4 + g * 4;
-      uint32_t lo, hi;
-      if constexpr (sizeof(Pix) == 1) { const uint32_t u = *reinterpret_cast<const uint32_t *>(q); lo = __builtin_amdgcn_perm(0u, u, 0x0c010c00u); hi = __builtin_amdgcn_perm(0u, u, 0x0c030c02u); }
-      else { const uint2 u = *reinterpret_cast<const uint2 *>(q); lo = u.x; hi = u.y; }
-      uint32_t *d = reinterpret_cast<uint32_t *>(tc[pl] + r * CSZ + g * 4 - 2);
-      if (g > 0) d[0] = lo;
-      if (g < 9) d[1] = hi;
+#pragma unroll
+    for (int k = 0; k < KC; k++) {
+      const int i = tid + 256 * k;
+      if (i < NC) {
+        const int pl = i / 360, j = i - pl * 360, r = j / 10, g = j - r * 10;
+        const Pix *q = reinterpret_cast<const Pix *>(L.src[1 + pl]) + (size_t)f * chh * L.stride_uv + (size_t)(sby * 32 - 2 + r) * L.stride_uv + sbx * 32 - 4 + g * 4;
+        if constexpr (sizeof(Pix) == 1) vc[k].x = *reinterpret_cast<const uint32_t *>(q);
+        else vc[k] = *reinterpret_cast<const uint2 *>(q);
+      }
+    }
+    auto pairs = [](uint2 v, uint32_t &lo, uint32_t &hi) {
+      if constexpr (sizeof(Pix) == 1) { lo = __builtin_amdgcn_perm(0u, v.x, 0x0c010c00u); hi = __builtin_amdgcn_perm(0u, v.x, 0x0c030c02u); }
+      else { lo = v.x; hi = v.y; }
+    };
+#pragma unroll
+    for (int k = 0; k < KY; k++) {
+      const int i = tid + 256 * k;
+      if (i < NY) {
+        const int r = i / 18, g = i - r * 18;
+        uint32_t lo, hi;
+        pairs(vy[k], lo, hi);
+        uint32_t *d = reinterpret_cast<uint32_t *>(ty + r * YS + g * 4 - 2);
+        if (g > 0) d[0] = lo;
+        if (g < 17) d[1] = hi;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < KC; k++) {
+      const int i = tid + 256 * k;
+      if (i < NC) {
+        const int pl = i / 360, j = i - pl * 360, r = j / 10, g = j - r * 10;
+        uint32_t lo, hi;
+        pairs(vc[k], lo, hi);
+        uint32_t *d = reinterpret_cast<uint32_t *>(tc[pl] + r * CSZ + g * 4 - 2);
+        if (g > 0) d[0] = lo;
+        if (g < 9) d[1] = hi;
+      }
     }
   } else {
     for (int i = tid; i < 68 * 68; i += 256) {

@@ -164,25 +164,43 @@ __global__ __launch_bounds__(256) void k_deblock(DeblockLaunch L) {
     if (ur >= 0 && ur < rows && uc >= 0 && uc < cols) v = mi[(size_t)ur * L.mi_stride + uc];
     mis[i] = v;
   }
-  // samples, coordinates clamped into the plane, 4 per lane per step
-  for (int i = tid; i < LH * (LW / 4); i += 256) {
-    const int ly = i / (LW / 4), lx = (i % (LW / 4)) * 4;
-    const int fy = min(max(Y0 + ly, 0), L.h - 1), fx = X0 + lx;
-    const Pix *row = src + (size_t)fy * L.src_stride;
-    uint16_t *d = tile + ly * LS + lx;
-    if (fx >= 0 && fx + 3 < L.w) {
-      // four samples = two uint16 pairs = two dword stores (rows are an even number of samples, lx a multiple of 4)
-      uint32_t *d32 = reinterpret_cast<uint32_t *>(d);
-      if constexpr (sizeof(Pix) == 1) {
-        const uint32_t u = *reinterpret_cast<const uint32_t *>(row + fx);
-        d32[0] = __builtin_amdgcn_perm(0u, u, 0x0c010c00u); d32[1] = __builtin_amdgcn_perm(0u, u, 0x0c030c02u);
-      } else {
-        const uint2 u = *reinterpret_cast<const uint2 *>(row + fx);
-        d32[0] = u.x; d32[1] = u.y;
-      }
-    } else {
+  // samples, coordinates clamped into the plane, 4 per lane per item: all of a lane's loads first, then its LDS stores (as one
+  // loop every load was waited for before the next one was issued)
+  {
+    constexpr int NITEMS = LH * (LW / 4), NIT = (NITEMS + 255) / 256;
+    uint2 v[NIT];
+    unsigned done = 0;          // bit k: item k is already in uint16-pair form (border items, assembled sample by sample)
 #pragma unroll
-      for (int k = 0; k < 4; k++) d[k] = row[min(max(fx + k, 0), L.w - 1)];
+    for (int k = 0; k < NIT; k++) {
+      const int i = tid + 256 * k;
+      if (i < NITEMS) {
+        const int ly = i / (LW / 4), lx = (i % (LW / 4)) * 4;
+        const int fy = min(max(Y0 + ly, 0), L.h - 1), fx = X0 + lx;
+        const Pix *row = src + (size_t)fy * L.src_stride;
+        if (fx >= 0 && fx + 3 < L.w) {
+          if constexpr (sizeof(Pix) == 1) v[k].x = *reinterpret_cast<const uint32_t *>(row + fx);
+          else v[k] = *reinterpret_cast<const uint2 *>(row + fx);
+        } else {
+          int q[4];
+#pragma unroll
+          for (int c = 0; c < 4; c++) q[c] = row[min(max(fx + c, 0), L.w - 1)];
+          v[k].x = (uint32_t)q[0] | ((uint32_t)q[1] << 16); v[k].y = (uint32_t)q[2] | ((uint32_t)q[3] << 16);
+          done |= 1u << k;
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NIT; k++) {
+      const int i = tid + 256 * k;
+      if (i < NITEMS) {
+        const int ly = i / (LW / 4), lx = (i % (LW / 4)) * 4;
+        // four samples = two uint16 pairs = two dword stores (rows are an even number of samples, lx a multiple of 4)
+        uint32_t *d32 = reinterpret_cast<uint32_t *>(tile + ly * LS + lx);
+        uint2 w = v[k];
+        if constexpr (sizeof(Pix) == 1)
+          if (!((done >> k) & 1)) { const uint32_t u = v[k].x; w.x = __builtin_amdgcn_perm(0u, u, 0x0c010c00u); w.y = __builtin_amdgcn_perm(0u, u, 0x0c030c02u); }
+        d32[0] = w.x; d32[1] = w.y;
+      }
     }
   }
   __syncthreads();

@@ -63,22 +63,40 @@ __global__ __launch_bounds__(256) void k_lr(LrLaunch L) {
     // full-width bands (every band of a picture whose width is a multiple of 64) get compile-time divisors: an integer
     // division by a runtime value is ~25 VALU instructions, and this kernel is VALU-bound
     const bool full = bw == MAXW;
-    const int ng = (bw + 8) / 4;
-    for (int i = tid; i < (bh + 6) * ng; i += 256) {
-      const int r = full ? i / ((MAXW + 8) / 4) : i / ng, g = i - r * ng;
-      int y = min(max(y0 - 3 + r, 0), L.h - 1);
-      const Pix *p = cdef;
-      if (y < sstart) { y = max(sstart - 2, y); p = dbl; }
-      else if (y > send) { y = min(send + 2, y); p = dbl; }
-      const Pix *q = p + (size_t)y * L.stride + X0 - 4 + 4 * g;
-      uint2 o;
-      if (((uintptr_t)q & (4 * sizeof(Pix) - 1)) == 0) {
-        if constexpr (sizeof(Pix) == 1) {
-          const uint32_t u = *reinterpret_cast<const uint32_t *>(q);
-          o.x = (u & 255) | ((u & 0xff00) << 8); o.y = ((u >> 16) & 255) | ((u >> 8) & 0xff0000);
-        } else o = *reinterpret_cast<const uint2 *>(q);
-      } else { o.x = (uint32_t)q[0] | ((uint32_t)q[1] << 16); o.y = (uint32_t)q[2] | ((uint32_t)q[3] << 16); }
-      *reinterpret_cast<uint2 *>(src + r * SS + 4 * g) = o;
+    const int ng = (bw + 8) / 4, nitems = (bh + 6) * ng;
+    // All of a lane's loads first, then all of its LDS stores: at most 70 x 18 items = 5 per lane.  As one loop every load was
+    // waited for before the next was issued, and the kernel spent most of its time in those waits (waves stalled 64 % of
+    // their cycles by PMC).
+    constexpr int NIT = ((MAXH + 6) * ((MAXW + 8) / 4) + 255) / 256;
+    uint2 o[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; k++) {
+      const int i = tid + 256 * k;
+      if (i < nitems) {
+        const int r = full ? i / ((MAXW + 8) / 4) : i / ng, g = i - r * ng;
+        int y = min(max(y0 - 3 + r, 0), L.h - 1);
+        const Pix *p = cdef;
+        if (y < sstart) { y = max(sstart - 2, y); p = dbl; }
+        else if (y > send) { y = min(send + 2, y); p = dbl; }
+        const Pix *q = p + (size_t)y * L.stride + X0 - 4 + 4 * g;
+        if (((uintptr_t)q & (4 * sizeof(Pix) - 1)) == 0) {
+          if constexpr (sizeof(Pix) == 1) o[k].x = *reinterpret_cast<const uint32_t *>(q);
+          else o[k] = *reinterpret_cast<const uint2 *>(q);
+        } else {
+          if constexpr (sizeof(Pix) == 1) o[k].x = (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24);
+          else { o[k].x = (uint32_t)q[0] | ((uint32_t)q[1] << 16); o[k].y = (uint32_t)q[2] | ((uint32_t)q[3] << 16); }
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NIT; k++) {
+      const int i = tid + 256 * k;
+      if (i < nitems) {
+        const int r = full ? i / ((MAXW + 8) / 4) : i / ng, g = i - r * ng;
+        uint2 w = o[k];
+        if constexpr (sizeof(Pix) == 1) { const uint32_t u = o[k].x; w.x = __builtin_amdgcn_perm(0u, u, 0x0c010c00u); w.y = __builtin_amdgcn_perm(0u, u, 0x0c030c02u); }
+        *reinterpret_cast<uint2 *>(src + r * SS + 4 * g) = w;
+      }
     }
   } else {
     for (int i = tid; i < (bh + 6) * (bw + 6); i += 256) {
