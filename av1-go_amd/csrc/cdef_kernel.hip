@@ -96,6 +96,7 @@ __global__ __launch_bounds__(256) void k_cdef(CdefLaunch L) {
   __shared__ __attribute__((aligned(16))) uint16_t ty[(64 + 4) * YS + 8];
   __shared__ __attribute__((aligned(16))) uint16_t tc[2][(32 + 4) * CSZ + 8];
   __shared__ uint8_t bdir[64];
+  __shared__ uint8_t bskip[64];   // skip flag of each 8x8 block of the superblock (1 also for blocks outside the picture)
   __shared__ int bvar[64];
   __shared__ __attribute__((aligned(16))) int16_t offy[64], offc[64];   // tap offsets per direction for the two tile strides
   const int tid = threadIdx.x;
@@ -106,6 +107,12 @@ __global__ __launch_bounds__(256) void k_cdef(CdefLaunch L) {
   const Pix *sy = reinterpret_cast<const Pix *>(L.src[0]) + (size_t)f * L.h * L.stride_y;
   Pix *dy = reinterpret_cast<Pix *>(L.dst[0]) + (size_t)f * L.h * L.stride_y;
   const int cw = L.w / 2, chh = L.h / 2;
+  // the 64 skip flags once, next to the tiles: the filter loops read one per quad, and as a global load each of those sat
+  // in front of a branch with its whole latency exposed
+  if (tid >= 192) {
+    const int b = tid - 192, fy8 = sby * 8 + (b >> 3), fx8 = sbx * 8 + (b & 7);
+    bskip[b] = (fy8 < (L.h >> 3) && fx8 < (L.w >> 3)) ? L.skip8[(size_t)f * L.skip_frame_stride + (size_t)fy8 * (L.w >> 3) + fx8] : (uint8_t)1;
+  }
   // every tap of this superblock inside the picture?  (then the tile holds no 0xFFFF mark: vector staging, no mark handling)
   const bool interior = sbx > 0 && sby > 0 && sbx * 64 + 66 <= L.w && sby * 64 + 66 <= L.h;
   // stage luma 68x68 and chroma 36x36 x2 (local (0,0) = picture (sb*64-2, sb*64-2))
@@ -234,13 +241,12 @@ __global__ __launch_bounds__(256) void k_cdef(CdefLaunch L) {
   // filter: luma 64x64 -> 16 samples per lane (4 rows x 4 columns), chroma 2 x 32x32 -> 2 x 4 samples per lane
   const int ypri0 = st[0] << cs, ysec = (st[1] == 3 ? 4 : st[1]) << cs;
   const int upri = st[2] << cs, usec = (st[3] == 3 ? 4 : st[3]) << cs;
-  const uint8_t *skip8 = L.skip8 + (size_t)f * L.skip_frame_stride;
   for (int q = tid; q < 64 * 16; q += 256) {         // q -> (row, group of 4 columns)
     const int r = q >> 4, c = (q & 15) * 4;
     const int fy = sby * 64 + r, fx = sbx * 64 + c;
     if (fy >= L.h || fx >= L.w) continue;
     const int b = (r >> 3) * 8 + (c >> 3);
-    const bool skip = !enabled || skip8[(size_t)(fy >> 3) * (L.w >> 3) + (fx >> 3)];
+    const bool skip = !enabled || bskip[b];
     const uint16_t *p = ty + (2 + r) * YS + 2 + c;
     int o[4];
     if (skip) { o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; o[3] = p[3]; }
@@ -263,7 +269,7 @@ __global__ __launch_bounds__(256) void k_cdef(CdefLaunch L) {
     const int fy = sby * 32 + r, fx = sbx * 32 + c;
     if (fy >= chh || fx >= cw) continue;
     const int b = (r >> 2) * 8 + (c >> 2);
-    const bool skip = !enabled || skip8[(size_t)(fy >> 2) * (L.w >> 3) + (fx >> 2)];
+    const bool skip = !enabled || bskip[b];
     const uint16_t *p = tc[pl] + (2 + r) * CSZ + 2 + c;
     int o[4];
     if (skip) { o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; o[3] = p[3]; }
