@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void k_me_int(InterLaunch L) {
   __shared__ uint32_t s_best[64];                    // per 8x8 block: min of (SAD, rank)
   constexpr int sh = sizeof(Pix) == 1 ? 0 : 2;
   const int tid = threadIdx.x, R = L.range, R4 = (R + 3) & ~3, NC = 2 * R + 1;
-  const int WDX = 64 + 2 * R4 + 4, WDY = 64 + 2 * R + 1;    // window columns start at x - R4 (4-aligned), rows at y - R; one more row for the unused half of the last dy pair
+  const int WDX = 64 + 2 * R4 + 4, WDY = 64 + 2 * R + 2;    // window columns start at x - R4 (4-aligned), rows at y - R; two more rows for the unused part of the last dy triple
   const int sbw = (L.w + 63) / 64;
   const Tile3 tl = xcd_tile(sbw, (L.h + 63) / 64, L.nframes);
   const int f = tl.z, sby = tl.y, sbx = tl.x;
@@ -94,13 +94,16 @@ __global__ __launch_bounds__(256) void k_me_int(InterLaunch L) {
   const int wave = tid >> 6, lane = tid & 63;
   const int bw = L.w / 8, bh = L.h / 8;
   const int NG = (2 * R4) / 4 + 1;                 // groups of four dx starting at -R4
-  const int NP = (NC + 1) >> 1;                    // pairs of vertical displacements (the last pair may hold one)
-  const int per = NP * NG;                         // (dy pair, dx group) items per block
+  constexpr int HD = 3;                            // vertical displacements per item
+  const int NP = (NC + HD - 1) / HD;               // triples of vertical displacements (the last one may hold fewer)
+  const int per = NP * NG;                         // (dy triple, dx group) items per block
   int16_t *mvs = L.mvs + (size_t)f * bw * bh * 2;
-  // A lane scores TWO vertically adjacent displacements of four horizontal ones: they share seven of their eight window
-  // rows, so nine rows of three dwords are read for 32 QSADs instead of sixteen.  The 16 blocks of a wave form ONE item
-  // space (16 x per): with +-8 a block has 45 items, which alone would leave a 64-lane wave a third empty; the per-block
-  // minimum is an LDS atomic instead of a wave reduction.
+  // A lane scores THREE vertically adjacent displacements of four horizontal ones: they share six of their eight window
+  // rows, so ten rows of three dwords and ONE copy of the source block are read for 48 QSADs (pairs: nine rows and a source
+  // copy per 32; the QSADs are half of the kernel's cycles, the reads and the per-item arithmetic the other half, and +-8 is
+  // 17 = 6 x 3 - 1 rows: as little padding as pairs).  The 16 blocks of a wave form ONE item space (16 x per): with +-8 a
+  // block has 30 items, which alone would leave a 64-lane wave half empty; the per-block minimum is an LDS atomic instead of a
+  // wave reduction.
   // item -> (block, dy pair, dx group) by reciprocal multiplication: u < 16 x 144 and (u + 0.5) / per is never closer than
   // 0.5 / per to an integer, far outside float rounding, so the truncation is the exact quotient (an integer division by a
   // run-time divisor is ~25 instructions, and there are two per item)
@@ -111,38 +114,48 @@ __global__ __launch_bounds__(256) void k_me_int(InterLaunch L) {
       const int bi = (int)(((float)u + 0.5f) * inv_per), t = u - bi * per, b = wave + 4 * bi;
       const int by = b >> 3, bx = b & 7;
       if (sbx * 8 + bx < bw && sby * 8 + by < bh) {
-        const int dp = (int)(((float)t + 0.5f) * inv_ng), g = t - dp * NG;    // dy = 2 dp - R and 2 dp + 1 - R, dx0 = -R4 + 4 g
-        const uint8_t *p = win + (by * 8 + 2 * dp) * WS + bx * 8 + 4 * g;
+        const int dp = (int)(((float)t + 0.5f) * inv_ng), g = t - dp * NG;    // dy = 3 dp - R + {0, 1, 2}, dx0 = -R4 + 4 g
+        const uint8_t *p = win + (by * 8 + HD * dp) * WS + bx * 8 + 4 * g;
         const uint8_t *s = srct + (by * 8) * 64 + bx * 8;
         uint2 sr[8];
 #pragma unroll
         for (int r = 0; r < 8; r++) sr[r] = *reinterpret_cast<const uint2 *>(s + r * 64);
-        unsigned long long acc0 = 0, acc1 = 0;
+        unsigned long long acc[HD] = { 0, 0, 0 };
 #pragma unroll
-        for (int r = 0; r < 9; r++) {
-          const uint32_t *q = reinterpret_cast<const uint32_t *>(p + r * WS);   // row 2 dp + r <= 2 R + 8: inside the window
+        for (int r = 0; r < 8 + HD - 1; r++) {
+          const uint32_t *q = reinterpret_cast<const uint32_t *>(p + r * WS);   // row 3 dp + r <= 2 R + 11: inside the staged window
           const unsigned long long w01 = (unsigned long long)q[0] | ((unsigned long long)q[1] << 32);
           const unsigned long long w12 = (unsigned long long)q[1] | ((unsigned long long)q[2] << 32);
-          if (r < 8) { acc0 = __builtin_amdgcn_qsad_pk_u16_u8(w01, sr[r].x, acc0); acc0 = __builtin_amdgcn_qsad_pk_u16_u8(w12, sr[r].y, acc0); }
-          if (r > 0) { acc1 = __builtin_amdgcn_qsad_pk_u16_u8(w01, sr[r - 1].x, acc1); acc1 = __builtin_amdgcn_qsad_pk_u16_u8(w12, sr[r - 1].y, acc1); }
+#pragma unroll
+          for (int h = 0; h < HD; h++)
+            if (r - h >= 0 && r - h < 8) {
+              acc[h] = __builtin_amdgcn_qsad_pk_u16_u8(w01, sr[r - h].x, acc[h]);
+              acc[h] = __builtin_amdgcn_qsad_pk_u16_u8(w12, sr[r - h].y, acc[h]);
+            }
         }
         // key = SAD << 10 | rank: (0,0) ranks first (0), the others in raster order (1 + (dy + R) NC + dx + R < 1024); ties keep
         // the lower rank.  Branch-free: a displacement outside +-R gets rank ~0, which turns its key into ~0 under the OR.
-        // dx_i = 4 g - R4 + i is in range for i in [imin, imax]; the second row of the pair exists when 2 dp + 1 < NC.
+        // dx_i = 4 g - R4 + i is in range for i in [imin, imax]; row h of the triple exists when 3 dp + h < NC.
         const int imin = R4 - R - 4 * g, imax = R4 + R - 4 * g;
-        const unsigned rank0 = (unsigned)(2 * dp * NC + 4 * g - R4 + R + 1);
-        const unsigned inv_h1 = (unsigned)((NC - 2 - 2 * dp) >> 31);
+        const unsigned rank0 = (unsigned)(HD * dp * NC + 4 * g - R4 + R + 1);
+        unsigned inv_h[HD];
+#pragma unroll
+        for (int h = 0; h < HD; h++) inv_h[h] = (unsigned)((NC - 1 - h - HD * dp) >> 31);
         unsigned best = 0xFFFFFFFFu;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
           const unsigned inv = (unsigned)(((i - imin) | (imax - i)) >> 31);
-          const unsigned s0 = (unsigned)(acc0 >> (16 * i)) & 0xFFFFu, s1 = (unsigned)(acc1 >> (16 * i)) & 0xFFFFu;
-          best = min(best, min((s0 << 10) | (rank0 + i) | inv, (s1 << 10) | (rank0 + NC + i) | inv | inv_h1));
+#pragma unroll
+          for (int h = 0; h < HD; h++) {
+            const unsigned sd = (unsigned)(acc[h] >> (16 * i)) & 0xFFFFu;
+            best = min(best, (sd << 10) | (rank0 + h * NC + i) | inv | inv_h[h]);
+          }
         }
-        // the zero vector: dy index R = row R & 1 of pair R >> 1, dx index R4 = sample 0 of group R4 >> 2
+        // the zero vector: dy index R = row R % 3 of triple R / 3, dx index R4 = sample 0 of group R4 >> 2
         {
-          const unsigned sz = (unsigned)((R & 1) ? acc1 : acc0) & 0xFFFFu;
-          const unsigned not_zero_item = (dp == (R >> 1) && g == (R4 >> 2)) ? 0u : 0xFFFFFFFFu;
+          const int hz = R % HD;
+          const unsigned sz = (unsigned)(hz == 0 ? acc[0] : hz == 1 ? acc[1] : acc[2]) & 0xFFFFu;
+          const unsigned not_zero_item = (dp == R / HD && g == (R4 >> 2)) ? 0u : 0xFFFFFFFFu;
           best = min(best, (sz << 10) | not_zero_item);
         }
         atomicMin(&s_best[b], best);
