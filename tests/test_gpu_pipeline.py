@@ -51,25 +51,29 @@ def test_4k_10bit_full_chain_one_frame(ctx, O):
     pipe.close()
 
 
-def test_closed_gop_chain_matches_oracle(ctx, O):
-    """BASELINE config 3 end to end: 2 segments x (1 key + 3 P frames); every P frame predicts from the loop-filtered
+@pytest.mark.parametrize("w,h,bd,q,segs,gop,rng_", [
+    (192, 128, 8, 90, 2, 4, 6),          # small: 2 segments x (1 key + 3 P)
+    (1920, 1080, 8, 128, 1, 3, 8),       # BASELINE configs[2] size: 1080p 8-bit, key + 2 P
+    (3840, 2160, 10, 128, 1, 2, 8),      # BASELINE configs[3] size = the bench's default workload: 4K 10-bit, key + P
+])
+def test_closed_gop_chain_matches_oracle(ctx, O, w, h, bd, q, segs, gop, rng_):
+    """BASELINE configs 2/3 end to end: closed GOPs (1 key + P frames); every P frame predicts from the loop-filtered
     previous frame.  Reconstruction after the whole filter chain equals the oracle chain for every frame."""
     import pipeline
-    w, h, bd, q = 192, 128, 8, 90
-    gp = pipeline.GopPipeline(ctx, w, h, bd, segments=2, gop=4, qindex=q, first_frame=1, search_range=6)
+    gp = pipeline.GopPipeline(ctx, w, h, bd, segments=segs, gop=gop, qindex=q, first_frame=1, search_range=rng_)
     got = []
     dl = lambda bufs, shapes: [b.download(s.shape, s.dtype) for b, s in zip(bufs, shapes)]
     gp.step(on_frame=lambda t: got.append(dl(gp.d_ref, gp.src[t])))
     k = gp.key
-    for s in range(2):
+    for s in range(segs):
         ref = None
-        for t in range(4):
+        for t in range(gop):
             src = [gp.src[t][i][s] for i in range(3)]
             if t == 0:
                 r = O.intra_encode_frame(src[0], src[1], src[2], bd, 8, q)
                 skip8 = np.zeros((h // 8, w // 8), np.uint8)
             else:
-                r = O.inter_encode_frame(src, ref, bd, q, 6)
+                r = O.inter_encode_frame(src, ref, bd, q, rng_)
                 skip8 = r["skip"].reshape(h // 8, w // 8)
             dbl = [O.deblock_plane(r["rec_y"], bd, 0, k.mi_y), O.deblock_plane(r["rec_u"], bd, 1, k.mi_c), O.deblock_plane(r["rec_v"], bd, 1, k.mi_c)]
             cdef = O.cdef_frame(dbl[0], dbl[1], dbl[2], bd, k.cdef_damping, k.cdef_sb, skip8)
