@@ -18,7 +18,8 @@ __device__ __forceinline__ unsigned xcd_swizzle(unsigned bid, unsigned nwg) {
 // raster tile index -> (x, y, z) of a gx x gy x gz grid
 struct Tile3 { int x, y, z; };
 __device__ __forceinline__ Tile3 xcd_tile(unsigned gx, unsigned gy, unsigned gz) {
-  const unsigned t = xcd_swizzle(blockIdx.x, gx * gy * gz);
+  (void)gz;   // the launch's 1-D grid is exactly gx * gy * gz workgroups (every launch_* computes it from the same expressions)
+  const unsigned t = xcd_swizzle(blockIdx.x, gridDim.x);
   const unsigned z = t / (gx * gy), rem = t - z * gx * gy, y = rem / gx;
   return { (int)(rem - y * gx), (int)y, (int)z };
 }
