@@ -179,6 +179,9 @@ class Context:
     def memset(self, d_buf, value, nbytes):
         self._chk(self.lib.av1mi_memset(self.h, C.c_void_p(d_buf.ptr), int(value), C.c_size_t(nbytes)))
 
+    def copy(self, d_dst, d_src, nbytes):
+        self._chk(self.lib.av1mi_copy(self.h, C.c_void_p(d_dst.ptr), C.c_void_p(d_src.ptr), C.c_size_t(nbytes)))
+
     def timer_begin(self):
         self._chk(self.lib.av1mi_timer_begin(self.h))
 

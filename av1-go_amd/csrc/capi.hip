@@ -197,6 +197,12 @@ int av1mi_memset(av1mi_ctx *ctx, void *d_dst, int value, size_t bytes) {
   HIP_TRY(ctx, hipMemsetAsync(d_dst, value, bytes, ctx->stream));
   return AV1MI_OK;
 }
+int av1mi_copy(av1mi_ctx *ctx, void *d_dst, const void *d_src, size_t bytes) {
+  BIND(ctx);
+  if (!d_dst || !d_src) return fail(ctx, AV1MI_E_INVAL, "null device pointer");
+  HIP_TRY(ctx, hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  return AV1MI_OK;
+}
 int av1mi_sync(av1mi_ctx *ctx) {
   BIND(ctx);
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

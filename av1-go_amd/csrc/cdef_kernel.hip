@@ -107,6 +107,10 @@ __global__ __launch_bounds__(256) void k_cdef(CdefLaunch L) {
   const Pix *sy = reinterpret_cast<const Pix *>(L.src[0]) + (size_t)f * L.h * L.stride_y;
   Pix *dy = reinterpret_cast<Pix *>(L.dst[0]) + (size_t)f * L.h * L.stride_y;
   const int cw = L.w / 2, chh = L.h / 2;
+  // the superblock's strength set, requested before the tile loads so that its latency hides behind them (one aligned dword)
+  const int sbw = (L.w + 63) / 64;
+  const uint32_t st32 = *reinterpret_cast<const uint32_t *>(L.sb_strength + ((size_t)f * L.sb_frame_stride + (size_t)sby * sbw + sbx) * 4);
+  const int st[4] = { (int)(st32 & 255), (int)((st32 >> 8) & 255), (int)((st32 >> 16) & 255), (int)(st32 >> 24) };
   // the 64 skip flags once, next to the tiles: the filter loops read one per quad, and as a global load each of those sat
   // in front of a branch with its whole latency exposed
   if (tid >= 192) {
@@ -186,8 +190,6 @@ __global__ __launch_bounds__(256) void k_cdef(CdefLaunch L) {
     }
   }
   __syncthreads();
-  const int sbw = (L.w + 63) / 64;
-  const uint8_t *st = L.sb_strength + ((size_t)f * L.sb_frame_stride + (size_t)sby * sbw + sbx) * 4;
   const bool enabled = st[0] != 255;
   // direction search: lane b of wave 0 owns 8x8 block b (raster within the superblock)
   if (tid < 64 && enabled) {

@@ -47,7 +47,10 @@ __global__ __launch_bounds__(256) void k_lr(LrLaunch L) {
   Pix *out = reinterpret_cast<Pix *>(L.out) + (size_t)f * L.h * L.stride;
   const int urows = max((L.h + (L.unit_size >> 1)) / L.unit_size, 1), ucols = max((L.w + (L.unit_size >> 1)) / L.unit_size, 1);
   const int ur = min(urows - 1, (y0 + off) / L.unit_size), uc = min(ucols - 1, X0 / L.unit_size);
-  const int8_t *U = L.units + ((size_t)f * L.unit_frame_stride + (size_t)ur * ucols + uc) * 8;
+  // the unit's 8 parameter bytes as one load, up front (they were re-read from memory after the staging barrier)
+  const uint2 U8 = *reinterpret_cast<const uint2 *>(L.units + ((size_t)f * L.unit_frame_stride + (size_t)ur * ucols + uc) * 8);
+  const int U[8] = { (int8_t)(U8.x & 255), (int8_t)((U8.x >> 8) & 255), (int8_t)((U8.x >> 16) & 255), (int8_t)(U8.x >> 24),
+                     (int8_t)(U8.y & 255), (int8_t)((U8.y >> 8) & 255), (int8_t)((U8.y >> 16) & 255), (int8_t)(U8.y >> 24) };
   const int type = U[0];
 
   if (type == 0) {   // no restoration: copy the CDEF output

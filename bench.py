@@ -120,6 +120,22 @@ def cpu_baseline_gop(pipe, p_frames=2):
                       % (cores, p_frames, wall, t_key, t_p, gop, gop - 1)}
 
 
+def copy_bandwidth(ctx, nbytes=1 << 30, reps=10):
+    """device-to-device copy rate measured on this box (report against the 8 TB/s spec AND a measured copy):
+    GB/s moved = 2 x bytes (read + written) / time, HIP events on the context's stream"""
+    a, b = ctx.alloc(nbytes), ctx.alloc(nbytes)
+    ctx.memset(a, 1, nbytes)
+    ctx.copy(b, a, nbytes)
+    ctx.sync()
+    ctx.timer_begin()
+    for _ in range(reps):
+        ctx.copy(b, a, nbytes)
+    ms = ctx.timer_end()
+    a.free()
+    b.free()
+    return 2.0 * nbytes * reps / (ms * 1e-3) / 1e9
+
+
 def quality(pipe, bd):
     """PSNR-Y of the loop-filtered reconstruction against the source, on the frames the last step left in HBM (the metric's
     second half, "PSNR-Y delta vs libaom", needs libaom on the box: absent here, so only the absolute value is reported)"""
@@ -325,6 +341,15 @@ def main():
         out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                            "frac": ach / HBM_PEAK_GBPS, "traffic": pmc_traffic(dom, args.workload, pipe.segments if args.workload.endswith("-gop") else frames), "algorithmic_bytes_per_launch": alg[dom],
                            "avg_launch_ms": ms / n, "launches": n}
+        copy_gbps = copy_bandwidth(ctx)
+        out["roofline"]["copy_GBps_measured"] = copy_gbps
+        out["roofline"]["frac_of_measured_copy"] = ach / copy_gbps
+        # whole pipeline: (9b + 2) S per inter frame, (8b + 2) S per intra-only frame, times the job's frame rate
+        b_, s_frame = (1 if bd == 8 else 2), W * H * 3 // 2
+        per_frame = ((9 * b_ + 2) if args.workload.endswith("-gop") else (8 * b_ + 2)) * s_frame
+        out["pipeline_roofline"] = {"algorithmic_bytes_per_frame": per_frame, "achieved": per_frame * fps / world / 1e9, "peak": HBM_PEAK_GBPS,
+                                    "unit": "GB/s", "frac": per_frame * fps / world / 1e9 / HBM_PEAK_GBPS,
+                                    "note": "per GPU: whole-job frames/s / n_gpus x the fused-pipeline bytes of BASELINE.md §3"}
         out["kernels"] = {k: {"launches": v[0], "avg_ms": v[1] / v[0],
                               "algorithmic_GBps": alg[k] / (v[1] / v[0] * 1e-3) / 1e9 if k in alg else None} for k, v in prof.items()}
         out["quality"] = quality(pipe, bd)

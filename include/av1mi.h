@@ -69,6 +69,9 @@ int av1mi_free(av1mi_ctx *ctx, void *d_ptr);
 int av1mi_upload(av1mi_ctx *ctx, void *d_dst, const void *src, size_t bytes);
 int av1mi_download(av1mi_ctx *ctx, void *dst, const void *d_src, size_t bytes);
 int av1mi_memset(av1mi_ctx *ctx, void *d_dst, int value, size_t bytes);
+/* device-to-device copy on the context's stream (e.g. handing a reconstructed frame to the next GOP stage; bench.py uses it to
+ * measure the box's copy bandwidth, the second roofline BASELINE.md §3 asks for). */
+int av1mi_copy(av1mi_ctx *ctx, void *d_dst, const void *d_src, size_t bytes);
 int av1mi_sync(av1mi_ctx *ctx);
 /* HIP-event stopwatch on the context's stream: begin .. end brackets whatever was enqueued between. */
 int av1mi_timer_begin(av1mi_ctx *ctx);
