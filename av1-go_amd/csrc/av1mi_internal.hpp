@@ -65,6 +65,7 @@ struct IntraPipeLaunch {
   const void *src[3]; void *rec[3]; int16_t *lev[3];
   uint8_t *modes_y, *modes_uv;
   int w, h, stride_y, stride_uv, bd, nframes, dc_q, ac_q;
+  int dc_quant, ac_quant;   // (1 << 16) / step (libaom quant_fp): computed once by the host, see block_code.hpp
 };
 hipError_t launch_intra_pipe(const IntraPipeLaunch &L, int bs, hipStream_t s);
 
@@ -98,6 +99,7 @@ struct InterLaunch {
   const void *src[3]; const void *ref[3]; void *rec[3]; int16_t *lev[3];
   int16_t *mvs; uint8_t *skip;
   int w, h, stride_y, stride_uv, bd, nframes, dc_q, ac_q, range;
+  int dc_quant, ac_quant;   // (1 << 16) / step (libaom quant_fp): computed once by the host, see block_code.hpp
 };
 hipError_t launch_me_int(const InterLaunch &L, hipStream_t s);
 hipError_t launch_inter_pipe(const InterLaunch &L, hipStream_t s);

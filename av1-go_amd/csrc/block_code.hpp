@@ -40,7 +40,7 @@ template <int N, typename Pix> __device__ __forceinline__ void store_row(Pix *p,
 // s[]: source row, bp[]: prediction row.  Writes this lane's row of levels to lev_row and returns its reconstruction in
 // rec[]; the return value is non-zero when the row holds a non-zero level.
 template <int B, typename Pix>
-__device__ __forceinline__ int code_residual(int32_t *T, int lane, const int *s, const int *bp, int dc_q, int ac_q, int16_t *lev_row,
+__device__ __forceinline__ int code_residual(int32_t *T, int lane, const int *s, const int *bp, int dc_q, int ac_q, int dc_quant, int ac_quant, int16_t *lev_row,
                                              int *rec) {
   constexpr int RS = B + 4, bd = sizeof(Pix) == 1 ? 8 : 10;
   // forward transform (libaom fwd_txfm2d_c: columns, then rows), DCT_DCT
@@ -65,7 +65,10 @@ __device__ __forceinline__ int code_residual(int32_t *T, int lane, const int *s,
   }
   fdct<B, fwd_cos_bit_row(B, B)>(xv);
   // quantise / dequantise this row (libaom quantize_fp; spec 7.12.3), log_scale 0 for B <= 16
-  const int dc_quant = (1 << 16) / dc_q, ac_quant = (1 << 16) / ac_q, dc_rnd = (64 * dc_q) >> 7, ac_rnd = (64 * ac_q) >> 7;
+  // dc_quant / ac_quant = (1 << 16) / step come from the host: written here as a division, the compiler sank the (loop-invariant)
+  // division into the conditional block of every coefficient — ~25 scalar or ~30 vector instructions and a divergent branch, 8
+  // times per row of every block
+  const int dc_rnd = (64 * dc_q) >> 7, ac_rnd = (64 * ac_q) >> 7;
   const int maxv = (1 << (7 + bd)) - 1, minv = -(1 << (7 + bd));
   int lv[B];
 #pragma unroll
@@ -75,8 +78,8 @@ __device__ __forceinline__ int code_residual(int32_t *T, int lane, const int *s,
     const int v = round2(xv[c], -fwd_shift(B, B, 2));
     const bool neg = v < 0;
     int a = min(neg ? -v : v, 1 << 20), l = 0;
-    if ((a << 1) >= q) { a = min(a + rnd, 32767); l = (a * quant) >> 16; }
-    l = min(l, 32767);
+    l = (min(a + rnd, 32767) * quant) >> 16;          // <= 32767 * 16384 >> 16: no overflow, and already <= 32767
+    l = (a << 1) >= q ? l : 0;
     lv[c] = neg ? -l : l;
     const int d = (l * q) & 0xFFFFFF;
     xv[c] = min(max(neg ? -d : d, minv), maxv);

@@ -421,6 +421,7 @@ int av1mi_intra_encode(av1mi_ctx *ctx, const av1mi_intra_job *j) {
   L.modes_y = j->d_modes_y; L.modes_uv = j->d_modes_uv;
   L.w = j->width; L.h = j->height; L.stride_y = j->stride_y; L.stride_uv = j->stride_uv; L.bd = j->bit_depth; L.nframes = j->nframes;
   L.dc_q = av1mi_dc_q(j->qindex, j->bit_depth); L.ac_q = av1mi_ac_q(j->qindex, j->bit_depth);
+  L.dc_quant = (1 << 16) / L.dc_q; L.ac_quant = (1 << 16) / L.ac_q;
   { ProfScope ps(ctx, AV1MI_K_INTRA_PIPE); HIP_TRY(ctx, av1mi::launch_intra_pipe(L, j->block_size, ctx->stream)); }
   return AV1MI_OK;
 }
@@ -447,6 +448,7 @@ int av1mi_inter_encode(av1mi_ctx *ctx, const av1mi_inter_job *j) {
   L.mvs = j->d_mvs; L.skip = j->d_skip;
   L.w = j->width; L.h = j->height; L.stride_y = j->stride_y; L.stride_uv = j->stride_uv; L.bd = j->bit_depth; L.nframes = j->nframes;
   L.dc_q = av1mi_dc_q(j->qindex, j->bit_depth); L.ac_q = av1mi_ac_q(j->qindex, j->bit_depth); L.range = j->search_range;
+  L.dc_quant = (1 << 16) / L.dc_q; L.ac_quant = (1 << 16) / L.ac_q;
   // one event pair per kernel, so that either can be the bench's roofline kernel and be matched with rocprofv3's per-kernel stats
   { ProfScope ps(ctx, AV1MI_K_ME_INT); HIP_TRY(ctx, av1mi::launch_me_int(L, ctx->stream)); }
   { ProfScope ps(ctx, AV1MI_K_INTER_PIPE); HIP_TRY(ctx, av1mi::launch_inter_pipe(L, ctx->stream)); }

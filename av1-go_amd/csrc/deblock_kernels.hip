@@ -157,12 +157,17 @@ __global__ __launch_bounds__(256) void k_deblock(DeblockLaunch L) {
   const Pix *src = reinterpret_cast<const Pix *>(L.src) + (size_t)tl.z * L.h * L.src_stride;
   const uint32_t *mi = L.mi + (size_t)tl.z * L.mi_frame_stride;
   const int cols = L.w >> 2, rows = L.h >> 2;
-  // mode-info units (0xFFFFFFFF outside the plane)
-  for (int i = tid; i < MH * MW; i += 256) {
-    const int ur = (Y0 >> 2) + i / MW, uc = (X0 >> 2) + i % MW;
-    uint32_t v = 0xFFFFFFFFu;
-    if (ur >= 0 && ur < rows && uc >= 0 && uc < cols) v = mi[(size_t)ur * L.mi_stride + uc];
-    mis[i] = v;
+  // mode-info units (0xFFFFFFFF outside the plane): requested first, stored after the sample loads have been issued too
+  constexpr int NMI = (MH * MW + 255) / 256;
+  uint32_t miv[NMI];
+#pragma unroll
+  for (int k = 0; k < NMI; k++) {
+    const int i = tid + 256 * k;
+    miv[k] = 0xFFFFFFFFu;
+    if (i < MH * MW) {
+      const int ur = (Y0 >> 2) + i / MW, uc = (X0 >> 2) + i % MW;
+      if (ur >= 0 && ur < rows && uc >= 0 && uc < cols) miv[k] = mi[(size_t)ur * L.mi_stride + uc];
+    }
   }
   // samples, coordinates clamped into the plane, 4 per lane per item: all of a lane's loads first, then its LDS stores (as one
   // loop every load was waited for before the next one was issued)
@@ -188,6 +193,11 @@ __global__ __launch_bounds__(256) void k_deblock(DeblockLaunch L) {
           done |= 1u << k;
         }
       }
+    }
+#pragma unroll
+    for (int k = 0; k < NMI; k++) {
+      const int i = tid + 256 * k;
+      if (i < MH * MW) mis[i] = miv[k];
     }
 #pragma unroll
     for (int k = 0; k < NIT; k++) {

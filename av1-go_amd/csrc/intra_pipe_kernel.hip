@@ -73,7 +73,7 @@ template <typename ES> struct TileCtx {
 #endif
 template <int B, int GW, typename Pix>
 __device__ __forceinline__ int code_block(const TileCtx<Pix> &C, int lane, int bx, int by, int n, int n_top, int n_topright, int n_left,
-                                          int n_bottomleft, int filter_type, int dc_q, int ac_q, const Pix *src_row,
+                                          int n_bottomleft, int filter_type, int dc_q, int ac_q, int dc_quant, int ac_quant, const Pix *src_row,
                                           Pix *rec_row, int16_t *lev_row STAMP_ARGS) {
   constexpr int bd = sizeof(Pix) == 1 ? 8 : 10;
   using ES = Pix;
@@ -114,7 +114,7 @@ __device__ __forceinline__ int code_block(const TileCtx<Pix> &C, int lane, int b
   AV1MI_GROUP_SYNC();
   STAMP(2);
   int rec[B];
-  code_residual<B, Pix>(C.tbuf, lane, s, bp, dc_q, ac_q, lev_row, rec);
+  code_residual<B, Pix>(C.tbuf, lane, s, bp, dc_q, ac_q, dc_quant, ac_quant, lev_row, rec);
   STAMP(3);
   store_row<B>(rec_row, rec);
   // neighbour context for the blocks to come
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256, BS == 8 ? 3 : 1) void k_intra_pipe(IntraPipeLa
       const size_t off = ((size_t)fy * BS + lane) * L.stride_y + (size_t)fx * BS;
 #endif
       const int m = code_block<BS, BS, Pix>(Y, lane, bx, by, N, have_top ? BS : 0, have_tr ? BS : 0, have_left ? BS : 0,
-                                             have_bl ? BS : 0, ft, L.dc_q, L.ac_q, src_y + off, rec_y + off,
+                                             have_bl ? BS : 0, ft, L.dc_q, L.ac_q, L.dc_quant, L.ac_quant, src_y + off, rec_y + off,
                                              lev_y + blk * BS * BS + lane * BS STAMP_PASS);
       if (lane == 0) { modes_y[blk] = (uint8_t)m; col_my[bx] = row_my[by] = (uint8_t)m; }
     }
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256, BS == 8 ? 3 : 1) void k_intra_pipe(IntraPipeLa
       const size_t off = ((size_t)fy * CS + cl) * L.stride_uv + (size_t)fx * CS;
 #endif
       const int m = code_block<CS, BS, Pix>(Cp, cl, bx, by, N, have_top ? CS : 0, have_tr ? CS : 0, have_left ? CS : 0,
-                                             have_bl ? CS : 0, ftc, L.dc_q, L.ac_q, src_c + off, rec_c + off,
+                                             have_bl ? CS : 0, ftc, L.dc_q, L.ac_q, L.dc_quant, L.ac_quant, src_c + off, rec_c + off,
                                              lev_c + blk * CS * CS + cl * CS STAMP_PASS);
       if (lane == 0) { modes_uv[blk] = (uint8_t)m; col_mc[bx] = row_mc[by] = (uint8_t)m; }
     }

@@ -63,9 +63,9 @@ __global__ __launch_bounds__(256) void k_lr(LrLaunch L) {
   // stage (bh + 6) rows x (bw + 8) columns of source samples: local row 0 == y0 - 3, local column 0 == X0 - 4 (4-aligned)
   const bool xin = X0 >= 4 && X0 + bw + 4 <= L.w && !(bw & 3);   // no horizontal clamping, whole 4-sample groups
   if (xin) {
-    // full-width bands (every band of a picture whose width is a multiple of 64) get compile-time divisors: an integer
-    // division by a runtime value is ~25 VALU instructions, and this kernel is VALU-bound
-    const bool full = bw == MAXW;
+    // item -> (row, group) by reciprocal multiplication (exact: items < 2^11 and (i + 0.5) / ng is never within 0.5 / ng of an
+    // integer); an integer division by a run-time value is ~25 VALU instructions, and "full ? i / const : i / ng" evaluated both
+    const float inv_ng = 1.0f / (float)((bw + 8) / 4);
     const int ng = (bw + 8) / 4, nitems = (bh + 6) * ng;
     // All of a lane's loads first, then all of its LDS stores: at most 70 x 18 items = 5 per lane.  As one loop every load was
     // waited for before the next was issued, and the kernel spent most of its time in those waits (waves stalled 64 % of
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void k_lr(LrLaunch L) {
     for (int k = 0; k < NIT; k++) {
       const int i = tid + 256 * k;
       if (i < nitems) {
-        const int r = full ? i / ((MAXW + 8) / 4) : i / ng, g = i - r * ng;
+        const int r = (int)(((float)i + 0.5f) * inv_ng), g = i - r * ng;
         int y = min(max(y0 - 3 + r, 0), L.h - 1);
         const Pix *p = cdef;
         if (y < sstart) { y = max(sstart - 2, y); p = dbl; }
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void k_lr(LrLaunch L) {
     for (int k = 0; k < NIT; k++) {
       const int i = tid + 256 * k;
       if (i < nitems) {
-        const int r = full ? i / ((MAXW + 8) / 4) : i / ng, g = i - r * ng;
+        const int r = (int)(((float)i + 0.5f) * inv_ng), g = i - r * ng;
         uint2 w = o[k];
         if constexpr (sizeof(Pix) == 1) { const uint32_t u = o[k].x; w.x = __builtin_amdgcn_perm(0u, u, 0x0c010c00u); w.y = __builtin_amdgcn_perm(0u, u, 0x0c030c02u); }
         *reinterpret_cast<uint2 *>(src + r * SS + 4 * g) = w;
@@ -130,9 +130,9 @@ __global__ __launch_bounds__(256) void k_lr(LrLaunch L) {
       auto pk = [](int a, int b) { return __builtin_bit_cast(s16x2, (uint32_t)(a & 0xffff) | ((uint32_t)b << 16)); };
       const s16x2 H0 = pk(hf[0], hf[1]), H1 = pk(hf[2], hf[3]), H2 = pk(hf[4], hf[5]), H3 = pk(hf[6], 0);
       const int q4 = bw / 4;
-      const bool full = bw == MAXW;
+      const float inv_q4 = 1.0f / (float)q4;
       for (int i = tid; i < (bh + 6) * q4; i += 256) {
-        const int r = full ? i / (MAXW / 4) : i / q4, c = (i - r * q4) * 4;
+        const int r = (int)(((float)i + 0.5f) * inv_q4), c = (i - r * q4) * 4;
         const uint2 *p = reinterpret_cast<const uint2 *>(src + r * SS + c);
         const uint2 a = p[0], b = p[1], e = p[2];
         const uint32_t d[6] = { a.x, a.y, b.x, b.y, e.x, e.y };
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void k_lr(LrLaunch L) {
       const s16x2 VO[4] = { pk(0, vf[0]), pk(vf[1], vf[2]), pk(vf[3], vf[4]), pk(vf[5], vf[6]) };
       const int hp = (bh + 1) >> 1;
       for (int i = tid; i < hp * q4; i += 256) {
-        const int rp = full ? i / (MAXW / 4) : i / q4, c = (i - rp * q4) * 4, r = 2 * rp;
+        const int rp = (int)(((float)i + 0.5f) * inv_q4), c = (i - rp * q4) * 4, r = 2 * rp;
         int se[4] = { 1024, 1024, 1024, 1024 }, so[4] = { 1024, 1024, 1024, 1024 };
 #pragma unroll
         for (int j = 0; j < 4; j++) {
