@@ -33,35 +33,43 @@ __device__ __forceinline__ v2s pk_constrain(v2s diff, v2u thr, v2u shift) {
   const v2s t = __builtin_bit_cast(v2s, __builtin_elementwise_sub_sat(thr, mag >> shift));
   return __builtin_elementwise_max(__builtin_elementwise_min(diff, t), -t);
 }
-// linear tap offsets of one direction in a tile of row stride LS: {o0 k0, o0 k1, o1 k0, o1 k1, o2 k0, o2 k1, 0, 0} as
-// int16, o0 = dir, o1 = dir + 2, o2 = dir + 6 (mod 8): one 16-byte LDS row per direction, read once per quad
-template <int LS> __device__ __forceinline__ void cdef_fill_offsets(int16_t *tab, int i) {   // i in [0, 64)
-  const int dir = i >> 3, j = i & 7;
+// Tap table of one direction in a tile of row stride LS, ready to use: for each of the six tap positions j (primary k = 0, 1;
+// secondary dir + 2, k = 0, 1; secondary dir + 6, k = 0, 1) three int32: the BYTE offset of the aligned dword pair that holds
+// the four samples at +offset, the same for the mirrored tap at -offset, and the funnel shift (16 when the offset is odd).
+// A quad reads its direction's 18 entries with five LDS loads and adds them to its centre address; derived per quad from
+// int16 sample offsets this was ~45 of the ~450 instructions of a quad.
+constexpr int kTapEntries = 20;   // 18 used, row padded to a multiple of 4 dwords
+template <int LS> __device__ __forceinline__ void cdef_fill_offsets(int32_t *tab, int i) {   // i in [0, 8 * 6)
+  const int dir = i / 6, j = i - dir * 6;
   const int d = j < 2 ? dir : j < 4 ? (dir + 2) & 7 : (dir + 6) & 7, k = j & 1;
-  tab[i] = j < 6 ? (int16_t)(kCdefDir[d][k][0] * LS + kCdefDir[d][k][1]) : (int16_t)0;
+  const int o = kCdefDir[d][k][0] * LS + kCdefDir[d][k][1], odd = o & 1;
+  tab[dir * kTapEntries + 3 * j] = 2 * (o - odd);
+  tab[dir * kTapEntries + 3 * j + 1] = 2 * (-o - odd);
+  tab[dir * kTapEntries + 3 * j + 2] = odd * 16;
 }
-template <int LS, bool SENT>
-__device__ __forceinline__ void cdef_quad_packed(const uint16_t *p, const int16_t *offtab, int pri, int sec, int damping, int dir, int cs, v2s *out) {
+// pshift / sshift: max(0, damping - msb(strength)) (0 for strength 0); pt0, pt1: the primary tap weights (4, 2) or (3, 3)
+template <bool SENT>
+__device__ __forceinline__ void cdef_quad_packed(const uint16_t *p, const int32_t *otab, int pri, int sec, int pshift, int sshift, int pt0, int pt1, v2s *out) {
   const uint32_t *c32 = reinterpret_cast<const uint32_t *>(p);
   const v2s x0 = __builtin_bit_cast(v2s, c32[0]), x1 = __builtin_bit_cast(v2s, c32[1]);
   v2s s0 = { 0, 0 }, s1 = { 0, 0 }, mx0 = x0, mx1 = x1, mn0 = x0, mn1 = x1;
-  const int pshift = pri ? max(0, damping - msb(pri)) : 0, sshift = sec ? max(0, damping - msb(sec)) : 0;
-  const int pt0 = ((pri >> cs) & 1) ? 3 : 4, pt1 = ((pri >> cs) & 1) ? 3 : 2;
-  const uint4 ot = *reinterpret_cast<const uint4 *>(offtab + dir * 8);
-  const int offs[6] = { (int16_t)(ot.x & 0xffff), (int16_t)(ot.x >> 16), (int16_t)(ot.y & 0xffff), (int16_t)(ot.y >> 16),
-                        (int16_t)(ot.z & 0xffff), (int16_t)(ot.z >> 16) };
+  int ot[kTapEntries];
+#pragma unroll
+  for (int i = 0; i < kTapEntries; i += 4) {
+    const int4 v = *reinterpret_cast<const int4 *>(otab + i);
+    ot[i] = v.x; ot[i + 1] = v.y; ot[i + 2] = v.z; ot[i + 3] = v.w;
+  }
   // one tap position and its mirror image share weight and strength: constrain both, add, one multiply-add per pair
-  auto taps = [&](int off, int thr, int shift, int w) {
+  auto taps = [&](int j, int thr, int shift, int w) {
     const v2u th = { (unsigned short)thr, (unsigned short)thr }, sh = { (unsigned short)shift, (unsigned short)shift };
     v2s c0 = { 0, 0 }, c1 = { 0, 0 };
 #pragma unroll
     for (int sg = 0; sg < 2; sg++) {
-      const int o = sg ? -off : off, odd = o & 1;
-      // the four samples at p + o .. p + o + 3 as two packed pairs; o may be odd: funnel-shift three aligned dwords
-      const uint32_t *q = reinterpret_cast<const uint32_t *>(p + o - odd);
+      // the four samples at p +- offset .. + 3 as two packed pairs; the offset may be odd: funnel-shift three aligned dwords
+      const uint32_t *q = reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(p) + ot[3 * j + sg]);
       const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
-      v2s a0 = __builtin_bit_cast(v2s, __builtin_amdgcn_alignbit(d1, d0, odd * 16));
-      v2s a1 = __builtin_bit_cast(v2s, __builtin_amdgcn_alignbit(d2, d1, odd * 16));
+      v2s a0 = __builtin_bit_cast(v2s, __builtin_amdgcn_alignbit(d1, d0, ot[3 * j + 2]));
+      v2s a1 = __builtin_bit_cast(v2s, __builtin_amdgcn_alignbit(d2, d1, ot[3 * j + 2]));
       if constexpr (SENT) {
         // picture-border superblocks: 0xFFFF marks a sample outside the picture (CdefAvailable = 0).  Valid samples are
         // < 2^15, so the sign bit is the mark; a marked tap is replaced by the centre sample: difference 0, and it cannot
@@ -80,9 +88,9 @@ __device__ __forceinline__ void cdef_quad_packed(const uint16_t *p, const int16_
   };
 #pragma unroll
   for (int k = 0; k < 2; k++) {
-    taps(offs[k], pri, pshift, k ? pt1 : pt0);
-    taps(offs[2 + k], sec, sshift, k ? 1 : 2);
-    taps(offs[4 + k], sec, sshift, k ? 1 : 2);
+    taps(k, pri, pshift, k ? pt1 : pt0);
+    taps(2 + k, sec, sshift, k ? 1 : 2);
+    taps(4 + k, sec, sshift, k ? 1 : 2);
   }
   const v2s eight = { 8, 8 }, four = { 4, 4 }, fifteen = { 15, 15 };
   const v2s y0 = x0 + ((s0 + (s0 >> fifteen) + eight) >> four), y1 = x1 + ((s1 + (s1 >> fifteen) + eight) >> four);
@@ -95,12 +103,13 @@ __global__ __launch_bounds__(256) void k_cdef(CdefLaunch L) {
   constexpr int YS = 64 + 4 + 2, CSZ = 32 + 4 + 2;   // LDS row strides (halo 2 each side, +2 pad)
   __shared__ __attribute__((aligned(16))) uint16_t ty[(64 + 4) * YS + 8];
   __shared__ __attribute__((aligned(16))) uint16_t tc[2][(32 + 4) * CSZ + 8];
-  __shared__ uint8_t bdir[64];
   __shared__ uint8_t bskip[64];   // skip flag of each 8x8 block of the superblock (1 also for blocks outside the picture)
-  __shared__ int bvar[64];
-  __shared__ __attribute__((aligned(16))) int16_t offy[64], offc[64];   // tap offsets per direction for the two tile strides
+  // per 8x8 block, from the direction search: luma primary strength after the variance adjustment (bits 0-7), its damping
+  // shift (8-11), the luma filter direction (12-14), the primary tap parity (15), the block's direction itself (16-18: chroma)
+  __shared__ uint32_t bpar[64];
+  __shared__ __attribute__((aligned(16))) int32_t offy[8 * kTapEntries], offc[8 * kTapEntries];   // tap tables for the two tile strides
   const int tid = threadIdx.x;
-  if (tid < 64) cdef_fill_offsets<YS>(offy, tid); else if (tid < 128) cdef_fill_offsets<CSZ>(offc, tid - 64);
+  if (tid < 48) cdef_fill_offsets<YS>(offy, tid); else if (tid >= 64 && tid < 112) cdef_fill_offsets<CSZ>(offc, tid - 64);
   const Tile3 tl = xcd_tile((L.w + 63) / 64, (L.h + 63) / 64, L.nframes);
   const int sbx = tl.x, sby = tl.y, f = tl.z;
   const int bd = L.bd, cs = bd - 8;
@@ -191,6 +200,10 @@ __global__ __launch_bounds__(256) void k_cdef(CdefLaunch L) {
   }
   __syncthreads();
   const bool enabled = st[0] != 255;
+  // strengths of the superblock (uniform) and what follows from them alone
+  const int ypri0 = st[0] << cs, ysec = (st[1] == 3 ? 4 : st[1]) << cs;
+  const int upri = st[2] << cs, usec = (st[3] == 3 ? 4 : st[3]) << cs;
+  const int dampy = L.damping + cs, dampc = L.damping + cs - 1;
   // direction search: lane b of wave 0 owns 8x8 block b (raster within the superblock)
   if (tid < 64 && enabled) {
     const int by = tid >> 3, bx = tid & 7;
@@ -235,14 +248,19 @@ __global__ __launch_bounds__(256) void k_cdef(CdefLaunch L) {
       int opp = 0;
 #pragma unroll
       for (int i = 0; i < 8; i++) if (i == ((best + 4) & 7)) opp = cost[i];
-      bdir[tid] = (uint8_t)best;
-      bvar[tid] = (best_cost - opp) >> 10;
+      // everything a quad of this block needs, once per block instead of once per quad (16 luma + 8 chroma quads per block)
+      const int var = (best_cost - opp) >> 10;
+      const int vs = (var >> 6) ? min(msb((unsigned)(var >> 6)), 12) : 0;
+      const int pri = var ? (ypri0 * (4 + vs) + 8) >> 4 : 0;             // spec 7.15.2: luma primary strength adjusted by the variance
+      const int pshift = pri ? max(0, dampy - msb((unsigned)pri)) : 0;
+      const int ydir = ypri0 == 0 ? 0 : best;
+      bpar[tid] = (uint32_t)pri | ((uint32_t)pshift << 8) | ((uint32_t)ydir << 12) | ((uint32_t)((pri >> cs) & 1) << 15) | ((uint32_t)best << 16);
     }
   }
   __syncthreads();
   // filter: luma 64x64 -> 16 samples per lane (4 rows x 4 columns), chroma 2 x 32x32 -> 2 x 4 samples per lane
-  const int ypri0 = st[0] << cs, ysec = (st[1] == 3 ? 4 : st[1]) << cs;
-  const int upri = st[2] << cs, usec = (st[3] == 3 ? 4 : st[3]) << cs;
+  const int ysshift = ysec ? max(0, dampy - msb((unsigned)ysec)) : 0, usshift = usec ? max(0, dampc - msb((unsigned)usec)) : 0;
+  const int upshift = upri ? max(0, dampc - msb((unsigned)upri)) : 0, upar = (upri >> cs) & 1;
   for (int q = tid; q < 64 * 16; q += 256) {         // q -> (row, group of 4 columns)
     const int r = q >> 4, c = (q & 15) * 4;
     const int fy = sby * 64 + r, fx = sbx * 64 + c;
@@ -253,13 +271,12 @@ __global__ __launch_bounds__(256) void k_cdef(CdefLaunch L) {
     int o[4];
     if (skip) { o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; o[3] = p[3]; }
     else {
-      const int var = bvar[b];
-      const int vs = (var >> 6) ? min(msb((unsigned)(var >> 6)), 12) : 0;
-      const int pri = var ? (ypri0 * (4 + vs) + 8) >> 4 : 0;
-      const int dir = ypri0 == 0 ? 0 : bdir[b];
+      const uint32_t bp = bpar[b];
+      const int pri = bp & 255, pshift = (bp >> 8) & 15, par = (bp >> 15) & 1;
+      const int32_t *ot = offy + ((bp >> 12) & 7) * kTapEntries;
       v2s r[2];
-      if (interior) cdef_quad_packed<YS, false>(p, offy, pri, ysec, L.damping + cs, dir, cs, r);
-      else cdef_quad_packed<YS, true>(p, offy, pri, ysec, L.damping + cs, dir, cs, r);
+      if (interior) cdef_quad_packed<false>(p, ot, pri, ysec, pshift, ysshift, par ? 3 : 4, par ? 3 : 2, r);
+      else cdef_quad_packed<true>(p, ot, pri, ysec, pshift, ysshift, par ? 3 : 4, par ? 3 : 2, r);
       o[0] = r[0].x; o[1] = r[0].y; o[2] = r[1].x; o[3] = r[1].y;
     }
     Pix *d = dy + (size_t)fy * L.stride_y + fx;
@@ -276,10 +293,10 @@ __global__ __launch_bounds__(256) void k_cdef(CdefLaunch L) {
     int o[4];
     if (skip) { o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; o[3] = p[3]; }
     else {
-      const int dir = upri == 0 ? 0 : bdir[b];
+      const int32_t *ot = offc + (upri == 0 ? 0 : (int)((bpar[b] >> 16) & 7)) * kTapEntries;
       v2s r[2];
-      if (interior) cdef_quad_packed<CSZ, false>(p, offc, upri, usec, L.damping + cs - 1, dir, cs, r);
-      else cdef_quad_packed<CSZ, true>(p, offc, upri, usec, L.damping + cs - 1, dir, cs, r);
+      if (interior) cdef_quad_packed<false>(p, ot, upri, usec, upshift, usshift, upar ? 3 : 4, upar ? 3 : 2, r);
+      else cdef_quad_packed<true>(p, ot, upri, usec, upshift, usshift, upar ? 3 : 4, upar ? 3 : 2, r);
       o[0] = r[0].x; o[1] = r[0].y; o[2] = r[1].x; o[3] = r[1].y;
     }
     Pix *d = reinterpret_cast<Pix *>(L.dst[1 + pl]) + (size_t)f * chh * L.stride_uv + (size_t)fy * L.stride_uv + fx;
