@@ -309,17 +309,24 @@ __device__ __forceinline__ void mc_h16(const ES *win, int ws, int16_t *im, int l
       const s16x2 fp[4] = { __builtin_bit_cast(s16x2, fq.x), __builtin_bit_cast(s16x2, fq.y), __builtin_bit_cast(s16x2, fq.z), __builtin_bit_cast(s16x2, fq.w) };
 #pragma unroll
       for (int c = 0; c < 8; c++) {
-        int acc = 4;
+        int acc = 128;                              // taps x 32 (see below): the rounding constant 4 x 32
 #pragma unroll
         for (int u = 0; u < 4; u++) acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, pm[c + 2 * u]), fp[u], acc, false);
         sum[c] = acc;
       }
     }
     uint32_t o[4];
+    if constexpr (sizeof(ES) == 1) {
 #pragma unroll
-    for (int c = 0; c < 8; c++) {
-      const uint32_t h = (uint32_t)(sum[c] >> 3) & 0xffff;
-      o[c >> 1] = (c & 1) ? (o[c >> 1] | (h << 16)) : h;
+      for (int c = 0; c < 8; c++) {
+        const uint32_t h = (uint32_t)(sum[c] >> 3) & 0xffff;
+        o[c >> 1] = (c & 1) ? (o[c >> 1] | (h << 16)) : h;
+      }
+    } else {
+      // 10-bit: `filt` is the x 32 table, (32 s + 128) >> 8 == (s + 4) >> 3: the int16 result is bytes 1..2 of the accumulator, and
+      // one v_perm shifts and packs two of them (|32 s| < 2^23: no overflow)
+#pragma unroll
+      for (int j = 0; j < 4; j++) o[j] = __builtin_amdgcn_perm((uint32_t)sum[2 * j + 1], (uint32_t)sum[2 * j], 0x06050201u);
     }
     *reinterpret_cast<uint4 *>(im + j * 8) = make_uint4(o[0], o[1], o[2], o[3]);
   }
@@ -484,7 +491,7 @@ __global__ __launch_bounds__(256) void k_inter_pipe(InterLaunch L) {
       const int fx = cx + (ix - 1) * step;
       // half-pel round, centre column: every block of the wave is at a whole-sample horizontal position
       if (step == 4 && ix == 1) mc_h16_copy<ES>(wy, YWS, im, lane);
-      else mc_h16<ES>(wy, YWS, im, lane, fx * 2, s_filt[0]);
+      else mc_h16<ES>(wy, YWS, im, lane, fx * 2, sizeof(ES) == 2 ? s_filt[2] : s_filt[0]);
       AV1MI_GROUP_SYNC();
       uint32_t pr[5][8];
       mc_rows9(im, lane, pr);
