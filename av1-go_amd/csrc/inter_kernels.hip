@@ -180,6 +180,14 @@ __global__ __launch_bounds__(256) void k_me_int(InterLaunch L) {
 // window starts 4 samples left of / above the integer-vector block): posx/posy = displacement from the window's block
 // origin in 1/16 samples, in [-16, 15].  im: (B+7) x B int16 scratch of the group.  NL = lanes of the block.
 typedef short s16x2 __attribute__((ext_vector_type(2)));
+// The first v_dot2 of an accumulation with its start value as an operand.  The compiler always picks the two-address form
+// (v_dot2c: accumulator = destination) and initialises every accumulator with a v_mov first — one extra instruction per output
+// sample in loops that are nothing but dot products; the three-address VOP3P form takes the start value from an SGPR.
+__device__ __forceinline__ int dot2_start(uint32_t a, uint32_t b, int start_uniform) {
+  int d;
+  asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(start_uniform));
+  return d;
+}
 // One window row of N samples from plane row `row`, columns x0 .. x0 + N - 1, into the dword-aligned LDS row `dst`.
 // Inside the plane it is one unaligned vector load (the hardware takes any address) and N * sizeof(Pix) / 4 dword stores;
 // rows that stick out clamp sample by sample (the spec's edge extension).
@@ -309,9 +317,9 @@ __device__ __forceinline__ void mc_h16(const ES *win, int ws, int16_t *im, int l
       const s16x2 fp[4] = { __builtin_bit_cast(s16x2, fq.x), __builtin_bit_cast(s16x2, fq.y), __builtin_bit_cast(s16x2, fq.z), __builtin_bit_cast(s16x2, fq.w) };
 #pragma unroll
       for (int c = 0; c < 8; c++) {
-        int acc = 128;                              // taps x 32 (see below): the rounding constant 4 x 32
+        int acc = dot2_start(pm[c], __builtin_bit_cast(uint32_t, fp[0]), 128);   // taps x 32 (see below): the rounding constant 4 x 32
 #pragma unroll
-        for (int u = 0; u < 4; u++) acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, pm[c + 2 * u]), fp[u], acc, false);
+        for (int u = 1; u < 4; u++) acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, pm[c + 2 * u]), fp[u], acc, false);
         sum[c] = acc;
       }
     }
@@ -361,7 +369,7 @@ __device__ __forceinline__ void mc_rows9(const int16_t *im, int lane, uint32_t (
   uint4 rw[10];
 #pragma unroll
   for (int k = 0; k < 9; k++) rw[k] = *reinterpret_cast<const uint4 *>(im + (lane + k) * 8);
-  rw[9] = make_uint4(0, 0, 0, 0);
+  rw[9] = make_uint4(0x00020002u, 0x00020002u, 0x00020002u, 0x00020002u);   // "row 9" = the constant 2: carries mc_v9's rounding term
 #pragma unroll
   for (int kp = 0; kp < 5; kp++) {
     const uint32_t x[4] = { rw[2 * kp].x, rw[2 * kp].y, rw[2 * kp].z, rw[2 * kp].w };
@@ -381,13 +389,18 @@ __device__ __forceinline__ void mc_v9(const uint32_t (*pr)[8], int posy, const i
   // the nine taps over rows lane .. lane + 8 as five pairs: the row of 8 taps as it lies in memory (oy = 0: pairs P0..P3, 0),
   // or moved up by one row (oy = 1: (0,t0) (t1,t2) (t3,t4) (t5,t6) (t7,0)) — one funnel shift per pair
   const uint4 fq = *reinterpret_cast<const uint4 *>(filt32[posy & 15]);
-  const uint32_t P[6] = { 0u, fq.x, fq.y, fq.z, fq.w, 0u };
-  int s[8] = { 32768, 32768, 32768, 32768, 32768, 32768, 32768, 32768 };
+  // The last pair's second row is the constant 2 (mc_rows9) and its tap 16384: 2 x 16384 = 32768 is the rounding term, so the
+  // accumulators start at 0 — an inline constant of the first dot2 instead of a v_mov of a literal per column.
+  const uint32_t P[6] = { 0u, fq.x, fq.y, fq.z, fq.w, 0x40000000u };
+  int s[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
 #pragma unroll
   for (int kp = 0; kp < 5; kp++) {
-    const s16x2 gp = __builtin_bit_cast(s16x2, oy ? __builtin_amdgcn_alignbit(P[kp + 1], P[kp], 16) : P[kp + 1]);
+    uint32_t g = oy ? __builtin_amdgcn_alignbit(P[kp + 1], P[kp], 16) : P[kp + 1];
+    if (kp == 4) g = (oy ? (P[4] >> 16) : 0u) | 0x40000000u;    // (t7 or 0, 16384)
+    const s16x2 gp = __builtin_bit_cast(s16x2, g);
 #pragma unroll
-    for (int c = 0; c < 8; c++) s[c] = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, pr[kp][c]), gp, s[c], false);
+    for (int c = 0; c < 8; c++)
+      s[c] = kp == 0 ? dot2_start(pr[kp][c], g, 0) : __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, pr[kp][c]), gp, s[c], false);
   }
   const s16x2 zero = { 0, 0 }, top = { (short)((1 << bd) - 1), (short)((1 << bd) - 1) };
 #pragma unroll
