@@ -15,6 +15,10 @@ __device__ __forceinline__ unsigned xcd_swizzle(unsigned bid, unsigned nwg) {
   const unsigned q = nwg >> 3, r = nwg & 7u, xcd = bid & 7u;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
+// row * stride of a plane row: both operands are below 2^24 and the product below 2^32 (the C ABI admits frames up to 16384 x
+// 16384), so it is ONE full-rate 24-bit multiply; written as (size_t)row * stride it is a 64-bit multiply-add, four passes.
+__device__ __forceinline__ size_t row_off(int row, int stride) { return (size_t)__umul24((unsigned)row, (unsigned)stride); }
+
 // raster tile index -> (x, y, z) of a gx x gy x gz grid
 struct Tile3 { int x, y, z; };
 __device__ __forceinline__ Tile3 xcd_tile(unsigned gx, unsigned gy, unsigned gz) {

@@ -78,10 +78,10 @@ __device__ __forceinline__ int code_residual(int32_t *T, int lane, const int *s,
     const int v = round2(xv[c], -fwd_shift(B, B, 2));
     const bool neg = v < 0;
     int a = min(neg ? -v : v, 1 << 20), l = 0;
-    l = (min(a + rnd, 32767) * quant) >> 16;          // <= 32767 * 16384 >> 16: no overflow, and already <= 32767
+    l = __mul24(min(a + rnd, 32767), quant) >> 16;    // 15 x 15 bits: a full-rate 24-bit multiply (a 32-bit one is four passes); <= 8191
     l = (a << 1) >= q ? l : 0;
     lv[c] = neg ? -l : l;
-    const int d = (l * q) & 0xFFFFFF;
+    const int d = __mul24(l, q) & 0xFFFFFF;            // l <= 8191, q < 2^15
     xv[c] = min(max(neg ? -d : d, minv), maxv);
   }
 #pragma unroll

@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void k_cdef(CdefLaunch L) {
       const int i = tid + 256 * k;
       if (i < NY) {
         const int r = i / 18, g = i - r * 18;
-        const Pix *q = sy + (size_t)(sby * 64 - 2 + r) * L.stride_y + sbx * 64 - 4 + g * 4;
+        const Pix *q = sy + row_off(sby * 64 - 2 + r, L.stride_y) + sbx * 64 - 4 + g * 4;
         if constexpr (sizeof(Pix) == 1) vy[k].x = *reinterpret_cast<const uint32_t *>(q);
         else vy[k] = *reinterpret_cast<const uint2 *>(q);
       }
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void k_cdef(CdefLaunch L) {
       const int i = tid + 256 * k;
       if (i < NC) {
         const int pl = i / 360, j = i - pl * 360, r = j / 10, g = j - r * 10;
-        const Pix *q = reinterpret_cast<const Pix *>(L.src[1 + pl]) + (size_t)f * chh * L.stride_uv + (size_t)(sby * 32 - 2 + r) * L.stride_uv + sbx * 32 - 4 + g * 4;
+        const Pix *q = reinterpret_cast<const Pix *>(L.src[1 + pl]) + (size_t)f * chh * L.stride_uv + row_off(sby * 32 - 2 + r, L.stride_uv) + sbx * 32 - 4 + g * 4;
         if constexpr (sizeof(Pix) == 1) vc[k].x = *reinterpret_cast<const uint32_t *>(q);
         else vc[k] = *reinterpret_cast<const uint2 *>(q);
       }
@@ -189,13 +189,13 @@ __global__ __launch_bounds__(256) void k_cdef(CdefLaunch L) {
     for (int i = tid; i < 68 * 68; i += 256) {
       const int r = i / 68, c = i - r * 68;
       const int fy = sby * 64 - 2 + r, fx = sbx * 64 - 2 + c;
-      ty[r * YS + c] = (fy >= 0 && fy < L.h && fx >= 0 && fx < L.w) ? (uint16_t)sy[(size_t)fy * L.stride_y + fx] : (uint16_t)0xFFFF;
+      ty[r * YS + c] = (fy >= 0 && fy < L.h && fx >= 0 && fx < L.w) ? (uint16_t)sy[row_off(fy, L.stride_y) + fx] : (uint16_t)0xFFFF;
     }
     for (int i = tid; i < 2 * 36 * 36; i += 256) {
       const int pl = i / (36 * 36), j = i - pl * 36 * 36, r = j / 36, c = j - r * 36;
       const int fy = sby * 32 - 2 + r, fx = sbx * 32 - 2 + c;
       const Pix *sc = reinterpret_cast<const Pix *>(L.src[1 + pl]) + (size_t)f * chh * L.stride_uv;
-      tc[pl][r * CSZ + c] = (fy >= 0 && fy < chh && fx >= 0 && fx < cw) ? (uint16_t)sc[(size_t)fy * L.stride_uv + fx] : (uint16_t)0xFFFF;
+      tc[pl][r * CSZ + c] = (fy >= 0 && fy < chh && fx >= 0 && fx < cw) ? (uint16_t)sc[row_off(fy, L.stride_uv) + fx] : (uint16_t)0xFFFF;
     }
   }
   __syncthreads();
@@ -222,25 +222,28 @@ __global__ __launch_bounds__(256) void k_cdef(CdefLaunch L) {
           partial[0][i + j] += x; partial[1][i + j / 2] += x; partial[2][i] += x; partial[3][3 + i - j / 2] += x;
           partial[4][7 + i - j] += x; partial[5][3 - i / 2 + j] += x; partial[6][j] += x; partial[7][i / 2 + j] += x;
         }
+      // squares of sums of at most 8 values in [-128, 127] (<= 2^20) times weights <= 840: 24-bit multiplies (a 32-bit integer
+      // multiply is four passes)
       constexpr int div_table[9] = { 0, 840, 420, 280, 210, 168, 140, 120, 105 };
+      auto sq = [](int v) { return __mul24(v, v); };
       int cost[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
 #pragma unroll
-      for (int i = 0; i < 8; i++) { cost[2] += partial[2][i] * partial[2][i]; cost[6] += partial[6][i] * partial[6][i]; }
-      cost[2] *= 105; cost[6] *= 105;
+      for (int i = 0; i < 8; i++) { cost[2] += sq(partial[2][i]); cost[6] += sq(partial[6][i]); }
+      cost[2] = (int)__umul24((unsigned)cost[2], 105u); cost[6] = (int)__umul24((unsigned)cost[6], 105u);
 #pragma unroll
       for (int i = 0; i < 7; i++) {
-        cost[0] += (partial[0][i] * partial[0][i] + partial[0][14 - i] * partial[0][14 - i]) * div_table[i + 1];
-        cost[4] += (partial[4][i] * partial[4][i] + partial[4][14 - i] * partial[4][14 - i]) * div_table[i + 1];
+        cost[0] += (int)__umul24((unsigned)(sq(partial[0][i]) + sq(partial[0][14 - i])), (unsigned)div_table[i + 1]);
+        cost[4] += (int)__umul24((unsigned)(sq(partial[4][i]) + sq(partial[4][14 - i])), (unsigned)div_table[i + 1]);
       }
-      cost[0] += partial[0][7] * partial[0][7] * 105;
-      cost[4] += partial[4][7] * partial[4][7] * 105;
+      cost[0] += (int)__umul24((unsigned)sq(partial[0][7]), 105u);
+      cost[4] += (int)__umul24((unsigned)sq(partial[4][7]), 105u);
 #pragma unroll
       for (int i = 1; i < 8; i += 2) {
 #pragma unroll
-        for (int j = 0; j < 5; j++) cost[i] += partial[i][3 + j] * partial[i][3 + j];
-        cost[i] *= 105;
+        for (int j = 0; j < 5; j++) cost[i] += sq(partial[i][3 + j]);
+        cost[i] = (int)__umul24((unsigned)cost[i], 105u);
 #pragma unroll
-        for (int j = 0; j < 3; j++) cost[i] += (partial[i][j] * partial[i][j] + partial[i][10 - j] * partial[i][10 - j]) * div_table[2 * j + 2];
+        for (int j = 0; j < 3; j++) cost[i] += (int)__umul24((unsigned)(sq(partial[i][j]) + sq(partial[i][10 - j])), (unsigned)div_table[2 * j + 2]);
       }
       int best = 0, best_cost = 0;
 #pragma unroll
@@ -279,7 +282,7 @@ __global__ __launch_bounds__(256) void k_cdef(CdefLaunch L) {
       else cdef_quad_packed<true>(p, ot, pri, ysec, pshift, ysshift, par ? 3 : 4, par ? 3 : 2, r);
       o[0] = r[0].x; o[1] = r[0].y; o[2] = r[1].x; o[3] = r[1].y;
     }
-    Pix *d = dy + (size_t)fy * L.stride_y + fx;
+    Pix *d = dy + row_off(fy, L.stride_y) + fx;
     if constexpr (sizeof(Pix) == 1) *reinterpret_cast<uint32_t *>(d) = (uint32_t)o[0] | ((uint32_t)o[1] << 8) | ((uint32_t)o[2] << 16) | ((uint32_t)o[3] << 24);
     else { uint2 u; u.x = (uint32_t)o[0] | ((uint32_t)o[1] << 16); u.y = (uint32_t)o[2] | ((uint32_t)o[3] << 16); *reinterpret_cast<uint2 *>(d) = u; }
   }
@@ -299,7 +302,7 @@ __global__ __launch_bounds__(256) void k_cdef(CdefLaunch L) {
       else cdef_quad_packed<true>(p, ot, upri, usec, upshift, usshift, upar ? 3 : 4, upar ? 3 : 2, r);
       o[0] = r[0].x; o[1] = r[0].y; o[2] = r[1].x; o[3] = r[1].y;
     }
-    Pix *d = reinterpret_cast<Pix *>(L.dst[1 + pl]) + (size_t)f * chh * L.stride_uv + (size_t)fy * L.stride_uv + fx;
+    Pix *d = reinterpret_cast<Pix *>(L.dst[1 + pl]) + (size_t)f * chh * L.stride_uv + row_off(fy, L.stride_uv) + fx;
     if constexpr (sizeof(Pix) == 1) *reinterpret_cast<uint32_t *>(d) = (uint32_t)o[0] | ((uint32_t)o[1] << 8) | ((uint32_t)o[2] << 16) | ((uint32_t)o[3] << 24);
     else { uint2 u; u.x = (uint32_t)o[0] | ((uint32_t)o[1] << 16); u.y = (uint32_t)o[2] | ((uint32_t)o[3] << 16); *reinterpret_cast<uint2 *>(d) = u; }
   }

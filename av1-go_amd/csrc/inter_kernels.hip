@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void k_me_int(InterLaunch L) {
   for (int i = tid; i < WDY * wg; i += 256) {
     const int r = i / wg, c = (i - r * wg) * 4;
     const int fy = min(max(sby * 64 - R + r, 0), L.h - 1), fx = sbx * 64 - R4 + c;
-    const Pix *row = ref + (size_t)fy * L.stride_y;
+    const Pix *row = ref + row_off(fy, L.stride_y);
     uint32_t u;
     if (fx >= 0 && fx + 3 < L.w) {
       if constexpr (sizeof(Pix) == 1) u = *reinterpret_cast<const uint32_t *>(row + fx);
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void k_me_int(InterLaunch L) {
   for (int i = tid; i < 64 * 16; i += 256) {
     const int r = i >> 4, c = (i & 15) * 4;
     const int fy = min(sby * 64 + r, L.h - 1), fx = sbx * 64 + c;
-    const Pix *row = src + (size_t)fy * L.stride_y;
+    const Pix *row = src + row_off(fy, L.stride_y);
     uint32_t u;
     if (fx + 3 < L.w) {
       if constexpr (sizeof(Pix) == 1) u = *reinterpret_cast<const uint32_t *>(row + fx);
@@ -465,11 +465,11 @@ __global__ __launch_bounds__(256) void k_inter_pipe(InterLaunch L) {
   for (int it = 0; it < 2; it++) {
     const int r = lane + it * 8;
     const int fy = min(max(y + imy - 4 + r, 0), L.h - 1);
-    const Pix *row = ref_y + (size_t)fy * L.stride_y;
+    const Pix *row = ref_y + row_off(fy, L.stride_y);
     stage_window_row<YW, Pix>(row, x + imx - 4, L.w, wy + r * YWS);
   }
   int s[8], bp[8];
-  load_row<8>(src_y + (size_t)(y + lane) * L.stride_y + x, s);
+  load_row<8>(src_y + row_off(y + lane, L.stride_y) + x, s);
   AV1MI_GROUP_SYNC();
   // rows are compared as packed pairs (v_sad_u16: two samples per instruction, both bit depths) and the running best
   // prediction is kept packed: four selects per candidate; it is unpacked once after the search
@@ -534,7 +534,7 @@ __global__ __launch_bounds__(256) void k_inter_pipe(InterLaunch L) {
   if (lane == 0) { mvs[0] = (int16_t)mvx; mvs[1] = (int16_t)mvy; }
   int rec[8];
   int nz = code_residual<8, Pix>(T, lane, s, bp, L.dc_q, L.ac_q, L.dc_quant, L.ac_quant, L.lev[0] + (size_t)f * L.w * L.h + (size_t)blk * 64 + lane * 8, rec);
-  store_row<8>(rec_y + (size_t)(y + lane) * L.stride_y + x, rec);
+  store_row<8>(rec_y + row_off(y + lane, L.stride_y) + x, rec);
 
   // chroma: lanes 0-3 code the U block, lanes 4-7 the V block (4x4 each, 4-tap regular filter rows)
   {
@@ -552,16 +552,16 @@ __global__ __launch_bounds__(256) void k_inter_pipe(InterLaunch L) {
     for (int it = 0; it < 3; it++) {
       const int r = cl + it * 4;
       const int fy = min(max(cy0 + ciy - 4 + r, 0), chh - 1);
-      const Pix *row = ref_c + (size_t)fy * L.stride_uv;
+      const Pix *row = ref_c + row_off(fy, L.stride_uv);
       stage_window_row<CW, Pix>(row, cx0 + cix - 4, cw, wc + r * CWS);
     }
     int sc[4], pc[4], rc[4];
-    load_row<4>(src_c + (size_t)(cy0 + cl) * L.stride_uv + cx0, sc);
+    load_row<4>(src_c + row_off(cy0 + cl, L.stride_uv) + cx0, sc);
     AV1MI_GROUP_SYNC();
     mc_row<4, ES, 2, 6>(wc, CWS, imc, cl, mvx & 15, mvy & 15, s_filt[1], bd, pc);
     nz |= code_residual<4, Pix>(T + pl * 32, cl, sc, pc, L.dc_q, L.ac_q, L.dc_quant, L.ac_quant,
                                 L.lev[1 + pl] + (size_t)f * cw * chh + (size_t)blk * 16 + cl * 4, rc);
-    store_row<4>(rec_c + (size_t)(cy0 + cl) * L.stride_uv + cx0, rc);
+    store_row<4>(rec_c + row_off(cy0 + cl, L.stride_uv) + cx0, rc);
   }
   nz = group_or<8>(nz);
   if (lane == 0) L.skip[(size_t)f * bw * bh + blk] = nz == 0;

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void k_lr(LrLaunch L) {
   if (type == 0) {   // no restoration: copy the CDEF output
     for (int i = tid; i < bh * bw; i += 256) {
       const int r = i / bw, c = i - r * bw;
-      out[(size_t)(y0 + r) * L.stride + X0 + c] = cdef[(size_t)(y0 + r) * L.stride + X0 + c];
+      out[row_off(y0 + r, L.stride) + X0 + c] = cdef[row_off(y0 + r, L.stride) + X0 + c];
     }
     return;
   }
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void k_lr(LrLaunch L) {
         const Pix *p = cdef;
         if (y < sstart) { y = max(sstart - 2, y); p = dbl; }
         else if (y > send) { y = min(send + 2, y); p = dbl; }
-        const Pix *q = p + (size_t)y * L.stride + X0 - 4 + 4 * g;
+        const Pix *q = p + row_off(y, L.stride) + X0 - 4 + 4 * g;
         if (((uintptr_t)q & (4 * sizeof(Pix) - 1)) == 0) {
           if constexpr (sizeof(Pix) == 1) o[k].x = *reinterpret_cast<const uint32_t *>(q);
           else o[k] = *reinterpret_cast<const uint2 *>(q);
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void k_lr(LrLaunch L) {
       const Pix *p = cdef;
       if (y < sstart) { y = max(sstart - 2, y); p = dbl; }
       else if (y > send) { y = min(send + 2, y); p = dbl; }
-      src[r * SS + c + 1] = p[(size_t)y * L.stride + x];
+      src[r * SS + c + 1] = p[row_off(y, L.stride) + x];
     }
   }
   __syncthreads();
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void k_lr(LrLaunch L) {
           int o[4];
 #pragma unroll
           for (int k = 0; k < 4; k++) o[k] = min(max((half ? so[k] : se[k]) >> 11, 0), maxpix);
-          Pix *d = out + (size_t)(y0 + r + half) * L.stride + X0 + c;
+          Pix *d = out + row_off(y0 + r + half, L.stride) + X0 + c;
           if (((uintptr_t)d & (4 * sizeof(Pix) - 1)) == 0) {
             if constexpr (sizeof(Pix) == 1) *reinterpret_cast<uint32_t *>(d) = (uint32_t)o[0] | ((uint32_t)o[1] << 8) | ((uint32_t)o[2] << 16) | ((uint32_t)o[3] << 24);
             else { uint2 u; u.x = (uint32_t)o[0] | ((uint32_t)o[1] << 16); u.y = (uint32_t)o[2] | ((uint32_t)o[3] << 16); *reinterpret_cast<uint2 *>(d) = u; }
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void k_lr(LrLaunch L) {
       int sum = 0;
 #pragma unroll
       for (int t = 0; t < 7; t++) sum += vf[t] * inter[(r + t) * MAXW + c];
-      out[(size_t)(y0 + r) * L.stride + X0 + c] = (Pix)min(max((sum + 1024) >> 11, 0), maxpix);
+      out[row_off(y0 + r, L.stride) + X0 + c] = (Pix)min(max((sum + 1024) >> 11, 0), maxpix);
     }
     return;
   }
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void k_lr(LrLaunch L) {
     int v = w1 * u;
     v += w0 * (r0 ? flt[0][k] : u);
     v += w2 * (r1 ? flt[1][k] : u);
-    out[(size_t)(y0 + i) * L.stride + X0 + j] = (Pix)min(max((v + 1024) >> 11, 0), maxpix);
+    out[row_off(y0 + i, L.stride) + X0 + j] = (Pix)min(max((v + 1024) >> 11, 0), maxpix);
   }
 }
 
