@@ -8,6 +8,14 @@
 
 namespace av1mi {
 
+// a 24-bit multiply the compiler cannot turn back into a 32-bit one (it does when it can bound the operands: v_mul_lo_u32 is
+// four passes on CDNA, v_mul_u32_u24 one); both operands non-negative and below 2^24
+__device__ __forceinline__ int mul24_pinned(int a, int b) {
+  int d;
+  asm("v_mul_u32_u24 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+
 template <int N, typename Pix> __device__ __forceinline__ void load_row(const Pix *p, int *v) {
   if constexpr (sizeof(Pix) == 1) {
 #pragma unroll
@@ -78,10 +86,10 @@ __device__ __forceinline__ int code_residual(int32_t *T, int lane, const int *s,
     const int v = round2(xv[c], -fwd_shift(B, B, 2));
     const bool neg = v < 0;
     int a = min(neg ? -v : v, 1 << 20), l = 0;
-    l = __mul24(min(a + rnd, 32767), quant) >> 16;    // 15 x 15 bits: a full-rate 24-bit multiply (a 32-bit one is four passes); <= 8191
+    l = mul24_pinned(min(a + rnd, 32767), quant) >> 16;    // 15 x 15 bits: a full-rate 24-bit multiply (a 32-bit one is four passes); <= 8191
     l = (a << 1) >= q ? l : 0;
     lv[c] = neg ? -l : l;
-    const int d = __mul24(l, q) & 0xFFFFFF;            // l <= 8191, q < 2^15
+    const int d = mul24_pinned(l, q) & 0xFFFFFF;            // l <= 8191, q < 2^15
     xv[c] = min(max(neg ? -d : d, minv), maxv);
   }
 #pragma unroll

@@ -197,12 +197,12 @@ __global__ __launch_bounds__(256, BS == 8 ? 3 : 1) void k_intra_pipe(IntraPipeLa
     int ft = 0, ftc = 0;
     if (have_top) { const int m = col_my[bx], mc = col_mc[bx]; ft |= m >= 9 && m <= 11; ftc |= mc >= 9 && mc <= 11; }
     if (have_left) { const int m = row_my[by], mc = row_mc[by]; ft |= m >= 9 && m <= 11; ftc |= mc >= 9 && mc <= 11; }
-    const size_t blk = (size_t)fy * bw + fx;
+    const size_t blk = row_off(fy, bw) + fx;        // 24-bit multiplies: see row_off
     {
 #ifdef AV1MI_EXP_TILED   // timing experiment only (wrong pixels): planes addressed as if block-tiled, 64 contiguous bytes per block
       const size_t off = blk * BS * BS + lane * BS;
 #else
-      const size_t off = ((size_t)fy * BS + lane) * L.stride_y + (size_t)fx * BS;
+      const size_t off = row_off(fy * BS + lane, L.stride_y) + (size_t)(fx * BS);
 #endif
       const int m = code_block<BS, BS, Pix>(Y, lane, bx, by, N, have_top ? BS : 0, have_tr ? BS : 0, have_left ? BS : 0,
                                              have_bl ? BS : 0, ft, L.dc_q, L.ac_q, L.dc_quant, L.ac_quant, src_y + off, rec_y + off,
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256, BS == 8 ? 3 : 1) void k_intra_pipe(IntraPipeLa
 #ifdef AV1MI_EXP_TILED
       const size_t off = blk * CS * CS + cl * CS;
 #else
-      const size_t off = ((size_t)fy * CS + cl) * L.stride_uv + (size_t)fx * CS;
+      const size_t off = row_off(fy * CS + cl, L.stride_uv) + (size_t)(fx * CS);
 #endif
       const int m = code_block<CS, BS, Pix>(Cp, cl, bx, by, N, have_top ? CS : 0, have_tr ? CS : 0, have_left ? CS : 0,
                                              have_bl ? CS : 0, ftc, L.dc_q, L.ac_q, L.dc_quant, L.ac_quant, src_c + off, rec_c + off,

@@ -59,8 +59,16 @@ AV1MI_HD int32_t sin128c(int bit, int angle) { return cos128c(bit, angle - 64); 
 // first-rotation angle of the odd block [M,2M): frequency k = 1 + 2*brev(log2 M, i)
 AV1MI_HD int r0_angle(int M, int i) { return 64 - (1 + 2 * brevc(ilog2c(M), i)) * 32 / M; }
 
+// w0 * a + w1 * b rounded: two 24-bit multiply-adds (full rate).  Written with __mul24 the compiler, which knows the operands'
+// ranges from the stage clamps, turned a good part of the products back into 32-bit multiplies and 64-bit multiply-adds
+// (v_mul_lo_u32 / v_mad_u64_u32: four passes each on CDNA) — a third of the multiplies of the fused kernels' residual tail.
+// w0, w1 are the rotation's constants (uniform); a, b fit 24 bits by the stage clamps (header comment).
 template <int BIT> AV1MI_DI int32_t hbtf(int32_t w0, int32_t a, int32_t w1, int32_t b) {
-  return (__mul24(w0, a) + __mul24(w1, b) + (1 << (BIT - 1))) >> BIT;
+  int32_t t;
+  const int32_t rnd = 1 << (BIT - 1);
+  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(t) : "v"(a), "s"(w0), "v"(rnd));
+  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(t) : "v"(b), "s"(w1), "v"(t));
+  return t >> BIT;
 }
 // clamp to a signed RANGE-bit value (one v_med3_i32); RANGE == 0: no clamp
 template <int RANGE> AV1MI_DI int32_t clampr(int32_t v) {
