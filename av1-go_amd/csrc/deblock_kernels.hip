@@ -103,20 +103,19 @@ __device__ __forceinline__ void lf_filter(int (&px)[16], int len, LfThr t, int b
 #undef Q
 }
 
-// edge decision for the unit `cur` against `prev` (the unit on the other side): returns filter length or 0
+// edge decision for the unit `cur` against `prev` (the unit on the other side): returns filter length or 0.  Branch-free: as
+// nested early returns it compiled to five levels of exec-mask save / branch per item.
 __device__ __forceinline__ int lf_edge(uint32_t cur, uint32_t prev, int pass, int pos, bool is_chroma, int &lvl) {
-  if (cur == 0xFFFFFFFFu || prev == 0xFFFFFFFFu) return 0;   // outside the plane
-  const int tx = pass == 0 ? (cur & 15) : ((cur >> 4) & 15);
-  if (pos & ((1 << tx) - 1)) return 0;                      // not a transform edge
+  const int tx = pass == 0 ? (cur & 15) : ((cur >> 4) & 15), ptx = pass == 0 ? (prev & 15) : ((prev >> 4) & 15);
   const int flags = cur >> 24;
-  if ((flags & 1) && !((flags >> (1 + pass)) & 1)) return 0; // skipped inter block, inner edge
-  const int ptx = pass == 0 ? (prev & 15) : ((prev >> 4) & 15);
-  const int base = 1 << min(tx, ptx);
-  lvl = (cur >> (8 + 8 * pass)) & 255;
-  if (lvl == 0) lvl = (prev >> (8 + 8 * pass)) & 255;
-  if (lvl == 0) return 0;
-  if (is_chroma) return base == 4 ? 4 : 6;
-  return base == 4 ? 4 : base == 8 ? 8 : 14;
+  const int outside = (cur == 0xFFFFFFFFu) | (prev == 0xFFFFFFFFu);                 // outside the plane
+  const int not_edge = (pos & ((1 << tx) - 1)) != 0;                                 // not a transform edge
+  const int inner_skip = (flags & 1) & ~(flags >> (1 + pass)) & 1;                   // skipped inter block, inner edge
+  const int lc = (cur >> (8 + 8 * pass)) & 255, lp = (prev >> (8 + 8 * pass)) & 255;
+  lvl = lc ? lc : lp;
+  const int b = min(tx, ptx);                                                        // log2 of the narrower transform
+  const int len = is_chroma ? (b == 2 ? 4 : 6) : (b == 2 ? 4 : b == 3 ? 8 : 14);
+  return (outside | not_edge | inner_skip | (lvl == 0)) ? 0 : len;
 }
 
 // One edge line of compile-time filter length: reads only the 2 x HALF samples that length can look at (p3..q3 for 8, p6..q6
