@@ -33,19 +33,20 @@ __device__ __forceinline__ void lf_filter(int (&px)[16], int len, LfThr t, int b
   const int lim = t.lim << sh, blim = t.mblim << sh, hevt = t.hev << sh, one = 1 << sh;
 #define P(i) px[7 - (i)]
 #define Q(i) px[8 + (i)]
-  bool mask = abs(P(1) - P(0)) <= lim && abs(Q(1) - Q(0)) <= lim && abs(P(0) - Q(0)) * 2 + abs(P(1) - Q(1)) / 2 <= blim;
-  bool flat = false, flat2 = false;
-  if (len >= 6) {
-    mask = mask && abs(P(2) - P(1)) <= lim && abs(Q(2) - Q(1)) <= lim;
-    flat = abs(P(1) - P(0)) <= one && abs(Q(1) - Q(0)) <= one && abs(P(2) - P(0)) <= one && abs(Q(2) - Q(0)) <= one;
-  }
-  if (len >= 8) {
-    mask = mask && abs(P(3) - P(2)) <= lim && abs(Q(3) - Q(2)) <= lim;
-    flat = flat && abs(P(3) - P(0)) <= one && abs(Q(3) - Q(0)) <= one;
-  }
+  // The masks are conjunctions of |a - b| <= threshold tests: each group is ONE comparison of the largest difference, and a
+  // difference of two samples is one v_sad_u32.  Written as a chain of abs() <= t && ... every term was three instructions and
+  // a short-circuit branch (exec-mask save + s_cbranch) of its own.
+  // (inline asm: there is no builtin for v_sad_u32, and __usad() is a library routine that compiles to min, max, subtract)
+  auto ad = [](int a, int b) { int d; asm("v_sad_u32 %0, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b)); return d; };
+  const int d10 = max(ad(P(1), P(0)), ad(Q(1), Q(0)));
+  int m = d10, fl = d10;
+  if (len >= 6) { m = max(m, max(ad(P(2), P(1)), ad(Q(2), Q(1)))); fl = max(fl, max(ad(P(2), P(0)), ad(Q(2), Q(0)))); }
+  if (len >= 8) { m = max(m, max(ad(P(3), P(2)), ad(Q(3), Q(2)))); fl = max(fl, max(ad(P(3), P(0)), ad(Q(3), Q(0)))); }
+  const bool mask = (m <= lim) & (ad(P(0), Q(0)) * 2 + (ad(P(1), Q(1)) >> 1) <= blim);
+  const bool flat = len >= 6 && fl <= one;
+  bool flat2 = false;
   if (len == 14)
-    flat2 = abs(P(4) - P(0)) <= one && abs(Q(4) - Q(0)) <= one && abs(P(5) - P(0)) <= one && abs(Q(5) - Q(0)) <= one &&
-            abs(P(6) - P(0)) <= one && abs(Q(6) - Q(0)) <= one;
+    flat2 = max(max(max(ad(P(4), P(0)), ad(Q(4), Q(0))), max(ad(P(5), P(0)), ad(Q(5), Q(0)))), max(ad(P(6), P(0)), ad(Q(6), Q(0)))) <= one;
   if (!mask) return;   // filter4 with mask == 0 leaves all four samples unchanged
   if (flat && flat2) {
     // 13 taps [1 1 1 1 1 2 2 2 1 1 1 1 1], positions clamped to p6 / q6
@@ -89,7 +90,7 @@ __device__ __forceinline__ void lf_filter(int (&px)[16], int len, LfThr t, int b
   } else {
     const int lo = -(128 << sh), hi = (128 << sh) - 1, t80 = 128 << sh;
     const int ps1 = P(1) - t80, ps0 = P(0) - t80, qs0 = Q(0) - t80, qs1 = Q(1) - t80;
-    const bool hev = abs(P(1) - P(0)) > hevt || abs(Q(1) - Q(0)) > hevt;
+    const bool hev = d10 > hevt;
     int f = hev ? min(max(ps1 - qs1, lo), hi) : 0;
     f = min(max(f + 3 * (qs0 - ps0), lo), hi);
     const int f1 = min(f + 4, hi) >> 3, f2 = min(f + 3, hi) >> 3;
