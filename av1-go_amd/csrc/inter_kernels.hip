@@ -111,11 +111,11 @@ __global__ __launch_bounds__(256) void k_me_int(InterLaunch L) {
   for (int u0 = 0; u0 < 16 * per; u0 += 64) {
     const int u = u0 + lane;
     if (u < 16 * per) {
-      const int bi = (int)(((float)u + 0.5f) * inv_per), t = u - bi * per, b = wave + 4 * bi;
+      const int bi = (int)(((float)u + 0.5f) * inv_per), t = u - __mul24(bi, per), b = wave + 4 * bi;   // (plain products here became 64-bit multiply-adds)
       const int by = b >> 3, bx = b & 7;
       if (sbx * 8 + bx < bw && sby * 8 + by < bh) {
-        const int dp = (int)(((float)t + 0.5f) * inv_ng), g = t - dp * NG;    // dy = 3 dp - R + {0, 1, 2}, dx0 = -R4 + 4 g
-        const uint8_t *p = win + (by * 8 + HD * dp) * WS + bx * 8 + 4 * g;
+        const int dp = (int)(((float)t + 0.5f) * inv_ng), g = t - __mul24(dp, NG);    // dy = 3 dp - R + {0, 1, 2}, dx0 = -R4 + 4 g
+        const uint8_t *p = win + __mul24(by * 8 + HD * dp, WS) + bx * 8 + 4 * g;
         const uint8_t *s = srct + (by * 8) * 64 + bx * 8;
         uint2 sr[8];
 #pragma unroll
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void k_me_int(InterLaunch L) {
         // the lower rank.  Branch-free: a displacement outside +-R gets rank ~0, which turns its key into ~0 under the OR.
         // dx_i = 4 g - R4 + i is in range for i in [imin, imax]; row h of the triple exists when 3 dp + h < NC.
         const int imin = R4 - R - 4 * g, imax = R4 + R - 4 * g;
-        const unsigned rank0 = (unsigned)(HD * dp * NC + 4 * g - R4 + R + 1);
+        const unsigned rank0 = (unsigned)(__mul24(HD * dp, NC) + 4 * g - R4 + R + 1);
         unsigned inv_h[HD];
 #pragma unroll
         for (int h = 0; h < HD; h++) inv_h[h] = (unsigned)((NC - 1 - h - HD * dp) >> 31);

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void k_lr(LrLaunch L) {
         const int r = (int)(((float)i + 0.5f) * inv_ng), g = i - r * ng;
         uint2 w = o[k];
         if constexpr (sizeof(Pix) == 1) { const uint32_t u = o[k].x; w.x = __builtin_amdgcn_perm(0u, u, 0x0c010c00u); w.y = __builtin_amdgcn_perm(0u, u, 0x0c030c02u); }
-        *reinterpret_cast<uint2 *>(src + r * SS + 4 * g) = w;
+        *reinterpret_cast<uint2 *>(src + __mul24(r, SS) + 4 * g) = w;
       }
     }
   } else {
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void k_lr(LrLaunch L) {
       const float inv_q4 = 1.0f / (float)q4;
       for (int i = tid; i < (bh + 6) * q4; i += 256) {
         const int r = (int)(((float)i + 0.5f) * inv_q4), c = (i - r * q4) * 4;
-        const uint2 *p = reinterpret_cast<const uint2 *>(src + r * SS + c);
+        const uint2 *p = reinterpret_cast<const uint2 *>(src + __mul24(r, SS) + c);   // (r * SS became a 64-bit multiply-add)
         const uint2 a = p[0], b = p[1], e = p[2];
         const uint32_t d[6] = { a.x, a.y, b.x, b.y, e.x, e.y };
         uint32_t A[6];
