@@ -228,7 +228,8 @@ __global__ __launch_bounds__(256) void k_cdef(CdefLaunch L) {
       // squares of sums of at most 8 values in [-128, 127] (<= 2^20) times weights <= 840: 24-bit multiplies (a 32-bit integer
       // multiply is four passes)
       constexpr int div_table[9] = { 0, 840, 420, 280, 210, 168, 140, 120, 105 };
-      auto sq = [](int v) { return __mul24(v, v); };
+      // (pinned by inline asm: the compiler, which can bound the sums, turned __mul24(v, v) back into v_mul_lo_u32 / v_mad_u64_u32)
+      auto sq = [](int v) { int d; asm("v_mul_i32_i24 %0, %1, %1" : "=v"(d) : "v"(v)); return d; };
       int cost[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
 #pragma unroll
       for (int i = 0; i < 8; i++) { cost[2] += sq(partial[2][i]); cost[6] += sq(partial[6][i]); }

@@ -92,7 +92,9 @@ __device__ __forceinline__ void lf_filter(int (&px)[16], int len, LfThr t, int b
     const int ps1 = P(1) - t80, ps0 = P(0) - t80, qs0 = Q(0) - t80, qs1 = Q(1) - t80;
     const bool hev = d10 > hevt;
     int f = hev ? min(max(ps1 - qs1, lo), hi) : 0;
-    f = min(max(f + 3 * (qs0 - ps0), lo), hi);
+    // f + 3 (qs0 - ps0) as one 24-bit multiply-add (the compiler made it a 64-bit one: four passes)
+    { const int dq = qs0 - ps0; asm("v_mad_i32_i24 %0, %1, 3, %0" : "+v"(f) : "v"(dq)); }
+    f = min(max(f, lo), hi);
     const int f1 = min(f + 4, hi) >> 3, f2 = min(f + 3, hi) >> 3;
     Q(0) = min(max(qs0 - f1, lo), hi) + t80;
     P(0) = min(max(ps0 + f2, lo), hi) + t80;
