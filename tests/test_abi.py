@@ -46,3 +46,20 @@ def test_null_context_is_rejected(av1mi):
     lib = av1mi.load()
     assert lib.av1mi_sync(None) == -1
     assert lib.av1mi_last_error(None) == b"null context"
+
+
+@pytest.mark.gpu
+def test_device_copy_and_memset(ctx):
+    """av1mi_copy / av1mi_memset on the context's stream: bytes arrive, null pointers are refused with an error text"""
+    import numpy as np
+    rng = np.random.default_rng(3)
+    a = rng.integers(0, 256, 1 << 20, dtype=np.uint8)
+    d_a, d_b = ctx.to_device(a), ctx.alloc(a.nbytes)
+    ctx.memset(d_b, 7, a.nbytes)
+    assert (d_b.download(a.shape, a.dtype) == 7).all()
+    ctx.copy(d_b, d_a, a.nbytes)
+    assert (d_b.download(a.shape, a.dtype) == a).all()
+    rc = ctx.lib.av1mi_copy(ctx.h, None, None, C.c_size_t(16))
+    assert rc < 0 and b"null" in ctx.lib.av1mi_last_error(ctx.h)
+    d_a.free()
+    d_b.free()
