@@ -37,7 +37,9 @@ __constant__ int16_t kRegular4[16][8] = {
 // mirrored by the oracle), which lets one v_qsad_pk_u16_u8 score FOUR horizontally adjacent candidate vectors against
 // four source samples at once.  A lane owns (dy, group of 4 dx): per block row it reads 12 reference bytes (three
 // aligned dwords) and issues two QSADs with the row's two source dwords, which all lanes read from the same LDS address.
-template <typename Pix>
+// RC: the search range as a compile-time constant (0 = take L.range at run time): with the default +-8 every quotient, item
+// count and validity bound below is a constant.
+template <typename Pix, int RC>
 __global__ __launch_bounds__(256) void k_me_int(InterLaunch L) {
   // window row stride in bytes: 35 dwords.  Consecutive lanes walk (dy pair, dx group): 5 consecutive dwords per dy pair, pairs
   // two rows apart.  The window reads are ds_read2_b32 (32 banks per 32-lane group): with 28-dword rows two rows are 24 banks
@@ -49,7 +51,7 @@ __global__ __launch_bounds__(256) void k_me_int(InterLaunch L) {
   __shared__ __attribute__((aligned(16))) uint8_t srct[64 * 64];
   __shared__ uint32_t s_best[64];                    // per 8x8 block: min of (SAD, rank)
   constexpr int sh = sizeof(Pix) == 1 ? 0 : 2;
-  const int tid = threadIdx.x, R = L.range, R4 = (R + 3) & ~3, NC = 2 * R + 1;
+  const int tid = threadIdx.x, R = RC ? RC : L.range, R4 = (R + 3) & ~3, NC = 2 * R + 1;
   const int WDX = 64 + 2 * R4 + 4, WDY = 64 + 2 * R + 2;    // window columns start at x - R4 (4-aligned), rows at y - R; two more rows for the unused part of the last dy triple
   const int sbw = (L.w + 63) / 64;
   const Tile3 tl = xcd_tile(sbw, (L.h + 63) / 64, L.nframes);
@@ -572,8 +574,13 @@ hipError_t launch_me_int(const InterLaunch &L, hipStream_t s) {
   if (L.nframes <= 0) return hipSuccess;
   const int sbs = ((L.w + 63) / 64) * ((L.h + 63) / 64);
   const dim3 g1((unsigned)(sbs * L.nframes));   // 1-D: the kernel orders the tiles (xcd_tile)
-  if (L.bd == 8) hipLaunchKernelGGL(k_me_int<uint8_t>, g1, dim3(256), 0, s, L);
-  else hipLaunchKernelGGL(k_me_int<uint16_t>, g1, dim3(256), 0, s, L);
+  if (L.range == 8) {
+    if (L.bd == 8) hipLaunchKernelGGL((k_me_int<uint8_t, 8>), g1, dim3(256), 0, s, L);
+    else hipLaunchKernelGGL((k_me_int<uint16_t, 8>), g1, dim3(256), 0, s, L);
+  } else {
+    if (L.bd == 8) hipLaunchKernelGGL((k_me_int<uint8_t, 0>), g1, dim3(256), 0, s, L);
+    else hipLaunchKernelGGL((k_me_int<uint16_t, 0>), g1, dim3(256), 0, s, L);
+  }
   return hipGetLastError();
 }
 hipError_t launch_inter_pipe(const InterLaunch &L, hipStream_t s) {
