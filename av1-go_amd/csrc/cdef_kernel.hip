@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void k_cdef(CdefLaunch L) {
   if (tid < 48) cdef_fill_offsets<YS>(offy, tid); else if (tid >= 64 && tid < 112) cdef_fill_offsets<CSZ>(offc, tid - 64);
   const Tile3 tl = xcd_tile((L.w + 63) / 64, (L.h + 63) / 64, L.nframes);
   const int sbx = tl.x, sby = tl.y, f = tl.z;
-  const int bd = L.bd, cs = bd - 8;
+  constexpr int bd = sizeof(Pix) == 1 ? 8 : 10, cs = bd - 8;   // the launch picks the instantiation by L.bd (8 or 10)
   const Pix *sy = reinterpret_cast<const Pix *>(L.src[0]) + (size_t)f * L.h * L.stride_y;
   Pix *dy = reinterpret_cast<Pix *>(L.dst[0]) + (size_t)f * L.h * L.stride_y;
   const int cw = L.w / 2, chh = L.h / 2;

@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void k_deblock(DeblockLaunch L) {
       const int len = lf_edge(mis[(ly >> 2) * MW + uc], mis[(ly >> 2) * MW + uc - 1], 0, fx, L.is_chroma, lvl);
       if (!len) continue;
       // (lf_line writes only what its length can modify: a neighbouring edge 4 samples away owns the rest)
-      lf_line_any(tile + ly * LS + 4 * uc, 1, len, lf_limits(lvl, L.sharpness), L.bd);
+      lf_line_any(tile + ly * LS + 4 * uc, 1, len, lf_limits(lvl, L.sharpness), sizeof(Pix) == 1 ? 8 : 10);
     }
   }
   __syncthreads();
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void k_deblock(DeblockLaunch L) {
       int lvl = 0;
       const int len = lf_edge(mis[ur * MW + (lx >> 2)], mis[(ur - 1) * MW + (lx >> 2)], 1, fy, L.is_chroma, lvl);
       if (!len) continue;
-      lf_line_any(tile + (4 * ur) * LS + lx, LS, len, lf_limits(lvl, L.sharpness), L.bd);
+      lf_line_any(tile + (4 * ur) * LS + lx, LS, len, lf_limits(lvl, L.sharpness), sizeof(Pix) == 1 ? 8 : 10);
     }
   }
   __syncthreads();

@@ -33,7 +33,8 @@ __global__ __launch_bounds__(256) void k_lr(LrLaunch L) {
   uint16_t *Abuf = reinterpret_cast<uint16_t *>(scratch);                      // self-guided: (SH+2) x (tw+2)
   int32_t *Bbuf = reinterpret_cast<int32_t *>(scratch + (MAXH + 2) * AS * 2);
 
-  const int tid = threadIdx.x, bd = L.bd, ss = L.ss;
+  constexpr int bd = sizeof(Pix) == 1 ? 8 : 10;              // the launch picks the instantiation by L.bd (8 or 10)
+  const int tid = threadIdx.x, ss = L.ss;
   const int SH = 64 >> ss, off = 8 >> ss;
   const int tw = L.unit_size < 64 ? L.unit_size : 64;
   const Tile3 tl = xcd_tile((L.w + tw - 1) / tw, (L.h + off + SH - 1) / SH, L.nframes);
