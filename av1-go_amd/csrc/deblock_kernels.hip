@@ -144,7 +144,9 @@ __device__ __forceinline__ void lf_line_any(uint16_t *p, int step, int len, LfTh
   else lf_line<14>(p, step, t, bd);
 }
 
-template <typename Pix, int TW, int TH>
+// CHROMA: the plane's filter-length rule (a launch is one plane); SHARP0: sharpness 0, the only value the encoder loops use
+// (other values take the run-time path) — both fold the per-line limit arithmetic.
+template <typename Pix, int TW, int TH, bool CHROMA, bool SHARP0>
 __global__ __launch_bounds__(256) void k_deblock(DeblockLaunch L) {
   // Halo of 8: an edge needs at most p6..q6 (13-tap filter) plus the flatness tests up to p6/q6; an edge whose filter can
   // reach the window lies in [0, TW] x [0, TH], so source samples in [-8, TW + 8) x [-8, TH + 8) are all that is ever read
@@ -228,10 +230,10 @@ __global__ __launch_bounds__(256) void k_deblock(DeblockLaunch L) {
       const int fx = X0 + 4 * uc, fy = Y0 + ly;
       if (fx <= 0 || fy < 0 || fy >= L.h) continue;
       int lvl = 0;
-      const int len = lf_edge(mis[(ly >> 2) * MW + uc], mis[(ly >> 2) * MW + uc - 1], 0, fx, L.is_chroma, lvl);
+      const int len = lf_edge(mis[(ly >> 2) * MW + uc], mis[(ly >> 2) * MW + uc - 1], 0, fx, CHROMA, lvl);
       if (!len) continue;
       // (lf_line writes only what its length can modify: a neighbouring edge 4 samples away owns the rest)
-      lf_line_any(tile + ly * LS + 4 * uc, 1, len, lf_limits(lvl, L.sharpness), sizeof(Pix) == 1 ? 8 : 10);
+      lf_line_any(tile + ly * LS + 4 * uc, 1, len, lf_limits(lvl, SHARP0 ? 0 : L.sharpness), sizeof(Pix) == 1 ? 8 : 10);
     }
   }
   __syncthreads();
@@ -243,9 +245,9 @@ __global__ __launch_bounds__(256) void k_deblock(DeblockLaunch L) {
       const int fx = X0 + lx, fy = Y0 + 4 * ur;
       if (fy <= 0 || fx >= L.w) continue;
       int lvl = 0;
-      const int len = lf_edge(mis[ur * MW + (lx >> 2)], mis[(ur - 1) * MW + (lx >> 2)], 1, fy, L.is_chroma, lvl);
+      const int len = lf_edge(mis[ur * MW + (lx >> 2)], mis[(ur - 1) * MW + (lx >> 2)], 1, fy, CHROMA, lvl);
       if (!len) continue;
-      lf_line_any(tile + (4 * ur) * LS + lx, LS, len, lf_limits(lvl, L.sharpness), sizeof(Pix) == 1 ? 8 : 10);
+      lf_line_any(tile + (4 * ur) * LS + lx, LS, len, lf_limits(lvl, SHARP0 ? 0 : L.sharpness), sizeof(Pix) == 1 ? 8 : 10);
     }
   }
   __syncthreads();
@@ -266,8 +268,14 @@ __global__ __launch_bounds__(256) void k_deblock(DeblockLaunch L) {
 hipError_t launch_deblock(const DeblockLaunch &L, hipStream_t s) {
   constexpr int TW = 64, TH = 64;
   const dim3 grid((unsigned)(((L.w + TW - 1) / TW) * ((L.h + TH - 1) / TH) * L.nframes));   // 1-D: the kernel orders the tiles (xcd_tile)
-  if (L.bd == 8) hipLaunchKernelGGL((k_deblock<uint8_t, TW, TH>), grid, dim3(256), 0, s, L);
-  else hipLaunchKernelGGL((k_deblock<uint16_t, TW, TH>), grid, dim3(256), 0, s, L);
+  const dim3 blk(256);
+#define AV1MI_DBL(PIX, C, S0) hipLaunchKernelGGL((k_deblock<PIX, TW, TH, C, S0>), grid, blk, 0, s, L)
+  const bool c = L.is_chroma != 0, s0 = L.sharpness == 0;
+  if (L.bd == 8) { if (c) { if (s0) AV1MI_DBL(uint8_t, true, true); else AV1MI_DBL(uint8_t, true, false); }
+                   else   { if (s0) AV1MI_DBL(uint8_t, false, true); else AV1MI_DBL(uint8_t, false, false); } }
+  else           { if (c) { if (s0) AV1MI_DBL(uint16_t, true, true); else AV1MI_DBL(uint16_t, true, false); }
+                   else   { if (s0) AV1MI_DBL(uint16_t, false, true); else AV1MI_DBL(uint16_t, false, false); } }
+#undef AV1MI_DBL
   return hipGetLastError();
 }
 
