@@ -23,7 +23,8 @@ __device__ constexpr int kSgrParams[16][4] = {
   { 2, 47, 1, 1079 }, { 2, 37, 1, 996 }, { 2, 30, 1, 925 }, { 2, 25, 1, 863 }, { 0, -1, 1, 2589 }, { 0, -1, 1, 1618 },
   { 0, -1, 1, 1177 }, { 0, -1, 1, 925 }, { 2, 56, 0, -1 }, { 2, 22, 0, -1 } };
 
-template <typename Pix>
+// SUBY: vertical subsampling of the plane (0 luma, 1 chroma of 4:2:0) — stripe height and offset become constants
+template <typename Pix, int SUBY>
 __global__ __launch_bounds__(256) void k_lr(LrLaunch L) {
   constexpr int MAXH = 64, MAXW = 64, SS = MAXW + 16;      // source tile row stride (u16): tile column 0 = X0 - 4
   constexpr int AS = MAXW + 2 + 2;                         // A/B row stride
@@ -34,8 +35,8 @@ __global__ __launch_bounds__(256) void k_lr(LrLaunch L) {
   int32_t *Bbuf = reinterpret_cast<int32_t *>(scratch + (MAXH + 2) * AS * 2);
 
   constexpr int bd = sizeof(Pix) == 1 ? 8 : 10;              // the launch picks the instantiation by L.bd (8 or 10)
-  const int tid = threadIdx.x, ss = L.ss;
-  const int SH = 64 >> ss, off = 8 >> ss;
+  const int tid = threadIdx.x;
+  constexpr int SH = 64 >> SUBY, off = 8 >> SUBY;
   const int tw = L.unit_size < 64 ? L.unit_size : 64;
   const Tile3 tl = xcd_tile((L.w + tw - 1) / tw, (L.h + off + SH - 1) / SH, L.nframes);
   const int X0 = tl.x * tw, stripe = tl.y, f = tl.z;
@@ -282,8 +283,13 @@ hipError_t launch_lr(const LrLaunch &L, hipStream_t s) {
   const int SH = 64 >> L.ss, off = 8 >> L.ss;
   const int tw = L.unit_size < 64 ? L.unit_size : 64;
   const dim3 grid((unsigned)(((L.w + tw - 1) / tw) * ((L.h + off + SH - 1) / SH) * L.nframes));   // 1-D: the kernel orders the tiles (xcd_tile)
-  if (L.bd == 8) hipLaunchKernelGGL(k_lr<uint8_t>, grid, dim3(256), 0, s, L);
-  else hipLaunchKernelGGL(k_lr<uint16_t>, grid, dim3(256), 0, s, L);
+  if (L.ss) {
+    if (L.bd == 8) hipLaunchKernelGGL((k_lr<uint8_t, 1>), grid, dim3(256), 0, s, L);
+    else hipLaunchKernelGGL((k_lr<uint16_t, 1>), grid, dim3(256), 0, s, L);
+  } else {
+    if (L.bd == 8) hipLaunchKernelGGL((k_lr<uint8_t, 0>), grid, dim3(256), 0, s, L);
+    else hipLaunchKernelGGL((k_lr<uint16_t, 0>), grid, dim3(256), 0, s, L);
+  }
   return hipGetLastError();
 }
 
