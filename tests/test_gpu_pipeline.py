@@ -3,6 +3,8 @@ the oracle chain, frame by frame, bit-exact; plus the quality sanity the metric 
 import numpy as np
 import pytest
 
+import synth
+
 pytestmark = pytest.mark.gpu
 
 
@@ -152,3 +154,36 @@ def test_closed_gop_chain_coded_records(ctx, O, use_async):
         for t in range(gop):
             assert gp.coded_records(t) == want[t], "frame index %d" % t
     gp.close()
+
+
+def test_job_edge_cases_and_error_behaviour(ctx, av1mi):
+    """the boundary's error contract on the fused pipelines: an empty segment is a no-op that touches nothing, malformed jobs are
+    refused with a negative code and a message (never a launch), 12-bit content is rejected (only 8 and 10 are built)"""
+    w, h = 64, 64
+    Y, U, V = synth.frames(w, h, 1, 8, first=0)
+    src = [ctx.to_device(a) for a in (Y, U, V)]
+    rec = [ctx.alloc(a.nbytes) for a in (Y, U, V)]
+    lev = [ctx.alloc(a.size * 2) for a in (Y, U, V)]
+    modes = [ctx.alloc(64), ctx.alloc(64)]
+    for b in rec + lev + modes:
+        ctx.memset(b, 0xAB, 64)
+    def job(width=w, height=h, bd=8, nframes=1, q=100, bs=8):
+        j = av1mi.IntraJob(width, height, bd, nframes, q, bs, width, width // 2)
+        for k, b in zip(("src_y", "src_u", "src_v", "rec_y", "rec_u", "rec_v", "lev_y", "lev_u", "lev_v", "modes_y", "modes_uv"), src + rec + lev + modes):
+            setattr(j, "d_" + k, b.ptr)
+        return j
+    ctx.intra_encode(job(nframes=0))                                   # empty segment: accepted, nothing written
+    ctx.sync()
+    assert (rec[0].download((64,), np.uint8) == 0xAB).all() and (modes[0].download((64,), np.uint8) == 0xAB).all()
+    for bad, what in ((job(bd=12), "bit depth"), (job(width=60), "multiple"), (job(q=256), "qindex"), (job(bs=32), "block"), (job(nframes=-1), "nframes")):
+        rc = ctx.lib.av1mi_intra_encode(ctx.h, __import__("ctypes").byref(bad))
+        msg = ctx.lib.av1mi_last_error(ctx.h).decode()
+        assert rc < 0 and msg, (what, rc, msg)
+    j = job()
+    j.d_rec_y = None
+    assert ctx.lib.av1mi_intra_encode(ctx.h, __import__("ctypes").byref(j)) < 0            # null device pointer
+    ctx.intra_encode(job())                                            # and the context still works afterwards
+    ctx.sync()
+    assert not (rec[0].download(Y.shape, np.uint8) == 0xAB).all()
+    for b in src + rec + lev + modes:
+        b.free()
