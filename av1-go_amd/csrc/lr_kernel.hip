@@ -68,40 +68,52 @@ __global__ __launch_bounds__(256) void k_lr(LrLaunch L) {
     // item -> (row, group) by reciprocal multiplication (exact: items < 2^11 and (i + 0.5) / ng is never within 0.5 / ng of an
     // integer); an integer division by a run-time value is ~25 VALU instructions, and "full ? i / const : i / ng" evaluated both
     const float inv_ng = 1.0f / (float)((bw + 8) / 4);
-    const int ng = (bw + 8) / 4, nitems = (bh + 6) * ng;
-    // All of a lane's loads first, then all of its LDS stores: at most 70 x 18 items = 5 per lane.  As one loop every load was
-    // waited for before the next was issued, and the kernel spent most of its time in those waits (waves stalled 64 % of
-    // their cycles by PMC).
-    constexpr int NIT = ((MAXH + 6) * ((MAXW + 8) / 4) + 255) / 256;
-    uint2 o[NIT];
+    const int ng = (bw + 8) / 4, nmain = bh * ng, nhalo = 6 * ng;
+    // All of a lane's loads first, then all of its LDS stores (as one loop every load was waited for before the next was issued,
+    // and the kernel spent most of its time in those waits: waves stalled 64 % of their cycles by PMC).  The bh rows of the
+    // block itself lie inside the stripe and the picture: plain CDEF rows, no clamping — at most 64 x 18 items = 5 per lane;
+    // only the 3 + 3 halo rows go through get_source_sample's stripe rule — at most 108 items = 1 per lane.  The 8-byte loads
+    // need no alignment check: the hardware takes any address.
+    constexpr int NMAIN = (MAXH * ((MAXW + 8) / 4) + 255) / 256, NHALO = (6 * ((MAXW + 8) / 4) + 255) / 256;
+    uint2 o[NMAIN + NHALO];
+    auto load4 = [&](const Pix *q, uint2 &v) {
+      if constexpr (sizeof(Pix) == 1) v.x = *reinterpret_cast<const uint32_t *>(q);
+      else v = *reinterpret_cast<const uint2 *>(q);
+    };
+    const Pix *cdef0 = cdef + row_off(y0, L.stride) + X0 - 4;
 #pragma unroll
-    for (int k = 0; k < NIT; k++) {
+    for (int k = 0; k < NMAIN; k++) {
       const int i = tid + 256 * k;
-      if (i < nitems) {
+      if (i < nmain) {
         const int r = (int)(((float)i + 0.5f) * inv_ng), g = i - r * ng;
-        int y = min(max(y0 - 3 + r, 0), L.h - 1);
-        const Pix *p = cdef;
-        if (y < sstart) { y = max(sstart - 2, y); p = dbl; }
-        else if (y > send) { y = min(send + 2, y); p = dbl; }
-        const Pix *q = p + row_off(y, L.stride) + X0 - 4 + 4 * g;
-        if (((uintptr_t)q & (4 * sizeof(Pix) - 1)) == 0) {
-          if constexpr (sizeof(Pix) == 1) o[k].x = *reinterpret_cast<const uint32_t *>(q);
-          else o[k] = *reinterpret_cast<const uint2 *>(q);
-        } else {
-          if constexpr (sizeof(Pix) == 1) o[k].x = (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24);
-          else { o[k].x = (uint32_t)q[0] | ((uint32_t)q[1] << 16); o[k].y = (uint32_t)q[2] | ((uint32_t)q[3] << 16); }
-        }
+        load4(cdef0 + row_off(r, L.stride) + 4 * g, o[k]);
       }
     }
 #pragma unroll
-    for (int k = 0; k < NIT; k++) {
+    for (int k = 0; k < NHALO; k++) {
       const int i = tid + 256 * k;
-      if (i < nitems) {
-        const int r = (int)(((float)i + 0.5f) * inv_ng), g = i - r * ng;
-        uint2 w = o[k];
-        if constexpr (sizeof(Pix) == 1) { const uint32_t u = o[k].x; w.x = __builtin_amdgcn_perm(0u, u, 0x0c010c00u); w.y = __builtin_amdgcn_perm(0u, u, 0x0c030c02u); }
-        *reinterpret_cast<uint2 *>(src + __mul24(r, SS) + 4 * g) = w;
+      if (i < nhalo) {
+        const int hr = (int)(((float)i + 0.5f) * inv_ng), g = i - hr * ng;
+        int y = min(max(hr < 3 ? y0 - 3 + hr : y1 - 2 + hr, 0), L.h - 1);       // rows y0 - 3 .. y0 - 1 and y1 + 1 .. y1 + 3
+        const Pix *p = cdef;
+        if (y < sstart) { y = max(sstart - 2, y); p = dbl; }
+        else if (y > send) { y = min(send + 2, y); p = dbl; }
+        load4(p + row_off(y, L.stride) + X0 - 4 + 4 * g, o[NMAIN + k]);
       }
+    }
+    auto store4 = [&](int r, int g, uint2 w) {
+      if constexpr (sizeof(Pix) == 1) { const uint32_t u = w.x; w.x = __builtin_amdgcn_perm(0u, u, 0x0c010c00u); w.y = __builtin_amdgcn_perm(0u, u, 0x0c030c02u); }
+      *reinterpret_cast<uint2 *>(src + __mul24(r, SS) + 4 * g) = w;
+    };
+#pragma unroll
+    for (int k = 0; k < NMAIN; k++) {
+      const int i = tid + 256 * k;
+      if (i < nmain) { const int r = (int)(((float)i + 0.5f) * inv_ng); store4(r + 3, i - r * ng, o[k]); }
+    }
+#pragma unroll
+    for (int k = 0; k < NHALO; k++) {
+      const int i = tid + 256 * k;
+      if (i < nhalo) { const int hr = (int)(((float)i + 0.5f) * inv_ng); store4(hr < 3 ? hr : bh + hr, i - hr * ng, o[NMAIN + k]); }
     }
   } else {
     for (int i = tid; i < (bh + 6) * (bw + 6); i += 256) {
