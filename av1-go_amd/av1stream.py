@@ -1,0 +1,82 @@
+"""ctypes binding of the host AV1 bitstream writer (host/av1_bitstream.hpp, exported by libav1mi_host.so).
+
+Plumbing only: builds the `av1mi_obu_frame` description from numpy arrays (the symbols the GPU pipeline produced) and
+returns the Section-5 OBU bytes of one temporal unit.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HOST = os.path.join(os.path.dirname(os.path.abspath(__file__)), "host", "libav1mi_host.so")
+_lib = None
+
+
+class ObuFrame(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("bit_depth", C.c_int32), ("frame_type", C.c_int32),
+                ("base_q_idx", C.c_int32), ("lf_level", C.c_int32 * 4), ("lf_sharpness", C.c_int32), ("cdef_damping", C.c_int32),
+                ("cdef_bits", C.c_int32), ("cdef_y", C.c_uint8 * 8), ("cdef_uv", C.c_uint8 * 8), ("cdef_idx", C.c_void_p),
+                ("lr_type", C.c_int32 * 3), ("lr_unit_shift", C.c_int32), ("lr_uv_shift", C.c_int32), ("lr_units", C.c_void_p * 3),
+                ("reduced_tx_set", C.c_int32), ("disable_cdf_update", C.c_int32), ("tile_cols_log2", C.c_int32),
+                ("tile_rows_log2", C.c_int32), ("y_mode", C.c_void_p), ("angle_y", C.c_void_p), ("uv_mode", C.c_void_p),
+                ("angle_uv", C.c_void_p), ("cfl_alpha", C.c_void_p), ("skip", C.c_void_p), ("tx_type", C.c_void_p),
+                ("is_inter", C.c_void_p), ("mv", C.c_void_p), ("lev_y", C.c_void_p), ("lev_u", C.c_void_p), ("lev_v", C.c_void_p)]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_HOST):
+            subprocess.check_call(["make", "-s", "-C", os.path.dirname(_HOST)])
+        _lib = C.CDLL(_HOST)
+        _lib.av1mi_obu_write_temporal_unit.restype = C.c_longlong
+        _lib.av1mi_obu_write_temporal_unit.argtypes = [C.POINTER(ObuFrame), C.c_int, C.c_int, C.c_void_p, C.c_longlong, C.c_char_p, C.c_int]
+    return _lib
+
+
+_PTR_FIELDS = {"cdef_idx": np.uint8, "y_mode": np.uint8, "angle_y": np.int8, "uv_mode": np.uint8, "angle_uv": np.int8, "cfl_alpha": np.int8,
+               "skip": np.uint8, "tx_type": np.uint8, "is_inter": np.uint8, "mv": np.int16, "lev_y": np.int16, "lev_u": np.int16,
+               "lev_v": np.int16}
+
+
+def temporal_unit(width, height, bit_depth, base_q_idx, frame_type=0, with_sequence_header=True, threads=1, lf_level=(0, 0, 0, 0),
+                  lf_sharpness=0, cdef_damping=3, cdef_bits=0, cdef_y=(0,), cdef_uv=(0,), lr_type=(0, 0, 0), lr_unit_shift=0, lr_uv_shift=0,
+                  lr_units=(None, None, None), reduced_tx_set=0, disable_cdf_update=0, tile_cols_log2=-1, tile_rows_log2=-1, **arrays):
+    """arrays: y_mode, angle_y, uv_mode, angle_uv, cfl_alpha, skip, tx_type, is_inter, mv, lev_y, lev_u, lev_v, cdef_idx (numpy, raster
+    order over 8x8 blocks; see av1_bitstream.hpp).  Returns bytes."""
+    f = ObuFrame()
+    f.width, f.height, f.bit_depth, f.frame_type, f.base_q_idx = width, height, bit_depth, frame_type, base_q_idx
+    for i in range(4):
+        f.lf_level[i] = int(lf_level[i])
+    f.lf_sharpness, f.cdef_damping, f.cdef_bits = lf_sharpness, cdef_damping, cdef_bits
+    for i, v in enumerate(cdef_y):
+        f.cdef_y[i] = int(v)
+    for i, v in enumerate(cdef_uv):
+        f.cdef_uv[i] = int(v)
+    keep = []
+    for p in range(3):
+        f.lr_type[p] = int(lr_type[p])
+        if lr_units[p] is not None:
+            a = np.ascontiguousarray(lr_units[p], np.int8)
+            keep.append(a)
+            f.lr_units[p] = a.ctypes.data
+    f.lr_unit_shift, f.lr_uv_shift = lr_unit_shift, lr_uv_shift
+    f.reduced_tx_set, f.disable_cdf_update, f.tile_cols_log2, f.tile_rows_log2 = reduced_tx_set, disable_cdf_update, tile_cols_log2, tile_rows_log2
+    for k, v in arrays.items():
+        if k not in _PTR_FIELDS:
+            raise TypeError("unknown field " + k)
+        if v is None:
+            continue
+        a = np.ascontiguousarray(v, _PTR_FIELDS[k])
+        keep.append(a)
+        setattr(f, k, a.ctypes.data)
+    cap = width * height * 4 + (1 << 16)
+    out = np.empty(cap, np.uint8)
+    err = C.create_string_buffer(256)
+    n = lib().av1mi_obu_write_temporal_unit(C.byref(f), int(with_sequence_header), threads, out.ctypes.data, cap, err, 256)
+    if n < 0:
+        raise ValueError("av1 bitstream writer: " + err.value.decode())
+    if n > cap:
+        raise RuntimeError("temporal unit of %d bytes exceeds the buffer" % n)
+    return out[:n].tobytes()

@@ -1,5 +1,5 @@
 // block_code.hpp — the residual-coding tail shared by the fused intra and inter kernels: one B x B block held by B
-// lanes of one wave (lane r owns row r): residual -> forward DCT (columns, rows; libaom fwd_txfm2d_c) -> quantise
+// lanes of one wave (lane r owns row r): residual -> forward DCT (ADST where an intra chroma block's mode implies it: columns, rows; libaom fwd_txfm2d_c) -> quantise
 // (libaom quantize_fp) -> levels to HBM -> dequantise (spec 7.12.3) -> inverse DCT (rows, columns; spec 7.13.3) ->
 // reconstruction.  T is the group's B x (B+4) int32 LDS transpose buffer.  SURVEY.md §8a rows K1 + K8 + K2.
 #pragma once
@@ -45,11 +45,39 @@ template <int N, typename Pix> __device__ __forceinline__ void store_row(Pix *p,
   }
 }
 
+// 1-D pass that is a DCT or an ADST per BLOCK (lanes of different blocks share the wave): both are evaluated and the lane
+// selects — for the 4-point (default) and 8-point chroma transforms that is cheaper than a divergent branch per group.
+template <int B, int BIT> __device__ __forceinline__ void fwd_dct_or_adst(int32_t *x, bool adst) {
+  static_assert(B == 4 || B == 8, "ADST is only selected for chroma blocks (4x4, or 8x8 with 16x16 luma blocks)");
+  int32_t a[B];
+#pragma unroll
+  for (int i = 0; i < B; i++) a[i] = x[i];
+  fdct<B, BIT>(x);
+  if constexpr (B == 4) fadst4<BIT>(a); else fadst8<BIT>(a);
+#pragma unroll
+  for (int i = 0; i < B; i++) x[i] = adst ? a[i] : x[i];
+}
+template <int B, int RANGE> __device__ __forceinline__ void inv_dct_or_adst(int32_t *x, bool adst) {
+  static_assert(B == 4 || B == 8, "see fwd_dct_or_adst");
+  int32_t a[B];
+#pragma unroll
+  for (int i = 0; i < B; i++) a[i] = x[i];
+  idct<B, RANGE>(x);
+  if constexpr (B == 4) iadst4<12>(a); else iadst8<12, RANGE>(a);
+#pragma unroll
+  for (int i = 0; i < B; i++) x[i] = adst ? a[i] : x[i];
+}
+// Mode_To_Txfm (AV1 spec 5.11.47 compute_tx_type): an intra CHROMA block's transform type follows from its prediction mode and is
+// not coded.  Bit m of the masks: mode m uses the ADST vertically (column pass) / horizontally (row pass).
+constexpr unsigned kModeVertAdst = 0x1732u;   // V D135 D113 D67 SMOOTH SMOOTH_V PAETH
+constexpr unsigned kModeHorzAdst = 0x1AD4u;   // H D135 D157 D203 SMOOTH SMOOTH_H PAETH
+
 // s[]: source row, bp[]: prediction row.  Writes this lane's row of levels to lev_row and returns its reconstruction in
-// rec[]; the return value is non-zero when the row holds a non-zero level.
-template <int B, typename Pix>
+// rec[]; the return value is non-zero when the row holds a non-zero level.  SEL = the block may use the ADST in either
+// direction (vadst: column / vertical pass, hadst: row / horizontal pass); otherwise DCT_DCT.
+template <int B, typename Pix, bool SEL = false>
 __device__ __forceinline__ int code_residual(int32_t *T, int lane, const int *s, const int *bp, int dc_q, int ac_q, int dc_quant, int ac_quant, int16_t *lev_row,
-                                             int *rec) {
+                                             int *rec, bool vadst = false, bool hadst = false) {
   constexpr int RS = B + 4, bd = sizeof(Pix) == 1 ? 8 : 10;
   // forward transform (libaom fwd_txfm2d_c: columns, then rows), DCT_DCT
   {
@@ -61,7 +89,7 @@ __device__ __forceinline__ int code_residual(int32_t *T, int lane, const int *s,
   int32_t xv[B];
 #pragma unroll
   for (int r = 0; r < B; r++) xv[r] = T[r * RS + lane] << fwd_shift(B, B, 0);
-  fdct<B, fwd_cos_bit_col(B, B)>(xv);
+  if constexpr (SEL) fwd_dct_or_adst<B, fwd_cos_bit_col(B, B)>(xv, vadst); else fdct<B, fwd_cos_bit_col(B, B)>(xv);
   AV1MI_GROUP_SYNC();
 #pragma unroll
   for (int r = 0; r < B; r++) T[r * RS + lane] = round2(xv[r], -fwd_shift(B, B, 1));
@@ -71,7 +99,7 @@ __device__ __forceinline__ int code_residual(int32_t *T, int lane, const int *s,
     const int4 v = *reinterpret_cast<const int4 *>(T + lane * RS + c);
     xv[c] = v.x; xv[c + 1] = v.y; xv[c + 2] = v.z; xv[c + 3] = v.w;
   }
-  fdct<B, fwd_cos_bit_row(B, B)>(xv);
+  if constexpr (SEL) fwd_dct_or_adst<B, fwd_cos_bit_row(B, B)>(xv, hadst); else fdct<B, fwd_cos_bit_row(B, B)>(xv);
   // quantise / dequantise this row (libaom quantize_fp; spec 7.12.3), log_scale 0 for B <= 16
   // dc_quant / ac_quant = (1 << 16) / step come from the host: written here as a division, the compiler sank the (loop-invariant)
   // division into the conditional block of every coefficient — ~25 scalar or ~30 vector instructions and a divergent branch, 8
@@ -103,7 +131,7 @@ __device__ __forceinline__ int code_residual(int32_t *T, int lane, const int *s,
   constexpr int ROW_RANGE = bd + 8;
 #pragma unroll
   for (int c = 0; c < B; c++) xv[c] = clampr<ROW_RANGE>(xv[c]);
-  idct<B, ROW_RANGE>(xv);
+  if constexpr (SEL) inv_dct_or_adst<B, ROW_RANGE>(xv, hadst); else idct<B, ROW_RANGE>(xv);
   AV1MI_GROUP_SYNC();
 #pragma unroll
   for (int c = 0; c < B; c += 4)
@@ -112,7 +140,7 @@ __device__ __forceinline__ int code_residual(int32_t *T, int lane, const int *s,
   AV1MI_GROUP_SYNC();
 #pragma unroll
   for (int r = 0; r < B; r++) xv[r] = min(max(T[r * RS + lane], -32768), 32767);   // max(bd+6,16) = 16 bits for bd <= 10
-  idct<B, 16>(xv);
+  if constexpr (SEL) inv_dct_or_adst<B, 16>(xv, vadst); else idct<B, 16>(xv);
   AV1MI_GROUP_SYNC();
 #pragma unroll
   for (int r = 0; r < B; r++) T[r * RS + lane] = round2(xv[r], 4);

@@ -1,0 +1,801 @@
+// av1_bitstream.cpp — see av1_bitstream.hpp.  Written from the AV1 Bitstream & Decoding Process Specification; section
+// numbers in the comments are the specification's.  The default CDF tables come from av1_default_cdfs.inc (generated,
+// tools/extract_av1_cdfs.py).  Conformance is checked by decoding with dav1d (tests/test_av1_conformance.py).
+#include "av1_bitstream.hpp"
+
+#include <algorithm>
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+
+#include "av1_default_cdfs.inc"
+
+namespace av1mi_host {
+namespace av1 {
+namespace {
+
+// ------------------------------------------------------------------------------------------------ fixed-length bits
+struct BitWriter {   // f(n): most significant bit first (spec 4.10.2)
+  std::vector<uint8_t> b;
+  int used = 0;      // bits used in the last byte (0 = byte aligned)
+  void put(uint32_t v, int n) {
+    for (int i = n - 1; i >= 0; i--) {
+      if (!used) b.push_back(0);
+      b.back() |= (uint8_t)(((v >> i) & 1u) << (7 - used));
+      used = (used + 1) & 7;
+    }
+  }
+  void byte_align() { used = 0; }                       // byte_alignment(): zero bits (spec 5.3.5)
+  void trailing_bits() { put(1, 1); used = 0; }         // trailing_bits(): a one, then zeros (spec 5.3.4)
+};
+void put_leb128(std::vector<uint8_t> &o, uint64_t v) {  // spec 4.10.5
+  do { uint8_t c = v & 0x7F; v >>= 7; if (v) c |= 0x80; o.push_back(c); } while (v);
+}
+std::vector<uint8_t> make_obu(int type, const std::vector<uint8_t> &payload) {   // obu_header (5.3.2) with obu_has_size_field = 1
+  std::vector<uint8_t> o;
+  o.push_back((uint8_t)((type << 3) | 2));
+  put_leb128(o, payload.size());
+  o.insert(o.end(), payload.begin(), payload.end());
+  return o;
+}
+inline int tile_log2(int blk, int target) { int k = 0; while ((blk << k) < target) k++; return k; }   // spec 5.9.16
+inline int floor_log2(uint32_t v) { return 31 - __builtin_clz(v); }
+
+// ------------------------------------------------------------------------------------------------ symbol encoder (8.2)
+// The dual of the spec's symbol decoder (8.2.2 init, 8.2.6 decode_symbol, 8.2.4 exit): the stream value x satisfies
+// low <= x < low + rng at the current precision; symbol 0 sits at the BOTTOM of x-space (the decoder's SymbolValue is
+// the complement).  CDFs are kept in inverse form, icdf[i] = 32768 - cdf[i], icdf[N-1] = 0, icdf[N] = adaptation counter.
+struct RangeEnc {
+  std::vector<uint8_t> out;
+  uint64_t low = 0;
+  uint32_t rng = 0x8000;
+  int nb = -1;       // bits of x above the 16-bit window that are not in `out` yet (x has 15 + total shift bits)
+  inline void carry() {
+    if (nb >= 0 && (low >> (16 + nb))) {
+      for (size_t i = out.size(); i-- > 0;) if (++out[i] != 0) break;
+      low &= ((uint64_t)1 << (16 + nb)) - 1;
+    }
+  }
+  inline void renorm() {
+    const int d = 15 - floor_log2(rng);
+    rng <<= d; low <<= d; nb += d;
+    while (nb >= 8) {
+      nb -= 8;
+      out.push_back((uint8_t)(low >> (16 + nb)));
+      low &= ((uint64_t)1 << (16 + nb)) - 1;
+    }
+  }
+  // fl = icdf[s-1] (32768 for s = 0), fh = icdf[s]; n = number of symbols
+  inline void encode(uint32_t fl, uint32_t fh, int s, int n) {
+    const uint32_t r = rng;
+    const uint32_t v = (((r >> 8) * (fh >> 6)) >> 1) + 4u * (uint32_t)(n - 1 - s);
+    if (fl < 32768u) {
+      const uint32_t u = (((r >> 8) * (fl >> 6)) >> 1) + 4u * (uint32_t)(n - s);
+      low += r - u;
+      rng = u - v;
+    } else {
+      rng = r - v;
+    }
+    carry();
+    renorm();
+  }
+  inline void bool_eq(int bit) { encode(bit ? 16384u : 32768u, bit ? 0u : 16384u, bit, 2); }   // read_bool(): cdf {1<<14, 1<<15, 0}
+  void literal(uint32_t v, int n) { for (int i = n - 1; i >= 0; i--) bool_eq((v >> i) & 1); }     // L(n), spec 4.10.7
+  // exit process (8.2.4): the minimum number of bits, then the trailing one, then zero padding to a byte
+  void finish() {
+    uint64_t e = ((low + 0x3FFF) & ~(uint64_t)0x3FFF) | 0x4000;
+    if (nb >= 0 && (e >> (16 + nb))) {
+      for (size_t i = out.size(); i-- > 0;) if (++out[i] != 0) break;
+      e &= ((uint64_t)1 << (16 + nb)) - 1;
+    }
+    int top = 15 + nb;                     // most significant pending bit of x inside e
+    while (top >= 14) {
+      uint8_t byte = 0;
+      for (int k = 7; k >= 0 && top >= 14; k--, top--) byte |= (uint8_t)(((e >> top) & 1) << k);
+      out.push_back(byte);
+    }
+  }
+};
+
+// adaptive symbol (8.2.6 + the CDF update of 8.2.6 / libaom update_cdf), icdf has n + 1 entries
+inline void put_symbol(RangeEnc &ec, uint16_t *icdf, int n, int s, bool adapt) {
+  ec.encode(s ? icdf[s - 1] : 32768u, icdf[s], s, n);
+  if (adapt) {
+    const int count = icdf[n];
+    const int rate = 3 + (count > 15) + (count > 31) + std::min(floor_log2((uint32_t)n), 2);
+    for (int i = 0; i < n - 1; i++) {
+      if (i < s) icdf[i] += (uint16_t)((32768 - icdf[i]) >> rate);
+      else icdf[i] -= (uint16_t)(icdf[i] >> rate);
+    }
+    icdf[n] = (uint16_t)(count + (count < 32));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ CDF context of a tile
+struct MvCompCdf { uint16_t cls[12], class0[3], class0_fr[2][5], class0_hp[3], sign[3], bits[10][3], fr[5], hp[3]; };
+struct Cdfs {
+  uint16_t skip[3][3];
+  uint16_t kf_y_mode[5][5][14], y_mode[4][14], uv_mode_nocfl[13][14], uv_mode_cfl[13][15], angle_delta[8][8];
+  uint16_t part8[4][5], part16[4][11], part32[4][11], part64[4][11];
+  uint16_t cfl_sign[9], cfl_alpha[6][17];
+  uint16_t intra_tx1[2][13][8], intra_tx2[3][13][6], inter_tx1[2][17], inter_tx2[13], inter_tx3[4][3];
+  uint16_t use_wiener[3], use_sgrproj[3], switchable_restore[4];
+  uint16_t is_inter[4][3], single_ref[3][6][3], new_mv[6][3], zero_mv[2][3], ref_mv[6][3], drl[3][3];
+  uint16_t mv_joint[5];
+  MvCompCdf mv[2];
+  uint16_t txb_skip[5][13][3], eob16[2][2][6], eob32[2][2][7], eob64[2][2][8], eob128[2][2][9], eob256[2][2][10],
+      eob512[2][2][11], eob1024[2][2][12], eob_extra[5][2][9][3], dc_sign[2][3][3], base_eob[5][2][4][4], base[5][2][42][5],
+      br[5][2][21][5];
+};
+// rows of (nsym - 1) spec-form values -> rows of dst_stride inverse-form entries
+void load_rows(uint16_t *dst, int dst_stride, const uint16_t *src, int nsym, int rows) {
+  for (int r = 0; r < rows; r++) {
+    for (int i = 0; i < nsym - 1; i++) dst[r * dst_stride + i] = (uint16_t)(32768 - src[r * (nsym - 1) + i]);
+    for (int i = nsym - 1; i < dst_stride; i++) dst[r * dst_stride + i] = 0;
+  }
+}
+template <class D, class S> void load_tab(D &dst, const S &src, int nsym) {
+  const int rows = (int)(sizeof(S) / sizeof(uint16_t)) / (nsym - 1);
+  const int stride = (int)(sizeof(D) / sizeof(uint16_t)) / rows;
+  load_rows((uint16_t *)&dst, stride, (const uint16_t *)&src, nsym, rows);
+}
+const Cdfs &default_cdfs(int qcat) {   // init_non_coeff_cdfs / init_coeff_cdfs (7.20 "setup past independence")
+  static Cdfs tabs[4];
+  static bool ready = [] {
+    for (int q = 0; q < 4; q++) {
+      Cdfs &c = tabs[q];
+      memset(&c, 0, sizeof(c));
+      load_tab(c.skip, Default_Skip_Cdf, 2);
+      load_tab(c.kf_y_mode, Default_Intra_Frame_Y_Mode_Cdf, 13);
+      load_tab(c.y_mode, Default_Y_Mode_Cdf, 13);
+      load_tab(c.uv_mode_nocfl, Default_Uv_Mode_Cfl_Not_Allowed_Cdf, 13);
+      load_tab(c.uv_mode_cfl, Default_Uv_Mode_Cfl_Allowed_Cdf, 14);
+      load_tab(c.angle_delta, Default_Angle_Delta_Cdf, 7);
+      load_tab(c.part8, Default_Partition_W8_Cdf, 4);
+      load_tab(c.part16, Default_Partition_W16_Cdf, 10);
+      load_tab(c.part32, Default_Partition_W32_Cdf, 10);
+      load_tab(c.part64, Default_Partition_W64_Cdf, 10);
+      load_tab(c.cfl_sign, Default_Cfl_Sign_Cdf, 8);
+      load_tab(c.cfl_alpha, Default_Cfl_Alpha_Cdf, 16);
+      load_tab(c.intra_tx1, Default_Intra_Tx_Type_Set1_Cdf, 7);
+      load_tab(c.intra_tx2, Default_Intra_Tx_Type_Set2_Cdf, 5);
+      load_tab(c.inter_tx1, Default_Inter_Tx_Type_Set1_Cdf, 16);
+      load_tab(c.inter_tx2, Default_Inter_Tx_Type_Set2_Cdf, 12);
+      load_tab(c.inter_tx3, Default_Inter_Tx_Type_Set3_Cdf, 2);
+      load_tab(c.use_wiener, Default_Use_Wiener_Cdf, 2);
+      load_tab(c.use_sgrproj, Default_Use_Sgrproj_Cdf, 2);
+      load_tab(c.switchable_restore, Default_Switchable_Restore_Cdf, 3);
+      load_tab(c.is_inter, Default_Is_Inter_Cdf, 2);
+      load_tab(c.single_ref, Default_Single_Ref_Cdf, 2);
+      load_tab(c.new_mv, Default_New_Mv_Cdf, 2);
+      load_tab(c.zero_mv, Default_Zero_Mv_Cdf, 2);
+      load_tab(c.ref_mv, Default_Ref_Mv_Cdf, 2);
+      load_tab(c.drl, Default_Drl_Mode_Cdf, 2);
+      load_tab(c.mv_joint, Default_Mv_Joint_Cdf, 4);
+      for (int k = 0; k < 2; k++) {
+        load_tab(c.mv[k].cls, Default_Mv_Class_Cdf, 11);
+        load_tab(c.mv[k].class0, Default_Mv_Class0_Bit_Cdf, 2);
+        load_tab(c.mv[k].class0_fr, Default_Mv_Class0_Fr_Cdf, 4);
+        load_tab(c.mv[k].class0_hp, Default_Mv_Class0_Hp_Cdf, 2);
+        load_tab(c.mv[k].sign, Default_Mv_Sign_Cdf, 2);
+        load_tab(c.mv[k].bits, Default_Mv_Bit_Cdf, 2);
+        load_tab(c.mv[k].fr, Default_Mv_Fr_Cdf, 4);
+        load_tab(c.mv[k].hp, Default_Mv_Hp_Cdf, 2);
+      }
+      load_tab(c.txb_skip, Default_Txb_Skip_Cdf[q], 2);
+      load_tab(c.eob16, Default_Eob_Pt_16_Cdf[q], 5);
+      load_tab(c.eob32, Default_Eob_Pt_32_Cdf[q], 6);
+      load_tab(c.eob64, Default_Eob_Pt_64_Cdf[q], 7);
+      load_tab(c.eob128, Default_Eob_Pt_128_Cdf[q], 8);
+      load_tab(c.eob256, Default_Eob_Pt_256_Cdf[q], 9);
+      load_tab(c.eob512, Default_Eob_Pt_512_Cdf[q], 10);
+      load_tab(c.eob1024, Default_Eob_Pt_1024_Cdf[q], 11);
+      load_tab(c.eob_extra, Default_Eob_Extra_Cdf[q], 2);
+      load_tab(c.dc_sign, Default_Dc_Sign_Cdf[q], 2);
+      load_tab(c.base_eob, Default_Coeff_Base_Eob_Cdf[q], 3);
+      load_tab(c.base, Default_Coeff_Base_Cdf[q], 4);
+      load_tab(c.br, Default_Coeff_Br_Cdf[q], 4);
+    }
+    return true;
+  }();
+  (void)ready;
+  return tabs[qcat];
+}
+
+// ------------------------------------------------------------------------------------------------ constants of the syntax
+enum { DC_PRED, V_PRED, H_PRED, D45_PRED, D135_PRED, D113_PRED, D157_PRED, D203_PRED, D67_PRED, SMOOTH_PRED, SMOOTH_V_PRED,
+       SMOOTH_H_PRED, PAETH_PRED, UV_CFL_PRED };
+enum { T_DCT_DCT, T_ADST_DCT, T_DCT_ADST, T_ADST_ADST, T_FLIPADST_DCT, T_DCT_FLIPADST, T_FLIPADST_FLIPADST, T_ADST_FLIPADST,
+       T_FLIPADST_ADST, T_IDTX };
+const uint8_t kIntraModeContext[13] = { 0, 1, 2, 3, 4, 4, 4, 4, 3, 0, 1, 2, 0 };   // Intra_Mode_Context (9.3)
+// symbol of a 2-D-class transform type inside each set = inverse of Tx_Type_Intra_Inv_Set1/2, Tx_Type_Inter_Inv_Set1/3 (5.11.47)
+const int8_t kIntraSet1Sym[16] = { 1, 5, 6, 4, -1, -1, -1, -1, -1, 0, 2, 3, -1, -1, -1, -1 };
+const int8_t kIntraSet2Sym[16] = { 1, 3, 4, 2, -1, -1, -1, -1, -1, 0, -1, -1, -1, -1, -1, -1 };
+const int8_t kInterSet1Sym[16] = { 1, 8, 9, 10, 11, 12, 13, 14, 15, 0, 2, 3, 4, 5, 6, 7 };
+inline bool is_directional(int m) { return m >= V_PRED && m <= D67_PRED; }
+inline bool tx_class_2d(int t) { return t <= T_FLIPADST_ADST; }
+
+struct Scans { uint8_t s4[16], s8[64]; };
+const Scans &scans() {   // Default_Scan_4x4 / Default_Scan_8x8 for row-major blocks (row = vertical frequency): 0, 1, 8, 16, 9, 2, 3, 10, ...
+  static Scans sc = [] {
+    Scans t;
+    auto gen = [](int n, uint8_t *o) {
+      int k = 0;
+      for (int d = 0; d < 2 * n - 1; d++)
+        for (int i = 0; i <= d; i++) {
+          const int r = (d & 1) ? i : d - i, c = d - r;
+          if (r < n && c < n) o[k++] = (uint8_t)(r * n + c);
+        }
+    };
+    gen(4, t.s4); gen(8, t.s8);
+    return t;
+  }();
+  return sc;
+}
+
+// ------------------------------------------------------------------------------------------------ frame-level derived values
+struct FrameInfo {
+  const av1mi_obu_frame *f;
+  int w8, h8;                 // frame size in 8x8 blocks
+  int mi_rows, mi_cols;       // in 4x4 units
+  int sb_rows, sb_cols;
+  int tile_cols_log2, tile_rows_log2, tile_w_sb, tile_h_sb, tile_cols, tile_rows;
+  int qcat;
+  int lr_size[3], lr_rows[3], lr_cols[3];
+  bool key;
+};
+
+bool check(const av1mi_obu_frame &f, std::string *err) {
+  auto bad = [&](const char *m) { if (err) *err = m; return false; };
+  if (f.width <= 0 || f.height <= 0 || (f.width & 7) || (f.height & 7) || f.width > 4096 || f.height > 4096)
+    return bad("frame size must be a multiple of 8 and at most 4096x4096 (64 superblock tiles per dimension)");
+  if (f.bit_depth != 8 && f.bit_depth != 10) return bad("bit depth must be 8 or 10");
+  if (f.frame_type != 0 && f.frame_type != 1) return bad("frame_type must be 0 (key) or 1 (inter)");
+  if (f.base_q_idx < 1 || f.base_q_idx > 255) return bad("base_q_idx must be 1..255 (0 is the lossless mode, not coded)");
+  for (int i = 0; i < 4; i++) if (f.lf_level[i] < 0 || f.lf_level[i] > 63) return bad("loop filter level out of range");
+  if (f.lf_sharpness < 0 || f.lf_sharpness > 7) return bad("loop filter sharpness out of range");
+  if (f.cdef_damping < 3 || f.cdef_damping > 6 || f.cdef_bits < 0 || f.cdef_bits > 3) return bad("CDEF parameters out of range");
+  for (int p = 0; p < 3; p++) {
+    if (f.lr_type[p] < 0 || f.lr_type[p] > 3) return bad("restoration type out of range");
+    if (f.lr_type[p] && !f.lr_units[p]) return bad("restoration units missing");
+  }
+  if (f.lr_unit_shift < 0 || f.lr_unit_shift > 2 || f.lr_uv_shift < 0 || f.lr_uv_shift > 1) return bad("restoration unit size out of range");
+  if (!f.lev_y || !f.lev_u || !f.lev_v) return bad("levels missing");
+  if (f.frame_type == 0 && (!f.y_mode || !f.uv_mode)) return bad("key frame without prediction modes");
+  if (f.frame_type == 1 && !f.mv) return bad("inter frame without motion vectors");
+  return true;
+}
+
+FrameInfo frame_info(const av1mi_obu_frame &f) {
+  FrameInfo fi;
+  fi.f = &f;
+  fi.key = f.frame_type == 0;
+  fi.w8 = f.width / 8; fi.h8 = f.height / 8;
+  fi.mi_cols = 2 * fi.w8; fi.mi_rows = 2 * fi.h8;
+  fi.sb_cols = (fi.mi_cols + 15) >> 4; fi.sb_rows = (fi.mi_rows + 15) >> 4;
+  // tile_info (5.9.15), uniform spacing
+  const int max_log2_cols = tile_log2(1, std::min(fi.sb_cols, 64)), max_log2_rows = tile_log2(1, std::min(fi.sb_rows, 64));
+  const int min_log2_cols = tile_log2(64, fi.sb_cols);
+  fi.tile_cols_log2 = f.tile_cols_log2 < 0 ? max_log2_cols : std::min(std::max(f.tile_cols_log2, min_log2_cols), max_log2_cols);
+  fi.tile_w_sb = (fi.sb_cols + (1 << fi.tile_cols_log2) - 1) >> fi.tile_cols_log2;
+  fi.tile_cols = (fi.sb_cols + fi.tile_w_sb - 1) / fi.tile_w_sb;
+  const int min_log2_tiles = std::max(min_log2_cols, tile_log2(2304, fi.sb_rows * fi.sb_cols));
+  const int min_log2_rows = std::max(min_log2_tiles - tile_log2(1, fi.tile_cols), 0);
+  fi.tile_rows_log2 = f.tile_rows_log2 < 0 ? max_log2_rows : std::min(std::max(f.tile_rows_log2, min_log2_rows), max_log2_rows);
+  fi.tile_h_sb = (fi.sb_rows + (1 << fi.tile_rows_log2) - 1) >> fi.tile_rows_log2;
+  fi.tile_rows = (fi.sb_rows + fi.tile_h_sb - 1) / fi.tile_h_sb;
+  fi.qcat = f.base_q_idx <= 20 ? 0 : f.base_q_idx <= 60 ? 1 : f.base_q_idx <= 120 ? 2 : 3;   // init_coeff_cdfs index (7.20)
+  for (int p = 0; p < 3; p++) {
+    fi.lr_size[p] = (64 << f.lr_unit_shift) >> (p ? f.lr_uv_shift : 0);
+    const int ph = p ? (f.height + 1) >> 1 : f.height, pw = p ? (f.width + 1) >> 1 : f.width;
+    fi.lr_rows[p] = std::max((ph + (fi.lr_size[p] >> 1)) / fi.lr_size[p], 1);   // count_units_in_frame (5.11.57)
+    fi.lr_cols[p] = std::max((pw + (fi.lr_size[p] >> 1)) / fi.lr_size[p], 1);
+  }
+  return fi;
+}
+
+// ------------------------------------------------------------------------------------------------ one tile
+struct MvCand { int16_t x, y; int weight; };
+
+struct TileEnc {
+  const FrameInfo &fi;
+  const av1mi_obu_frame &f;
+  int r8_0, r8_1, c8_0, c8_1;          // tile bounds in 8x8 blocks
+  RangeEnc ec;
+  Cdfs cdf;
+  bool adapt;
+  std::vector<uint8_t> a_lvl[3], a_dc[3];   // AboveLevelContext / AboveDcContext, 4-sample units of the plane, tile relative
+  uint8_t l_lvl[3][16], l_dc[3][16];        // Left..., superblock relative
+  int ref_wiener[3][2][3], ref_sgr[3][2];   // RefLrWiener / RefSgrXqd (5.11.58)
+  bool cdef_coded = false;
+
+  TileEnc(const FrameInfo &fi_, int tr, int tc) : fi(fi_), f(*fi_.f), cdf(default_cdfs(fi_.qcat)) {
+    r8_0 = tr * fi.tile_h_sb * 8; r8_1 = std::min(r8_0 + fi.tile_h_sb * 8, fi.h8);
+    c8_0 = tc * fi.tile_w_sb * 8; c8_1 = std::min(c8_0 + fi.tile_w_sb * 8, fi.w8);
+    adapt = !f.disable_cdf_update;
+    for (int p = 0; p < 3; p++) {
+      const int n = (c8_1 - c8_0) * (p ? 1 : 2) + 4;
+      a_lvl[p].assign(n, 0); a_dc[p].assign(n, 0);
+      for (int k = 0; k < 2; k++) {
+        ref_wiener[p][k][0] = 3; ref_wiener[p][k][1] = -7; ref_wiener[p][k][2] = 15;   // Wiener_Taps_Mid
+      }
+      ref_sgr[p][0] = -32; ref_sgr[p][1] = 31;                                          // Sgrproj_Xqd_Mid
+    }
+  }
+  inline void sym(uint16_t *icdf, int n, int s) { put_symbol(ec, icdf, n, s, adapt); }
+  inline int blk(int r8, int c8) const { return r8 * fi.w8 + c8; }
+  inline bool avail_u(int r8) const { return r8 - 1 >= r8_0; }
+  inline bool avail_l(int c8) const { return c8 - 1 >= c8_0; }
+  inline int skip_of(int b) const { return f.skip ? f.skip[b] : 0; }
+  inline int inter_of(int b) const { return fi.key ? 0 : (f.is_inter ? f.is_inter[b] : 1); }
+
+  // ---- decode_tile (5.11.2)
+  void run() {
+    for (int r8 = r8_0; r8 < r8_1; r8 += 8) {
+      memset(l_lvl, 0, sizeof(l_lvl)); memset(l_dc, 0, sizeof(l_dc));      // clear_left_context
+      for (int c8 = c8_0; c8 < c8_1; c8 += 8) {
+        cdef_coded = false;                                                 // clear_cdef
+        write_lr(r8 * 2, c8 * 2);
+        partition(r8 * 2, c8 * 2, 64);
+      }
+    }
+    ec.finish();
+  }
+
+  // ---- subexponential codes with a reference, written with equiprobable bools (5.11.58, 4.10.10 structure)
+  void put_ns(int n, int v) {               // NS(n) by literals
+    const int w = floor_log2((uint32_t)n) + 1, m = (1 << w) - n;
+    if (v < m) ec.literal((uint32_t)v, w - 1);
+    else { ec.literal((uint32_t)((v + m) >> 1), w - 1); ec.literal((uint32_t)((v + m) & 1), 1); }
+  }
+  void put_subexp(int num_syms, int k, int v) {   // decode_subexp_bool
+    int i = 0, mk = 0;
+    for (;;) {
+      const int b2 = i ? k + i - 1 : k, a = 1 << b2;
+      if (num_syms <= mk + 3 * a) { put_ns(num_syms - mk, v - mk); return; }
+      const int more = v >= mk + a;
+      ec.literal((uint32_t)more, 1);
+      if (!more) { ec.literal((uint32_t)(v - mk), b2); return; }
+      i++; mk += a;
+    }
+  }
+  static int recenter(int r, int v) { return v > 2 * r ? v : v >= r ? 2 * (v - r) : 2 * (r - v) - 1; }   // inverse of inverse_recenter
+  void put_signed_subexp_with_ref(int v, int low, int high, int k, int r) {   // decode_signed_subexp_with_ref_bool
+    const int mx = high - low; v -= low; r -= low;
+    put_subexp(mx, k, (r << 1) <= mx ? recenter(r, v) : recenter(mx - 1 - r, mx - 1 - v));
+  }
+
+  // ---- read_lr / read_lr_unit (5.11.57, 5.11.58)
+  void write_lr(int mi_r, int mi_c) {
+    for (int p = 0; p < 3; p++) {
+      if (!f.lr_type[p]) continue;
+      const int ss = p ? 1 : 0, us = fi.lr_size[p];
+      const int row0 = (mi_r * (4 >> ss) + us - 1) / us, row1 = std::min(((mi_r + 16) * (4 >> ss) + us - 1) / us, fi.lr_rows[p]);
+      const int col0 = (mi_c * (4 >> ss) + us - 1) / us, col1 = std::min(((mi_c + 16) * (4 >> ss) + us - 1) / us, fi.lr_cols[p]);
+      for (int ur = row0; ur < row1; ur++)
+        for (int uc = col0; uc < col1; uc++) lr_unit(p, f.lr_units[p] + ((size_t)ur * fi.lr_cols[p] + uc) * 8);
+    }
+  }
+  void lr_unit(int p, const int8_t *u) {
+    const int type = u[0];   // 0 none, 1 Wiener, 2 self-guided
+    if (f.lr_type[p] == 1) sym(cdf.use_wiener, 2, type == 1);
+    else if (f.lr_type[p] == 2) sym(cdf.use_sgrproj, 2, type == 2);
+    else sym(cdf.switchable_restore, 3, type);
+    if (type == 1 && f.lr_type[p] != 2) {
+      static const int kMin[3] = { -5, -23, -17 }, kMax[3] = { 10, 8, 46 }, kK[3] = { 1, 2, 3 };   // Wiener_Taps_Min / Max / K
+      for (int pass = 0; pass < 2; pass++)
+        for (int j = p ? 1 : 0; j < 3; j++) {
+          const int v = u[1 + pass * 3 + j];
+          put_signed_subexp_with_ref(v, kMin[j], kMax[j] + 1, kK[j], ref_wiener[p][pass][j]);
+          ref_wiener[p][pass][j] = v;
+        }
+    } else if (type == 2 && f.lr_type[p] != 1) {
+      static const int8_t kRadius[16][2] = { { 2, 1 }, { 2, 1 }, { 2, 1 }, { 2, 1 }, { 2, 1 }, { 2, 1 }, { 2, 1 }, { 2, 1 }, { 2, 1 }, { 2, 1 },
+                                             { 0, 1 }, { 0, 1 }, { 0, 1 }, { 0, 1 }, { 2, 0 }, { 2, 0 } };   // Sgr_Params radii
+      static const int kMin[2] = { -96, -32 }, kMax[2] = { 31, 95 };
+      const int set = u[1];
+      ec.literal((uint32_t)set, 4);
+      for (int i = 0; i < 2; i++) {
+        int v = u[2 + i];
+        if (kRadius[set][i]) put_signed_subexp_with_ref(v, kMin[i], kMax[i] + 1, 4, ref_sgr[p][i]);
+        else v = i == 0 ? 0 : std::min(std::max(128 - ref_sgr[p][0], kMin[1]), kMax[1]);
+        ref_sgr[p][i] = v;
+      }
+    }
+  }
+
+  // ---- decode_partition (5.11.4): always split down to 8x8
+  void partition(int r, int c, int bsize) {
+    if (r >= fi.mi_rows || c >= fi.mi_cols) return;
+    const int half = bsize >> 3;      // halfBlock4x4
+    const bool has_rows = r + half < fi.mi_rows, has_cols = c + half < fi.mi_cols;
+    const bool au = (r >> 1) - 1 >= r8_0, al = (c >> 1) - 1 >= c8_0;
+    if (bsize == 8) {
+      sym(cdf.part8[0], 4, 0);        // PARTITION_NONE; the neighbours are 8x8 too, so the context is 0
+      block(r >> 1, c >> 1);
+      return;
+    }
+    // neighbours are 8x8 blocks, narrower than this one: ctx = left * 2 + above (9.3)
+    uint16_t *pc = (bsize == 16 ? cdf.part16 : bsize == 32 ? cdf.part32 : cdf.part64)[(al ? 2 : 0) + (au ? 1 : 0)];
+    if (has_rows && has_cols) {
+      sym(pc, 10, 3);                 // PARTITION_SPLIT
+    } else if (has_rows || has_cols) {
+      // split_or_horz / split_or_vert: the probability of "split" gathers every partition type that splits the missing way
+      auto prob = [&](int k) { return (uint32_t)((k ? pc[k - 1] : 32768) - pc[k]); };
+      uint32_t psum;
+      if (has_cols) psum = prob(2) + prob(3) + prob(4) + prob(6) + prob(7) + prob(9);   // VERT SPLIT HORZ_A VERT_A VERT_B VERT_4
+      else psum = prob(1) + prob(3) + prob(4) + prob(5) + prob(6) + prob(8);            // HORZ SPLIT HORZ_A HORZ_B VERT_A HORZ_4
+      ec.encode(psum, 0, 1, 2);       // the bit is 1 (split), cdf { 32768 - psum, 32768 }: no adaptation
+    }
+    const int q = bsize >> 1;
+    partition(r, c, q); partition(r, c + half, q); partition(r + half, c, q); partition(r + half, c + half, q);
+  }
+
+  // ---- decode_block (5.11.5) of one 8x8 block
+  void block(int r8, int c8) {
+    const int b = blk(r8, c8);
+    const bool au = avail_u(r8), al = avail_l(c8);
+    const int skip = skip_of(b);
+    if (fi.key) intra_frame_mode_info(r8, c8, b, au, al, skip);
+    else inter_frame_mode_info(r8, c8, b, au, al, skip);
+    // read_block_tx_size: TX_MODE_LARGEST, nothing coded.  residual (5.11.34)
+    const int x4 = (c8 - c8_0) * 2, y4 = (r8 & 7) * 2, cx4 = c8 - c8_0, cy4 = r8 & 7;
+    if (skip) {   // reset_block_context
+      a_lvl[0][x4] = a_lvl[0][x4 + 1] = a_dc[0][x4] = a_dc[0][x4 + 1] = 0;
+      l_lvl[0][y4] = l_lvl[0][y4 + 1] = l_dc[0][y4] = l_dc[0][y4 + 1] = 0;
+      for (int p = 1; p < 3; p++) a_lvl[p][cx4] = a_dc[p][cx4] = l_lvl[p][cy4] = l_dc[p][cy4] = 0;
+      return;
+    }
+    const int is_inter = inter_of(b);
+    const int tx_type = f.tx_type ? f.tx_type[b] : T_DCT_DCT;
+    coeffs(0, x4, y4, 8, f.lev_y + (size_t)b * 64, is_inter, tx_type, f.y_mode ? f.y_mode[b] : 0);
+    coeffs(1, cx4, cy4, 4, f.lev_u + (size_t)b * 16, is_inter, 0, 0);
+    coeffs(2, cx4, cy4, 4, f.lev_v + (size_t)b * 16, is_inter, 0, 0);
+  }
+
+  void write_skip(int b, bool au, bool al, int skip) {
+    const int ctx = (au ? skip_of(b - fi.w8) : 0) + (al ? skip_of(b - 1) : 0);
+    sym(cdf.skip[ctx], 2, skip);
+  }
+  void write_cdef(int r8, int c8, int skip) {   // read_cdef (5.11.56): the index is coded with the first non-skipped block of a 64x64
+    if (skip || cdef_coded) return;
+    const int sb = (r8 >> 3) * fi.sb_cols + (c8 >> 3);
+    ec.literal(f.cdef_idx ? f.cdef_idx[sb] : 0, f.cdef_bits);
+    cdef_coded = true;
+  }
+
+  // ---- intra_frame_mode_info (5.11.7)
+  void intra_frame_mode_info(int r8, int c8, int b, bool au, bool al, int skip) {
+    write_skip(b, au, al, skip);
+    write_cdef(r8, c8, skip);
+    const int ym = f.y_mode[b];
+    const int actx = kIntraModeContext[au ? f.y_mode[b - fi.w8] : DC_PRED], lctx = kIntraModeContext[al ? f.y_mode[b - 1] : DC_PRED];
+    sym(cdf.kf_y_mode[actx][lctx], 13, ym);
+    intra_tail(b, ym);
+  }
+  // intra_angle_info_y, uv_mode, read_cfl_alphas, intra_angle_info_uv (5.11.42 ..): shared by intra blocks of both frame types
+  void intra_tail(int b, int ym) {
+    if (is_directional(ym)) sym(cdf.angle_delta[ym - V_PRED], 7, (f.angle_y ? f.angle_y[b] : 0) + 3);
+    const int uvm = f.uv_mode[b];
+    sym(cdf.uv_mode_cfl[ym], 14, uvm);          // an 8x8 block allows chroma from luma
+    if (uvm == UV_CFL_PRED) {
+      const int au_ = f.cfl_alpha ? f.cfl_alpha[2 * b] : 0, av_ = f.cfl_alpha ? f.cfl_alpha[2 * b + 1] : 0;
+      const int su = au_ == 0 ? 0 : au_ < 0 ? 1 : 2, sv = av_ == 0 ? 0 : av_ < 0 ? 1 : 2;   // CFL_SIGN_ZERO / NEG / POS
+      sym(cdf.cfl_sign, 8, su * 3 + sv - 1);
+      if (su) sym(cdf.cfl_alpha[(su - 1) * 3 + sv], 16, std::abs(au_) - 1);
+      if (sv) sym(cdf.cfl_alpha[(sv - 1) * 3 + su], 16, std::abs(av_) - 1);
+    } else if (is_directional(uvm)) {
+      sym(cdf.angle_delta[uvm - V_PRED], 7, (f.angle_uv ? f.angle_uv[b] : 0) + 3);
+    }
+  }
+
+  void inter_frame_mode_info(int r8, int c8, int b, bool au, bool al, int skip);   // below
+  void mv_stack(int r8, int c8, MvCand *stack, int *num, int *new_ctx, int *ref_ctx);
+  void write_mv_comp(MvCompCdf &m, int diff);
+
+  // ---- coeffs (5.11.39) of one square transform block of n x n (4 or 8) at plane position (x4, y4), tile / superblock relative
+  void coeffs(int plane, int x4, int y4, int n, const int16_t *lev, int is_inter, int tx_type, int y_mode) {
+    const int w4 = n >> 2, ptype = plane > 0, txs = n == 4 ? 0 : 1;      // txSzCtx == txSzSqr for square sizes
+    const uint8_t *scan = n == 4 ? scans().s4 : scans().s8;
+    const int nc = n * n;
+    int eob = 0;
+    for (int c = nc - 1; c >= 0; c--) if (lev[scan[c]]) { eob = c + 1; break; }
+    // all_zero context (9.3)
+    int ctx;
+    if (plane == 0) {
+      ctx = 0;      // the transform covers the whole block
+    } else {
+      int above = 0, left = 0;
+      for (int k = 0; k < w4; k++) { above |= a_lvl[plane][x4 + k] | a_dc[plane][x4 + k]; left |= l_lvl[plane][y4 + k] | l_dc[plane][y4 + k]; }
+      ctx = 7 + (above != 0) + (left != 0);
+    }
+    sym(cdf.txb_skip[txs][ctx], 2, eob == 0);
+    int cul = 0, dc_cat = 0;
+    if (eob) {
+      if (plane == 0) {   // transform_type (5.11.47)
+        if (is_inter) {
+          if (f.reduced_tx_set) sym(cdf.inter_tx3[txs], 2, tx_type == T_IDTX ? 0 : 1);
+          else sym(cdf.inter_tx1[txs], 16, kInterSet1Sym[tx_type]);
+        } else {
+          if (f.reduced_tx_set) sym(cdf.intra_tx2[txs][y_mode], 5, kIntraSet2Sym[tx_type]);
+          else sym(cdf.intra_tx1[txs][y_mode], 7, kIntraSet1Sym[tx_type]);
+        }
+      }
+      // eob_pt_*, eob_extra, eob_extra_bit
+      const int eob_pt = eob < 3 ? eob : floor_log2((uint32_t)(eob - 1)) + 2;   // eob in (2^(pt-2), 2^(pt-1)]
+      if (n == 4) sym(cdf.eob16[ptype][0], 5, eob_pt - 1);
+      else sym(cdf.eob64[ptype][0], 7, eob_pt - 1);
+      if (eob_pt >= 3) {
+        const int off = eob - ((1 << (eob_pt - 2)) + 1);
+        int shift = eob_pt - 3;
+        sym(cdf.eob_extra[txs][ptype][eob_pt - 3], 2, (off >> shift) & 1);
+        for (shift--; shift >= 0; shift--) ec.literal((uint32_t)((off >> shift) & 1), 1);
+      }
+      // levels, last to first
+      uint8_t mag[8 + 4][8 + 4];      // min(|level|, 15) with a zero border on the right and bottom
+      memset(mag, 0, sizeof(mag));
+      for (int i = 0; i < nc; i++) { const int a = std::abs((int)lev[i]); mag[i / n][i % n] = (uint8_t)std::min(a, 15); }
+      for (int c = eob - 1; c >= 0; c--) {
+        const int pos = scan[c], row = pos / n, col = pos % n;
+        const int a = std::abs((int)lev[pos]);
+        if (c == eob - 1) {
+          const int ectx = c == 0 ? 0 : c <= nc / 8 ? 1 : c <= nc / 4 ? 2 : 3;
+          sym(cdf.base_eob[txs][ptype][ectx], 3, std::min(a, 3) - 1);
+        } else {
+          // get_coeff_base_ctx, TX_CLASS_2D (9.3)
+          int m = std::min<int>(mag[row][col + 1], 3) + std::min<int>(mag[row + 1][col], 3) + std::min<int>(mag[row + 1][col + 1], 3) +
+                  std::min<int>(mag[row][col + 2], 3) + std::min<int>(mag[row + 2][col], 3);
+          int bctx = std::min((m + 1) >> 1, 4);
+          if (pos == 0) bctx = 0;
+          else bctx += row + col < 2 ? 1 : row + col < 4 ? 6 : 21;     // Coeff_Base_Ctx_Offset of the square sizes
+          sym(cdf.base[txs][ptype][bctx], 4, std::min(a, 3));
+        }
+        if (a > 2) {     // coeff_br: up to four increments of 0..3
+          int m = mag[row][col + 1] + mag[row + 1][col] + mag[row + 1][col + 1];
+          m = std::min((m + 1) >> 1, 6);
+          const int rctx = pos == 0 ? m : (row < 2 && col < 2) ? m + 7 : m + 14;
+          int rem = a - 3;
+          for (int i = 0; i < 4; i++) {
+            const int k = std::min(rem, 3);
+            sym(cdf.br[txs][ptype][rctx], 4, k);
+            rem -= k;
+            if (k < 3) break;
+          }
+        }
+      }
+      // signs and Golomb remainders, first to last
+      for (int c = 0; c < eob; c++) {
+        const int pos = scan[c], v = lev[pos];
+        if (!v) continue;
+        const int a = std::abs(v);
+        if (c == 0) {
+          int s = 0;
+          for (int k = 0; k < w4; k++) {
+            const int ad = a_dc[plane][x4 + k], ld = l_dc[plane][y4 + k];
+            s += (ad == 2) - (ad == 1) + (ld == 2) - (ld == 1);
+          }
+          sym(cdf.dc_sign[ptype][s < 0 ? 1 : s > 0 ? 2 : 0], 2, v < 0);
+          dc_cat = v < 0 ? 1 : 2;
+        } else {
+          ec.literal((uint32_t)(v < 0), 1);
+        }
+        if (a > 14) {    // read_golomb: x = a - 14 >= 1, length - 1 zeros then x in `length` bits
+          const uint32_t x = (uint32_t)(a - 14);
+          const int len = floor_log2(x) + 1;
+          ec.literal(0, len - 1);
+          ec.literal(x, len);
+        }
+        cul += a;
+      }
+      cul = std::min(cul, 63);
+    }
+    for (int k = 0; k < w4; k++) {
+      a_lvl[plane][x4 + k] = (uint8_t)cul; a_dc[plane][x4 + k] = (uint8_t)dc_cat;
+      l_lvl[plane][y4 + k] = (uint8_t)cul; l_dc[plane][y4 + k] = (uint8_t)dc_cat;
+    }
+  }
+};
+
+// ---- inter_frame_mode_info (5.11.18) for the tool set of this encoder: single reference LAST_FRAME, NEWMV / GLOBALMV,
+// no segmentation, no skip mode, no compound, simple translation, fixed interpolation filter.
+void TileEnc::inter_frame_mode_info(int r8, int c8, int b, bool au, bool al, int skip) {
+  (void)r8; (void)c8; (void)b; (void)au; (void)al; (void)skip;
+  // filled in by the inter-frame part (next section of the file)
+}
+
+// ------------------------------------------------------------------------------------------------ headers
+void write_color_config(BitWriter &w, int bd) {   // color_config (5.5.2), profile 0
+  w.put(bd == 10, 1);   // high_bitdepth
+  w.put(0, 1);          // mono_chrome
+  w.put(0, 1);          // color_description_present_flag
+  w.put(0, 1);          // color_range: studio swing
+  w.put(0, 2);          // chroma_sample_position: unknown
+  w.put(0, 1);          // separate_uv_delta_q
+}
+
+void write_frame_header(BitWriter &w, const FrameInfo &fi, int tile_size_bytes) {   // uncompressed_header (5.9.2)
+  const av1mi_obu_frame &f = *fi.f;
+  w.put(0, 1);                       // show_existing_frame
+  w.put(fi.key ? 0 : 1, 2);          // frame_type: KEY_FRAME / INTER_FRAME
+  w.put(1, 1);                       // show_frame
+  if (!fi.key) w.put(1, 1);          // error_resilient_mode = 1: every frame starts from the default CDFs (primary_ref_frame = NONE)
+  w.put(f.disable_cdf_update ? 1 : 0, 1);
+  // allow_screen_content_tools = seq_force_screen_content_tools = 0: not coded
+  w.put(0, 1);                       // frame_size_override_flag
+  // order_hint: 0 bits.  primary_ref_frame = PRIMARY_REF_NONE (intra frame or error resilient)
+  if (!fi.key) {
+    w.put(0x01, 8);                  // refresh_frame_flags: the frame replaces slot 0
+    // error_resilient_mode && enable_order_hint would code ref_order_hint[]: order hints are off
+    for (int i = 0; i < 7; i++) w.put(0, 3);   // ref_frame_idx[i] = 0: every reference name maps to slot 0 (the previous frame)
+  }
+  // frame_size(): sequence maximum; superres_params(): off; render_size():
+  w.put(0, 1);                       // render_and_frame_size_different
+  if (!fi.key) {
+    w.put(0, 1);                     // allow_high_precision_mv
+    w.put(0, 1);                     // is_filter_switchable
+    w.put(0, 2);                     // interpolation_filter = EIGHTTAP
+    w.put(0, 1);                     // is_motion_mode_switchable
+    // use_ref_frame_mvs = 0 (error resilient)
+  }
+  if (!f.disable_cdf_update) w.put(1, 1);   // disable_frame_end_update_cdf: nothing inherits this frame's CDFs
+  // tile_info (5.9.15)
+  w.put(1, 1);                       // uniform_tile_spacing_flag
+  const int min_log2_cols = tile_log2(64, fi.sb_cols), max_log2_cols = tile_log2(1, std::min(fi.sb_cols, 64));
+  for (int k = min_log2_cols; k < max_log2_cols; k++) {
+    const int inc = k < fi.tile_cols_log2;
+    w.put(inc, 1);                   // increment_tile_cols_log2
+    if (!inc) break;
+  }
+  const int cols_log2 = tile_log2(1, fi.tile_cols);
+  const int min_log2_tiles = std::max(min_log2_cols, tile_log2(2304, fi.sb_rows * fi.sb_cols));
+  const int min_log2_rows = std::max(min_log2_tiles - cols_log2, 0), max_log2_rows = tile_log2(1, std::min(fi.sb_rows, 64));
+  for (int k = min_log2_rows; k < max_log2_rows; k++) {
+    const int inc = k < fi.tile_rows_log2;
+    w.put(inc, 1);                   // increment_tile_rows_log2
+    if (!inc) break;
+  }
+  const int rows_log2 = tile_log2(1, fi.tile_rows);
+  if (cols_log2 || rows_log2) {
+    w.put(0, cols_log2 + rows_log2); // context_update_tile_id
+    w.put((uint32_t)(tile_size_bytes - 1), 2);   // tile_size_bytes_minus_1
+  }
+  // quantization_params (5.9.12)
+  w.put((uint32_t)f.base_q_idx, 8);
+  w.put(0, 1);                       // DeltaQYDc: delta_coded
+  w.put(0, 1);                       // DeltaQUDc
+  w.put(0, 1);                       // DeltaQUAc
+  w.put(0, 1);                       // using_qmatrix
+  w.put(0, 1);                       // segmentation_enabled (5.9.14)
+  w.put(0, 1);                       // delta_q_present (5.9.17, base_q_idx > 0)
+  // loop_filter_params (5.9.11)
+  w.put((uint32_t)f.lf_level[0], 6); w.put((uint32_t)f.lf_level[1], 6);
+  if (f.lf_level[0] || f.lf_level[1]) { w.put((uint32_t)f.lf_level[2], 6); w.put((uint32_t)f.lf_level[3], 6); }
+  w.put((uint32_t)f.lf_sharpness, 3);
+  w.put(0, 1);                       // loop_filter_delta_enabled
+  // cdef_params (5.9.19)
+  w.put((uint32_t)(f.cdef_damping - 3), 2);
+  w.put((uint32_t)f.cdef_bits, 2);
+  for (int i = 0; i < (1 << f.cdef_bits); i++) {
+    w.put(f.cdef_y[i] >> 2, 4); w.put(f.cdef_y[i] & 3, 2);
+    w.put(f.cdef_uv[i] >> 2, 4); w.put(f.cdef_uv[i] & 3, 2);
+  }
+  // lr_params (5.9.20)
+  static const int kLrCode[4] = { 0, 2, 3, 1 };   // inverse of Remap_Lr_Type: none, Wiener, self-guided, switchable
+  bool uses_lr = false, uses_chroma_lr = false;
+  for (int p = 0; p < 3; p++) {
+    w.put((uint32_t)kLrCode[f.lr_type[p]], 2);
+    if (f.lr_type[p]) { uses_lr = true; if (p) uses_chroma_lr = true; }
+  }
+  if (uses_lr) {
+    w.put(f.lr_unit_shift > 0, 1);                         // lr_unit_shift
+    if (f.lr_unit_shift > 0) w.put(f.lr_unit_shift > 1, 1); // lr_unit_extra_shift
+    if (uses_chroma_lr) w.put((uint32_t)f.lr_uv_shift, 1);
+  }
+  w.put(0, 1);                       // tx_mode_select = 0: TX_MODE_LARGEST (5.9.21)
+  if (!fi.key) w.put(0, 1);          // reference_select (5.9.23): single reference
+  // skip_mode_params: not allowed without order hints.  allow_warped_motion: off in the sequence
+  w.put((uint32_t)(f.reduced_tx_set ? 1 : 0), 1);
+  if (!fi.key) for (int i = 0; i < 7; i++) w.put(0, 1);   // global_motion_params (5.9.24): is_global = 0 for LAST..ALTREF
+  // film_grain_params: not present in the sequence
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ public
+std::vector<uint8_t> temporal_delimiter_obu() { return make_obu(2, {}); }
+
+std::vector<uint8_t> sequence_header_obu(const SequenceParams &sp) {   // sequence_header_obu (5.5.1)
+  BitWriter w;
+  w.put(0, 3);      // seq_profile 0: 4:2:0, 8 / 10 bit
+  w.put(0, 1);      // still_picture
+  w.put(0, 1);      // reduced_still_picture_header
+  w.put(0, 1);      // timing_info_present_flag
+  w.put(0, 1);      // initial_display_delay_present_flag
+  w.put(0, 5);      // operating_points_cnt_minus_1
+  w.put(0, 12);     // operating_point_idc[0]
+  w.put(31, 5);     // seq_level_idx[0] = 31: "maximum parameters" (one tile per superblock exceeds every numbered level's tile count)
+  w.put(0, 1);      // seq_tier[0]
+  const int wb = floor_log2((uint32_t)std::max(sp.width - 1, 1)) + 1, hb = floor_log2((uint32_t)std::max(sp.height - 1, 1)) + 1;
+  w.put((uint32_t)(wb - 1), 4); w.put((uint32_t)(hb - 1), 4);
+  w.put((uint32_t)(sp.width - 1), wb); w.put((uint32_t)(sp.height - 1), hb);
+  w.put(0, 1);      // frame_id_numbers_present_flag
+  w.put(0, 1);      // use_128x128_superblock
+  w.put(0, 1);      // enable_filter_intra
+  w.put(1, 1);      // enable_intra_edge_filter
+  w.put(0, 1);      // enable_interintra_compound
+  w.put(0, 1);      // enable_masked_compound
+  w.put(0, 1);      // enable_warped_motion
+  w.put(0, 1);      // enable_dual_filter
+  w.put(0, 1);      // enable_order_hint
+  w.put(0, 1);      // seq_choose_screen_content_tools
+  w.put(0, 1);      // seq_force_screen_content_tools = 0 (so seq_force_integer_mv = SELECT_INTEGER_MV, not coded)
+  w.put(0, 1);      // enable_superres
+  w.put(1, 1);      // enable_cdef
+  w.put(1, 1);      // enable_restoration
+  write_color_config(w, sp.bit_depth);
+  w.put(0, 1);      // film_grain_params_present
+  w.trailing_bits();
+  return make_obu(1, w.b);
+}
+
+bool frame_obu(const av1mi_obu_frame &f, int threads, std::vector<uint8_t> *out, std::string *err) {
+  if (!check(f, err)) return false;
+  const FrameInfo fi = frame_info(f);
+  const int ntiles = fi.tile_cols * fi.tile_rows;
+  std::vector<std::vector<uint8_t>> tiles((size_t)ntiles);
+  std::atomic<int> next(0);
+  auto work = [&] {
+    for (int t; (t = next.fetch_add(1)) < ntiles;) {
+      TileEnc te(fi, t / fi.tile_cols, t % fi.tile_cols);
+      te.run();
+      tiles[(size_t)t].swap(te.ec.out);
+    }
+  };
+  const int nt = std::max(1, std::min(threads, ntiles));
+  if (nt == 1) {
+    work();
+  } else {
+    std::vector<std::thread> pool;
+    for (int i = 0; i < nt; i++) pool.emplace_back(work);
+    for (auto &t : pool) t.join();
+  }
+  size_t largest = 0, total = 0;
+  for (int t = 0; t + 1 < ntiles; t++) largest = std::max(largest, tiles[(size_t)t].size());
+  for (auto &t : tiles) total += t.size();
+  const int tsb = largest <= 0x100 ? 1 : largest <= 0x10000 ? 2 : largest <= 0x1000000 ? 3 : 4;   // tile_size_minus_1 must fit
+  BitWriter w;
+  write_frame_header(w, fi, tsb);
+  w.byte_align();                                 // frame_obu: byte_alignment after the header (5.10)
+  // tile_group_obu (5.11.1)
+  if (ntiles > 1) { w.put(0, 1); w.byte_align(); }   // tile_start_and_end_present_flag
+  std::vector<uint8_t> payload;
+  payload.swap(w.b);
+  payload.reserve(payload.size() + total + (size_t)ntiles * 4);
+  for (int t = 0; t < ntiles; t++) {
+    const std::vector<uint8_t> &d = tiles[(size_t)t];
+    if (t + 1 < ntiles) {
+      const size_t sz = d.size() - 1;             // tile_size_minus_1, little endian (le(TileSizeBytes))
+      for (int k = 0; k < tsb; k++) payload.push_back((uint8_t)(sz >> (8 * k)));
+    }
+    payload.insert(payload.end(), d.begin(), d.end());
+  }
+  *out = make_obu(6, payload);
+  return true;
+}
+
+bool temporal_unit(const av1mi_obu_frame &f, bool with_sequence_header, int threads, std::vector<uint8_t> *out, std::string *err) {
+  std::vector<uint8_t> fr;
+  if (!frame_obu(f, threads, &fr, err)) return false;
+  *out = temporal_delimiter_obu();
+  if (with_sequence_header) {
+    SequenceParams sp; sp.width = f.width; sp.height = f.height; sp.bit_depth = f.bit_depth;
+    const std::vector<uint8_t> sh = sequence_header_obu(sp);
+    out->insert(out->end(), sh.begin(), sh.end());
+  }
+  out->insert(out->end(), fr.begin(), fr.end());
+  return true;
+}
+
+}  // namespace av1
+}  // namespace av1mi_host

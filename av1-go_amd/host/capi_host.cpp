@@ -3,6 +3,7 @@
 #include <cstring>
 #include "daemon.hpp"
 #include "entropy.hpp"
+#include "av1_bitstream.hpp"
 
 using namespace av1mi_host;
 
@@ -76,6 +77,18 @@ int av1mi_host_entropy_final_models(int w, int h, int key, const int16_t *ly, co
   if ((size_t)cap_words * 2 < sizeof(m)) return -1;
   memcpy(out, &m, sizeof(m));
   return (int)(sizeof(m) / 2);
+}
+// AV1 bitstream writer (av1_bitstream.hpp): one temporal unit (delimiter [+ sequence header] + frame) for a frame description.
+// Returns the size in bytes (copied into out when it fits in cap), -1 on a description the writer cannot code (text in err).
+long long av1mi_obu_write_temporal_unit(const av1mi_obu_frame *f, int with_sequence_header, int threads, uint8_t *out, long long cap,
+                                        char *err, int errcap) {
+  std::vector<uint8_t> b; std::string e;
+  if (!av1::temporal_unit(*f, with_sequence_header != 0, threads, &b, &e)) {
+    if (err && errcap > 0) { strncpy(err, e.c_str(), errcap - 1); err[errcap - 1] = 0; }
+    return -1;
+  }
+  if ((long long)b.size() <= cap && out) memcpy(out, b.data(), b.size());
+  return (long long)b.size();
 }
 // RunJobPool over `n` source files joined with '\n'; statuses joined with '\n' into buf; returns the number of successes
 int av1mi_host_job_pool(const char *sources, int workers, int ngpus, double ratio, const char *state_dir, char *buf, int cap) {

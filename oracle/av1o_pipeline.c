@@ -56,6 +56,10 @@ int av1o_intra_predict(const void *ref, int ref_stride, int bd, int bw, int bh, 
                        int n_bottomleft_px, uint16_t *pred);
 
 static const int intra_candidates[11] = { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 12 }; /* DC V H D45 D135 D113 D157 D203 D67 SMOOTH PAETH */
+/* Mode_To_Txfm (AV1 spec 5.11.47 compute_tx_type / libaom intra_mode_to_tx_type): the transform type an intra CHROMA block
+ * takes from its prediction mode (it is not coded in the bitstream); luma types are coded explicitly and stay DCT_DCT here. */
+const uint8_t av1o_mode_to_txfm[14] = { DCT_DCT, ADST_DCT, DCT_ADST, DCT_DCT, ADST_ADST, ADST_DCT, DCT_ADST, DCT_ADST, ADST_DCT,
+                                         ADST_ADST, ADST_DCT, DCT_ADST, ADST_ADST, DCT_DCT };
 
 static unsigned morton(unsigned x, unsigned y) {
   unsigned m = 0;
@@ -84,6 +88,7 @@ static int encode_block(int nplanes, const void *const *src, void *const *rec, i
     }
     if (best < 0 || sad < best) { best = sad; best_mode = mode; }
   }
+  const int tx_type = nplanes == 2 ? av1o_mode_to_txfm[best_mode] : DCT_DCT;   /* chroma: implied by the mode; luma: coded, DCT_DCT */
   for (int p = 0; p < nplanes; p++) {
     int16_t resid[64 * 64];
     int32_t coef[1024], dq[1024];
@@ -93,13 +98,13 @@ static int encode_block(int nplanes, const void *const *src, void *const *rec, i
       for (int c = 0; c < bs; c++)
         resid[r * bs + c] = (int16_t)(px_get(src[p], bd, (size_t)(y + r) * stride + x + c) - pred[p][r * bs + c]);
     const int n = bs > 32 ? 1024 : bs * bs, ls = av1o_tx_scale(tx_size);
-    av1o_fwd_txfm2d(resid, bs, coef, tx_size, DCT_DCT, bd);
+    av1o_fwd_txfm2d(resid, bs, coef, tx_size, tx_type, bd);
     av1o_quantize(coef, n, dc_q, ac_q, ls, levels[p], NULL);
     av1o_dequantize(levels[p], n, dc_q, ac_q, ls, bd, dq);
     /* reconstruct: write the prediction, then add the residual in place */
     for (int r = 0; r < bs; r++)
       for (int c = 0; c < bs; c++) px_set(rec[p], bd, (size_t)(y + r) * stride + x + c, pred[p][r * bs + c]);
-    av1o_inv_txfm2d_add(dq, (char *)rec[p] + ((size_t)y * stride + x) * bps, stride, tx_size, DCT_DCT, bd, 1);
+    av1o_inv_txfm2d_add(dq, (char *)rec[p] + ((size_t)y * stride + x) * bps, stride, tx_size, tx_type, bd, 1);
   }
   return best_mode;
 }
