@@ -212,7 +212,7 @@ const uint8_t kIntraModeContext[13] = { 0, 1, 2, 3, 4, 4, 4, 4, 3, 0, 1, 2, 0 };
 // symbol of a 2-D-class transform type inside each set = inverse of Tx_Type_Intra_Inv_Set1/2, Tx_Type_Inter_Inv_Set1/3 (5.11.47)
 const int8_t kIntraSet1Sym[16] = { 1, 5, 6, 4, -1, -1, -1, -1, -1, 0, 2, 3, -1, -1, -1, -1 };
 const int8_t kIntraSet2Sym[16] = { 1, 3, 4, 2, -1, -1, -1, -1, -1, 0, -1, -1, -1, -1, -1, -1 };
-const int8_t kInterSet1Sym[16] = { 1, 8, 9, 10, 11, 12, 13, 14, 15, 0, 2, 3, 4, 5, 6, 7 };
+const int8_t kInterSet1Sym[16] = { 7, 8, 9, 12, 10, 11, 13, 14, 15, 0, 1, 2, 3, 4, 5, 6 };
 inline bool is_directional(int m) { return m >= V_PRED && m <= D67_PRED; }
 inline bool tx_class_2d(int t) { return t <= T_FLIPADST_ADST; }
 
@@ -244,6 +244,7 @@ struct FrameInfo {
   int qcat;
   int lr_size[3], lr_rows[3], lr_cols[3];
   bool key;
+  std::vector<uint8_t> *newmv;   // per block: coded with NEWMV (has_newmv of the MV prediction process); written by the tile coders
 };
 
 bool check(const av1mi_obu_frame &f, std::string *err) {
@@ -597,11 +598,177 @@ struct TileEnc {
   }
 };
 
-// ---- inter_frame_mode_info (5.11.18) for the tool set of this encoder: single reference LAST_FRAME, NEWMV / GLOBALMV,
-// no segmentation, no skip mode, no compound, simple translation, fixed interpolation filter.
+// ---- inter frames.  Tool set: single reference LAST_FRAME, modes NEWMV / NEARESTMV / NEARMV / GLOBALMV (whichever codes the
+// encoder's vector), no segmentation, no skip mode, no compound, simple translation, fixed interpolation filter; intra blocks
+// are allowed.  All blocks are 8x8, so every candidate of the MV prediction list has weight 2 * len = 4 (7.10.2.2 - 7.10.2.4).
+inline unsigned morton8(unsigned x, unsigned y) {   // z-order index inside a superblock of 8 x 8 blocks
+  unsigned m = 0;
+  for (int i = 0; i < 3; i++) m |= ((x >> i) & 1u) << (2 * i) | ((y >> i) & 1u) << (2 * i + 1);
+  return m;
+}
+
+// find_mv_stack (7.10.2) for a single-reference block: the list, its weights, and the mode contexts
+void TileEnc::mv_stack(int r8, int c8, MvCand *stack, int *num_out, int *new_ctx, int *ref_ctx) {
+  int num = 0, new_count = 0;
+  bool found = false;
+  auto inside = [&](int r, int c) { return r >= r8_0 && r < r8_1 && c >= c8_0 && c < c8_1; };
+  auto add = [&](int r, int c, bool count_new) {     // add_ref_mv_candidate + search_stack_process (7.10.2.7, 7.10.2.8), weight 4
+    if (!inside(r, c)) return;
+    const int nb = blk(r, c);
+    if (!inter_of(nb)) return;                        // intra neighbour: no candidate
+    const int16_t mx = f.mv[2 * nb], my = f.mv[2 * nb + 1];   // already at quarter-sample precision: lower_mv_precision is the identity
+    if (count_new && (*fi.newmv)[(size_t)nb]) new_count++;
+    found = true;
+    int i = 0;
+    for (; i < num; i++) if (stack[i].x == mx && stack[i].y == my) break;
+    if (i < num) stack[i].weight += 4;
+    else if (num < 8) { stack[num].x = mx; stack[num].y = my; stack[num].weight = 4; num++; }
+  };
+  add(r8 - 1, c8, true);                              // scan_row(-1)
+  const bool above0 = found; found = false;
+  add(r8, c8 - 1, true);                              // scan_col(-1)
+  const bool left0 = found; found = false;
+  {   // scan_point(-1, bw4): the top-right block counts only if it has been decoded already
+    const int tr = r8 - 1, tc = c8 + 1;
+    bool decoded = false;
+    if (inside(tr, tc)) {
+      if ((tr >> 3) < (r8 >> 3)) decoded = true;                       // superblock row above
+      else if ((tc >> 3) == (c8 >> 3)) decoded = morton8(tc & 7, tr & 7) < morton8(c8 & 7, r8 & 7);
+    }
+    if (decoded) add(tr, tc, true);
+  }
+  bool above = above0 || found; found = false;
+  const int close = (above ? 1 : 0) + (left0 ? 1 : 0);
+  const int num_nearest = num, num_new = new_count;
+  for (int i = 0; i < num_nearest; i++) stack[i].weight += 640;   // REF_CAT_LEVEL
+  // (no temporal candidates: use_ref_frame_mvs = 0, ZeroMvContext = 0)
+  add(r8 - 1, c8 - 1, false);                         // scan_point(-1, -1)
+  above = above || found; found = false;
+  bool left = left0;
+  add(r8 - 2, c8, false); above = above || found; found = false;      // scan_row(-3)
+  add(r8, c8 - 2, false); left = left || found; found = false;        // scan_col(-3)
+  add(r8 - 3, c8, false); above = above || found; found = false;      // scan_row(-5)
+  add(r8, c8 - 3, false); left = left || found; found = false;        // scan_col(-5)
+  const int total = (above ? 1 : 0) + (left ? 1 : 0);
+  // sorting process (7.10.2.11): the nearest entries, then the rest, each by descending weight (stable bubble sort)
+  auto sort_range = [&](int a, int b) {
+    for (int len = b; len > a;) {
+      int nr = a;
+      for (int i = a + 1; i < len; i++)
+        if (stack[i - 1].weight < stack[i].weight) { std::swap(stack[i - 1], stack[i]); nr = i; }
+      len = nr;
+    }
+  };
+  sort_range(0, num_nearest);
+  sort_range(num_nearest, num);
+  // extra search process (7.10.2.12): adds vectors of neighbours that use OTHER reference frames; every inter block here uses
+  // LAST_FRAME, so its vector is in the list already.  Context and clamping process (7.10.2.14):
+  if (close == 0) { *new_ctx = std::min(total, 1); *ref_ctx = total; }
+  else if (close == 1) { *new_ctx = 3 - std::min(num_new, 1); *ref_ctx = 2 + total; }
+  else { *new_ctx = 5 - std::min(num_new, 1); *ref_ctx = 5; }
+  const int mi_r = r8 * 2, mi_c = c8 * 2;
+  const int border = 128 + 2 * 4 * 8;                 // MV_BORDER + block size in 1/8 samples
+  const int top = -(mi_r * 4 * 8) - border, bottom = (fi.mi_rows - 2 - mi_r) * 4 * 8 + border;
+  const int lft = -(mi_c * 4 * 8) - border, right = (fi.mi_cols - 2 - mi_c) * 4 * 8 + border;
+  for (int i = 0; i < num; i++) {
+    stack[i].y = (int16_t)std::min(std::max<int>(stack[i].y, top), bottom);
+    stack[i].x = (int16_t)std::min(std::max<int>(stack[i].x, lft), right);
+  }
+  for (int i = num; i < 2; i++) { stack[i].x = stack[i].y = 0; stack[i].weight = 0; }   // GlobalMvs: identity
+  *num_out = num;
+}
+
+// read_mv_component (5.11.33), quarter-sample precision: diff is even and non-zero
+void TileEnc::write_mv_comp(MvCompCdf &m, int diff) {
+  sym(m.sign, 2, diff < 0);
+  const int off = std::abs(diff) - 1;
+  const int cls = (off >> 3) < 2 ? 0 : floor_log2((uint32_t)(off >> 3));
+  sym(m.cls, 11, cls);
+  if (cls == 0) {
+    sym(m.class0, 2, off >> 3);
+    sym(m.class0_fr[off >> 3], 4, (off >> 1) & 3);
+  } else {
+    const int o = off - (2 << (cls + 2)), d = o >> 3;
+    for (int i = 0; i < cls; i++) sym(m.bits[i], 2, (d >> i) & 1);
+    sym(m.fr, 4, (o >> 1) & 3);
+  }
+  // mv_class0_hp / mv_hp: allow_high_precision_mv = 0, implied 1
+}
+
 void TileEnc::inter_frame_mode_info(int r8, int c8, int b, bool au, bool al, int skip) {
-  (void)r8; (void)c8; (void)b; (void)au; (void)al; (void)skip;
-  // filled in by the inter-frame part (next section of the file)
+  write_skip(b, au, al, skip);      // inter_segment_id, read_skip_mode: nothing to code
+  write_cdef(r8, c8, skip);
+  const int is_inter = inter_of(b);
+  {   // is_inter (9.3)
+    const bool ai = au ? !inter_of(b - fi.w8) : false, li = al ? !inter_of(b - 1) : false;   // AboveIntra / LeftIntra
+    int ctx;
+    if (au && al) ctx = (li && ai) ? 3 : (li || ai);
+    else if (au || al) ctx = 2 * (au ? ai : li);
+    else ctx = 0;
+    sym(cdf.is_inter[ctx], 2, is_inter);
+  }
+  if (!is_inter) {   // intra_block_mode_info (5.11.22): y_mode with the size-group context (Size_Group[BLOCK_8X8] = 1)
+    const int ym = f.y_mode[b];
+    sym(cdf.y_mode[1], 13, ym);
+    intra_tail(b, ym);
+    (*fi.newmv)[(size_t)b] = 0;
+    return;
+  }
+  // read_ref_frames (5.11.25): single_ref_p1 = 0, single_ref_p3 = 0, single_ref_p4 = 0 -> LAST_FRAME.  The contexts compare
+  // counts of neighbouring references (9.3): only LAST_FRAME ever occurs, so each is 1 (no inter neighbour) or 2.
+  const int n_last = (au && inter_of(b - fi.w8) ? 1 : 0) + (al && inter_of(b - 1) ? 1 : 0);
+  const int rctx = n_last ? 2 : 1;
+  sym(cdf.single_ref[rctx][0], 2, 0);
+  sym(cdf.single_ref[rctx][2], 2, 0);
+  sym(cdf.single_ref[rctx][3], 2, 0);
+  MvCand st[8];
+  int num, new_ctx, ref_ctx;
+  mv_stack(r8, c8, st, &num, &new_ctx, &ref_ctx);
+  const int mx = f.mv[2 * b], my = f.mv[2 * b + 1];
+  // the cheapest mode that reproduces the encoder's vector: NEARESTMV, NEARMV (index 1..3), GLOBALMV, else NEWMV
+  int mode = 3, ref_idx = 0;      // 0 NEARESTMV, 1 NEARMV, 2 GLOBALMV, 3 NEWMV
+  if (st[0].x == mx && st[0].y == my) mode = 0;
+  else {
+    for (int i = 1; i < std::max(num, 2) && i < 4; i++)
+      if (st[i].x == mx && st[i].y == my) { mode = 1; ref_idx = i; break; }
+    if (mode == 3 && mx == 0 && my == 0) mode = 2;
+  }
+  sym(cdf.new_mv[new_ctx], 2, mode != 3);
+  if (mode != 3) {
+    sym(cdf.zero_mv[0], 2, mode != 2);
+    if (mode != 2) sym(cdf.ref_mv[ref_ctx], 2, mode == 1);
+  }
+  auto drl_ctx = [&](int i) {     // drl_mode context from the weights of entries i and i + 1 (9.3)
+    const bool a = st[i].weight >= 640, c = st[i + 1].weight >= 640;
+    return a && c ? 0 : a ? 1 : !c ? 2 : 0;
+  };
+  if (mode == 3) {
+    // NEWMV: the predictor is entry RefMvIdx of the list; pick the closest of the entries the syntax can name (0..2)
+    const int nsel = std::min(num, 3);
+    long best = -1;
+    for (int i = 0; i < std::max(nsel, 1); i++) {
+      const long c = std::abs(mx - st[i].x) + std::abs(my - st[i].y);
+      if (best < 0 || c < best) { best = c; ref_idx = i; }
+    }
+    for (int i = 0; i < 2; i++)
+      if (num > i + 1) {
+        sym(cdf.drl[drl_ctx(i)], 2, ref_idx != i);
+        if (ref_idx == i) break;
+      }
+    const int pred = num <= 1 ? 0 : ref_idx;            // assign_mv (5.11.26)
+    const int dx = mx - st[pred].x, dy = my - st[pred].y;   // read_mv (5.11.32): component 0 is the row (vertical) difference
+    sym(cdf.mv_joint, 4, (dx ? 1 : 0) + (dy ? 2 : 0));
+    if (dy) write_mv_comp(cdf.mv[0], dy);
+    if (dx) write_mv_comp(cdf.mv[1], dx);
+  } else if (mode == 1) {
+    for (int i = 1; i < 3; i++)
+      if (num > i + 1) {
+        sym(cdf.drl[drl_ctx(i)], 2, ref_idx != i);
+        if (ref_idx == i) break;
+      }
+  }
+  (*fi.newmv)[(size_t)b] = mode == 3;
+  // read_interintra_mode, read_motion_mode, read_compound_type, interpolation filter: nothing to code with this tool set
 }
 
 // ------------------------------------------------------------------------------------------------ headers
@@ -741,7 +908,9 @@ std::vector<uint8_t> sequence_header_obu(const SequenceParams &sp) {   // sequen
 
 bool frame_obu(const av1mi_obu_frame &f, int threads, std::vector<uint8_t> *out, std::string *err) {
   if (!check(f, err)) return false;
-  const FrameInfo fi = frame_info(f);
+  FrameInfo fi = frame_info(f);
+  std::vector<uint8_t> newmv((size_t)fi.w8 * fi.h8, 0);
+  fi.newmv = &newmv;
   const int ntiles = fi.tile_cols * fi.tile_rows;
   std::vector<std::vector<uint8_t>> tiles((size_t)ntiles);
   std::atomic<int> next(0);

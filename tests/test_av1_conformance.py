@@ -71,3 +71,46 @@ def test_threads_and_cdf_update_flag_do_not_change_the_pixels(O):
     for tu in (b, c):
         got = D.decode(tu)[0]
         assert all((got[i] == stages[3][i]).all() for i in range(3))
+
+
+def _gop(O, P, w, h, bd, q, nframes, first=3):
+    """oracle closed-GOP chain (key + P frames, every frame through deblock + CDEF + Wiener LR) and its AV1 stream"""
+    import av1stream
+    import synth
+    Y, U, V = synth.frames(w, h, nframes, bd, first)
+    stream, refs, ref, hdr = b"", [], None, None
+    for t in range(nframes):
+        if t == 0:
+            r, hdr, stages = _chain(O, P, Y[0], U[0], V[0], bd, q)
+            stream += av1stream.temporal_unit(w, h, bd, q, y_mode=r["modes_y"], uv_mode=r["modes_uv"], lev_y=r["lev_y"], lev_u=r["lev_u"],
+                                              lev_v=r["lev_v"], **hdr)
+            ref = stages[3]
+        else:
+            r = O.inter_encode_frame((Y[t], U[t], V[t]), ref, bd, q, 8)
+            stream += av1stream.temporal_unit(w, h, bd, q, frame_type=1, with_sequence_header=False, mv=r["mvs"], skip=r["skip"],
+                                              lev_y=r["lev_y"], lev_u=r["lev_u"], lev_v=r["lev_v"], **hdr)
+            acq = O.ac_q(q, bd)
+            lvl = hdr["lf_level"][0]
+            mi_y = np.full((h // 4, w // 4), P.lf_mi_word(3, 3, lvl, lvl), np.uint32)
+            mi_c = np.full((h // 8, w // 8), P.lf_mi_word(2, 2, lvl, lvl), np.uint32)
+            dbl = [O.deblock_plane(r["rec_y"], bd, 0, mi_y), O.deblock_plane(r["rec_u"], bd, 1, mi_c), O.deblock_plane(r["rec_v"], bd, 1, mi_c)]
+            nsb = ((h + 63) // 64) * ((w + 63) // 64)
+            cdef = O.cdef_frame(dbl[0], dbl[1], dbl[2], bd, hdr["cdef_damping"], np.tile(P.cdef_strength_from_q(acq, bd), (nsb, 1)),
+                                r["skip"].reshape(h // 8, w // 8))
+            uy, uc = hdr["lr_units"][0], hdr["lr_units"][1]
+            ref = [O.lr_plane(cdef[0], dbl[0], bd, 0, 64, uy), O.lr_plane(cdef[1], dbl[1], bd, 1, 64, uc), O.lr_plane(cdef[2], dbl[2], bd, 1, 64, uc)]
+        refs.append(ref)
+    return stream, refs
+
+
+@pytest.mark.parametrize("w,h,bd,q,n", [(64, 64, 8, 128, 2), (192, 128, 8, 128, 4), (200, 136, 10, 60, 3), (328, 184, 8, 200, 3)])
+def test_closed_gop_stream_decodes_to_the_oracle_chain(O, w, h, bd, q, n):
+    """P frames: sub-pel motion compensation (K4, all of a frame's vectors), inter residual, the filters on inter frames, a P
+    frame that references a P frame — the whole decoded sequence equals the oracle's reference frames."""
+    import pipeline as P
+    stream, refs = _gop(O, P, w, h, bd, q, n)
+    got = D.decode(stream)
+    assert len(got) == n
+    for t in range(n):
+        for i in range(3):
+            assert (got[t][i] == refs[t][i]).all(), "frame %d plane %d differs from dav1d" % (t, i)
