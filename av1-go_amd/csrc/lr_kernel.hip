@@ -18,10 +18,11 @@
 
 namespace av1mi {
 
+// Sgr_Params (spec 7.17.3): { r0, eps0, r1, eps1 }; s = ((1 << 20) + n*n*eps / 2) / (n*n*eps) is derived in the kernel
 __device__ constexpr int kSgrParams[16][4] = {
-  { 2, 140, 1, 3236 }, { 2, 112, 1, 2158 }, { 2, 93, 1, 1618 }, { 2, 80, 1, 1438 }, { 2, 70, 1, 1295 }, { 2, 58, 1, 1177 },
-  { 2, 47, 1, 1079 }, { 2, 37, 1, 996 }, { 2, 30, 1, 925 }, { 2, 25, 1, 863 }, { 0, -1, 1, 2589 }, { 0, -1, 1, 1618 },
-  { 0, -1, 1, 1177 }, { 0, -1, 1, 925 }, { 2, 56, 0, -1 }, { 2, 22, 0, -1 } };
+  { 2, 12, 1, 4 }, { 2, 15, 1, 6 }, { 2, 18, 1, 8 }, { 2, 21, 1, 9 }, { 2, 24, 1, 10 }, { 2, 29, 1, 11 },
+  { 2, 36, 1, 12 }, { 2, 45, 1, 13 }, { 2, 56, 1, 14 }, { 2, 68, 1, 15 }, { 0, 0, 1, 5 }, { 0, 0, 1, 8 },
+  { 0, 0, 1, 11 }, { 0, 0, 1, 14 }, { 2, 30, 0, 0 }, { 2, 75, 0, 0 } };
 
 // SUBY: vertical subsampling of the plane (0 luma, 1 chroma of 4:2:0) — stripe height and offset become constants
 template <typename Pix, int SUBY>

@@ -114,3 +114,159 @@ def test_closed_gop_stream_decodes_to_the_oracle_chain(O, w, h, bd, q, n):
     for t in range(n):
         for i in range(3):
             assert (got[t][i] == refs[t][i]).all(), "frame %d plane %d differs from dav1d" % (t, i)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# ARBITRARY symbols (not the encoder's own decisions): the writer codes them, dav1d decodes them, and the result must equal
+# the oracle primitives applied to the same symbols (tests/av1_recon.py).  Levels come from real residuals (forward
+# transform + quantiser of random blocks up to full amplitude), so the stream stays inside the spec's conformance limits on
+# intermediate values — decoders may legitimately differ on streams that overflow them.
+def _real_levels(O, rng, n, ts, types, bd, q, p_zero=0.15):
+    k = 8 if ts == 1 else 4
+    out = np.zeros((n, k, k), np.int16)
+    dcq, acq = O.dc_q(q, bd), O.ac_q(q, bd)
+    for i in range(n):
+        amp = int(rng.choice([0, 2, 8, 40, (1 << bd) - 1], p=[p_zero, 0.3, 0.55 - p_zero, 0.1, 0.05]))
+        if amp == 0:
+            continue
+        res = rng.integers(-amp, amp + 1, (k, k)).astype(np.int16)
+        if rng.random() < 0.5:
+            res = (res * np.linspace(1, 0, k)[None, :]).astype(np.int16) + rng.integers(-amp, amp + 1) // 2
+        res = np.clip(res, -(1 << bd) + 1, (1 << bd) - 1).astype(np.int16)
+        out[i] = O.quantize(O.fwd_txfm2d(res, ts, int(types[i]), bd), dcq, acq, 0)[0]
+    return out
+
+
+@pytest.mark.parametrize("w,h,bd,q,seed", [(128, 128, 8, 100, 1), (128, 128, 8, 128, 2), (192, 136, 10, 60, 7), (200, 72, 10, 180, 8),
+                                           (72, 200, 10, 30, 9)])
+def test_random_intra_symbols_all_modes_angles_cfl_and_transform_types(O, w, h, bd, q, seed):
+    """every intra mode x angle delta -3..3 (edge filter / upsampling corners included), chroma from luma with random alphas,
+    luma DCT/ADST combinations, mode-implied chroma transforms, escape-coded levels: K3 + K2 + K8 on symbols the encoder's
+    own search would never pick"""
+    import av1_recon as R
+    import av1stream
+    rng = np.random.default_rng(seed)
+    nb = (w // 8) * (h // 8)
+    ym, uvm = rng.integers(0, 13, nb).astype(np.uint8), rng.integers(0, 14, nb).astype(np.uint8)
+    ay, auv = rng.integers(-3, 4, nb).astype(np.int8), rng.integers(-3, 4, nb).astype(np.int8)
+    cfl = rng.integers(-16, 17, (nb, 2)).astype(np.int8)
+    cfl[(cfl[:, 0] == 0) & (cfl[:, 1] == 0), 0] = 5          # the joint sign excludes (zero, zero)
+    tx = rng.integers(0, 4, nb).astype(np.uint8)
+    uvt = [R.MODE_TO_TXFM[m] for m in uvm]
+    ly, lu, lv = _real_levels(O, rng, nb, 1, tx, bd, q), _real_levels(O, rng, nb, 0, uvt, bd, q), _real_levels(O, rng, nb, 0, uvt, bd, q)
+    tu = av1stream.temporal_unit(w, h, bd, q, y_mode=ym, uv_mode=uvm, angle_y=ay, angle_uv=auv, cfl_alpha=cfl, tx_type=tx, lev_y=ly, lev_u=lu,
+                                 lev_v=lv)
+    rec = R.recon_frame(O, w, h, bd, q, ym, uvm, ly, lu, lv, ay, auv, cfl.reshape(-1), tx)
+    got = D.decode(tu, inloop_filters=0)[0]
+    for i in range(3):
+        assert (got[i] == rec[i]).all(), "plane %d" % i
+
+
+@pytest.mark.parametrize("w,h,bd,q,seed,p_inter", [(128, 128, 8, 128, 1, 1.0), (128, 128, 8, 100, 3, 1.0), (192, 136, 10, 60, 5, 0.7),
+                                                   (200, 72, 8, 180, 6, 0.5), (72, 200, 10, 30, 7, 0.8)])
+def test_random_inter_symbols_vectors_skip_and_intra_blocks(O, w, h, bd, q, seed, p_inter):
+    """P frame with clustered + outlying vectors (up to 75 samples outside the picture: reference edge clamping), quarter-sample
+    phases, skip flags, intra blocks between inter blocks: the MV prediction list / mode contexts of the writer (any desync
+    fails dav1d's strict trailing-bits check) and K4 on arbitrary vectors"""
+    import av1_recon as R
+    import av1stream
+    import synth
+    rng = np.random.default_rng(seed)
+    nb = (w // 8) * (h // 8)
+    Y, U, V = synth.frames(w, h, 1, bd, 3)
+    k = O.intra_encode_frame(Y[0], U[0], V[0], bd, 8, q)
+    tu0 = av1stream.temporal_unit(w, h, bd, q, y_mode=k["modes_y"], uv_mode=k["modes_uv"], lev_y=k["lev_y"], lev_u=k["lev_u"], lev_v=k["lev_v"])
+    ref = [k["rec_y"], k["rec_u"], k["rec_v"]]       # no in-loop filter is switched on in these headers
+    inter = (rng.random(nb) < p_inter).astype(np.uint8)
+    ym, uvm = rng.integers(0, 13, nb).astype(np.uint8), rng.integers(0, 13, nb).astype(np.uint8)
+    ay, auv = rng.integers(-3, 4, nb).astype(np.int8), rng.integers(-3, 4, nb).astype(np.int8)
+    base = rng.integers(-6, 7, (4, 2)) * 2
+    mv = base[rng.integers(0, 4, nb)].astype(np.int16)
+    far = rng.random(nb) < 0.2
+    mv[far] = (rng.integers(-300, 301, (int(far.sum()), 2)) * 2).astype(np.int16)
+    mv[rng.random(nb) < 0.1] = 0
+    tx = np.where(inter == 1, 0, rng.integers(0, 4, nb)).astype(np.uint8)
+    ct = [t if i else R.MODE_TO_TXFM[m] for t, i, m in zip(tx, inter, uvm)]
+    ly, lu, lv = (_real_levels(O, rng, nb, 1, tx, bd, q, 0.3), _real_levels(O, rng, nb, 0, ct, bd, q, 0.3), _real_levels(O, rng, nb, 0, ct, bd, q, 0.3))
+    skip = (rng.random(nb) < 0.25).astype(np.uint8)
+    tu1 = av1stream.temporal_unit(w, h, bd, q, frame_type=1, with_sequence_header=False, y_mode=ym, uv_mode=uvm, angle_y=ay, angle_uv=auv,
+                                  tx_type=tx, is_inter=inter, mv=mv, skip=skip, lev_y=ly, lev_u=lu, lev_v=lv)
+    rec = R.recon_frame(O, w, h, bd, q, ym, uvm, ly, lu, lv, ay, auv, None, tx, inter, mv.reshape(-1), skip, ref)
+    got = D.decode(tu0 + tu1)
+    assert len(got) == 2
+    for i in range(3):
+        assert (got[1][i] == rec[i]).all(), "plane %d" % i
+
+
+@pytest.mark.parametrize("w,h,bd,q,seed", [(192, 128, 8, 160, 1), (192, 128, 8, 160, 2), (192, 128, 8, 160, 4), (192, 128, 8, 160, 5),
+                                           (200, 136, 10, 100, 11), (200, 136, 10, 100, 13), (328, 72, 8, 220, 21)])
+def test_random_filter_parameters(O, w, h, bd, q, seed):
+    """deblocking with four independent levels + sharpness (K5), CDEF with up to 8 strength sets, a per-superblock index,
+    any damping and skipped blocks (K6), loop restoration with Wiener taps over their whole range, all 16 self-guided sets
+    with random projection weights, switchable units, unit sizes 32..256 (K7): each stage compared on its own"""
+    import av1stream
+    import synth
+    rng = np.random.default_rng(seed)
+    Y, U, V = synth.frames(w, h, 1, bd, 3)
+    r = O.intra_encode_frame(Y[0], U[0], V[0], bd, 8, q)
+    nb = (w // 8) * (h // 8)
+    allz = (np.abs(r["lev_y"]).reshape(nb, -1).sum(1) + np.abs(r["lev_u"]).reshape(nb, -1).sum(1) + np.abs(r["lev_v"]).reshape(nb, -1).sum(1)) == 0
+    skip = (allz & (rng.random(nb) < 0.7)).astype(np.uint8)
+    lv = [int(x) for x in rng.integers(0, 64, 4)]
+    if rng.random() < 0.2:
+        lv[0] = 0
+    sharp = int(rng.integers(0, 8))
+    mi_y = np.full((h // 4, w // 4), int(O.lf_mi(3, 3, lv[0], lv[1])), np.uint32)
+    mi_u = np.full((h // 8, w // 8), int(O.lf_mi(2, 2, lv[2], lv[2])), np.uint32)
+    mi_v = np.full((h // 8, w // 8), int(O.lf_mi(2, 2, lv[3], lv[3])), np.uint32)
+    rec = [r["rec_y"], r["rec_u"], r["rec_v"]]
+    if lv[0] == 0 and lv[1] == 0:        # loop_filter_level[0] == [1] == 0 switches the whole filter off (spec 5.9.11)
+        dbl = rec
+    else:
+        dbl = [O.deblock_plane(rec[0], bd, 0, mi_y, sharp), O.deblock_plane(rec[1], bd, 1, mi_u, sharp), O.deblock_plane(rec[2], bd, 1, mi_v, sharp)]
+    nsb = ((h + 63) // 64) * ((w + 63) // 64)
+    cbits = int(rng.integers(0, 4))
+    nset = 1 << cbits
+    sets = np.stack([rng.integers(0, 16, nset), rng.integers(0, 4, nset), rng.integers(0, 16, nset), rng.integers(0, 4, nset)], 1).astype(np.uint8)
+    idx = rng.integers(0, nset, nsb).astype(np.uint8)
+    damping = int(rng.integers(3, 7))
+    cdef = O.cdef_frame(dbl[0], dbl[1], dbl[2], bd, damping, sets[idx], skip.reshape(h // 8, w // 8))
+    lr_shift, uvs = int(rng.integers(0, 3)), int(rng.integers(0, 2))
+    usz = [64 << lr_shift, (64 << lr_shift) >> uvs, (64 << lr_shift) >> uvs]
+    lrt = [int(x) for x in rng.integers(0, 4, 3)]
+
+    def units(p):
+        ph, pw = (h, w) if p == 0 else (h // 2, w // 2)
+        u = np.zeros((O.lr_units(usz[p], ph), O.lr_units(usz[p], pw), 8), np.int8)
+        for i in range(u.shape[0]):
+            for j in range(u.shape[1]):
+                t = lrt[p] if lrt[p] < 3 else int(rng.integers(0, 3))
+                if lrt[p] < 3 and rng.random() < 0.25:
+                    t = 0
+                if t == 1:
+                    c = [int(rng.integers(lo, hi + 1)) for lo, hi in ((-5, 10), (-23, 8), (-17, 46))]
+                    d = [int(rng.integers(lo, hi + 1)) for lo, hi in ((-5, 10), (-23, 8), (-17, 46))]
+                    if p:
+                        c[0] = d[0] = 0              # chroma: 5 taps
+                    u[i, j] = O.lr_unit_wiener(c, d)
+                elif t == 2:
+                    s, x0, x1 = int(rng.integers(0, 16)), int(rng.integers(-96, 32)), int(rng.integers(-32, 96))
+                    if s >= 14:
+                        x1 = min(max(128 - x0, -32), 95)   # r1 == 0: the second weight is derived, not coded
+                    if 10 <= s < 14:
+                        x0 = 0                             # r0 == 0
+                    u[i, j] = O.lr_unit_sgr(s, x0, x1)
+        return u
+
+    un = [units(p) for p in range(3)]
+    out = [O.lr_plane(cdef[p], dbl[p], bd, int(p > 0), usz[p], un[p]) if lrt[p] else cdef[p] for p in range(3)]
+    tu = av1stream.temporal_unit(w, h, bd, q, y_mode=r["modes_y"], uv_mode=r["modes_uv"], lev_y=r["lev_y"], lev_u=r["lev_u"], lev_v=r["lev_v"],
+                                 skip=skip, lf_level=lv, lf_sharpness=sharp, cdef_damping=damping, cdef_bits=cbits,
+                                 cdef_y=[int(a) << 2 | int(b) for a, b in sets[:, :2]], cdef_uv=[int(a) << 2 | int(b) for a, b in sets[:, 2:]],
+                                 cdef_idx=idx, lr_type=lrt, lr_unit_shift=lr_shift, lr_uv_shift=uvs,
+                                 lr_units=[un[p] if lrt[p] else None for p in range(3)])
+    for name, flt, ref in (("deblocked", D.INLOOP_DEBLOCK, dbl), ("cdef", D.INLOOP_DEBLOCK | D.INLOOP_CDEF, cdef), ("restored", D.INLOOP_ALL, out)):
+        got = D.decode(tu, inloop_filters=flt)[0]
+        for i in range(3):
+            assert (got[i] == ref[i]).all(), "%s plane %d (levels %s sharpness %d, cdef sets %d damping %d, lr %s units %s)" % (
+                name, i, lv, sharp, nset, damping, lrt, usz)
