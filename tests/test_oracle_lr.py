@@ -68,7 +68,7 @@ def test_sgr_smooths_noise_and_respects_units(O):
     base = np.full((64, 192), 120, np.int32)
     noisy = np.clip(base + rng.integers(-10, 11, base.shape), 0, 255).astype(np.uint8)
     units = _units(O, 64, 64, 192, O.lr_unit_none())
-    units[0, 1] = O.lr_unit_sgr(2, 31, 40)   # weights flt0 31, cdef 40, flt1 57
+    units[0, 1] = O.lr_unit_sgr(9, 31, 0)    # the strongest set (eps 68 / 15); weights flt0 31, cdef 0, flt1 97
     out = O.lr_plane(noisy, noisy, 8, 0, 64, units)
     assert (out[:, :64] == noisy[:, :64]).all() and (out[:, 128:] == noisy[:, 128:]).all()
     mid = out[:, 64:128].astype(int)
