@@ -79,6 +79,95 @@ class EntropyJob(C.Structure):
                 ("d_out", C.c_void_p), ("out_cap", C.c_size_t), ("d_frame_off", C.c_void_p)]
 
 
+class GopConfig(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("bit_depth", C.c_int), ("base_q_idx", C.c_int), ("gop_length", C.c_int),
+                ("segments", C.c_int), ("search_range", C.c_int)]
+
+
+class FrameParams(C.Structure):
+    _fields_ = [("frame_type", C.c_int), ("base_q_idx", C.c_int), ("lf_level", C.c_int * 4), ("lf_sharpness", C.c_int),
+                ("cdef_damping", C.c_int), ("cdef_y", C.c_uint8), ("cdef_uv", C.c_uint8), ("lr_unit_size", C.c_int),
+                ("lr_unit_y", C.c_int8 * 8), ("lr_unit_uv", C.c_int8 * 8)]
+
+
+class GopFrame(C.Structure):
+    _fields_ = [("params", FrameParams), ("segments", C.c_int), ("blocks_per_frame", C.c_size_t), ("y_mode", C.c_void_p),
+                ("uv_mode", C.c_void_p), ("mv", C.c_void_p), ("skip", C.c_void_p), ("lev_y", C.c_void_p), ("lev_u", C.c_void_p),
+                ("lev_v", C.c_void_p)]
+
+
+def policy_frame_params(base_q_idx, bit_depth, frame_type):
+    """the session's filter-parameter policy for one frame (include/av1mi.h av1mi_policy_frame_params); no GPU needed"""
+    p = FrameParams()
+    rc = load().av1mi_policy_frame_params(int(base_q_idx), int(bit_depth), int(frame_type), C.byref(p))
+    if rc:
+        raise Av1miError(rc, "av1mi_policy_frame_params")
+    return p
+
+
+def _view(ptr, shape, dtype):
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    return np.frombuffer((C.c_uint8 * n).from_address(ptr), dtype=dtype).reshape(shape)
+
+
+class GopSession:
+    """av1mi_gop_* (include/av1mi.h): closed GOPs in lockstep, policy and PCIe plumbing inside the library."""
+
+    def __init__(self, ctx, width, height, bit_depth, base_q_idx, gop_length, segments=1, search_range=8):
+        self.ctx, self.w, self.h, self.bd, self.segments = ctx, width, height, bit_depth, segments
+        self.cfg = GopConfig(width, height, bit_depth, base_q_idx, gop_length, segments, search_range)
+        self.g = C.c_void_p()
+        ctx.lib.av1mi_gop_open.argtypes = [C.c_void_p, C.POINTER(GopConfig), C.POINTER(C.c_void_p)]
+        ctx._chk(ctx.lib.av1mi_gop_open(ctx.h, C.byref(self.cfg), C.byref(self.g)))
+        for name in ("av1mi_gop_close", "av1mi_gop_acquire_input", "av1mi_gop_submit", "av1mi_gop_collect", "av1mi_gop_pending",
+                     "av1mi_gop_download_reference"):
+            getattr(ctx.lib, name).argtypes = None
+        ctx.lib.av1mi_gop_close.restype = None
+        self.dt = np.uint8 if bit_depth == 8 else np.uint16
+
+    def input_planes(self):
+        """numpy views of the pinned host planes of the next batch: shapes [segments * height, width] and the half-size chroma"""
+        y, u, v = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        self.ctx._chk(self.ctx.lib.av1mi_gop_acquire_input(self.g, C.byref(y), C.byref(u), C.byref(v)))
+        S, w, h = self.segments, self.w, self.h
+        return (_view(y.value, (S * h, w), self.dt), _view(u.value, (S * h // 2, w // 2), self.dt), _view(v.value, (S * h // 2, w // 2), self.dt))
+
+    def submit(self, frame_type=-1):
+        self.ctx._chk(self.ctx.lib.av1mi_gop_submit(self.g, int(frame_type)))
+
+    def pending(self):
+        return self.ctx.lib.av1mi_gop_pending(self.g)
+
+    def collect_raw(self):
+        f = GopFrame()
+        self.ctx._chk(self.ctx.lib.av1mi_gop_collect(self.g, C.byref(f)))
+        return f
+
+    def collect(self):
+        """dict of numpy views (valid for one more submit) + params"""
+        f = self.collect_raw()
+        S, nb = f.segments, f.blocks_per_frame
+        out = dict(params=f.params, frame_type=f.params.frame_type, lev_y=_view(f.lev_y, (S, nb, 8, 8), np.int16),
+                   lev_u=_view(f.lev_u, (S, nb, 4, 4), np.int16), lev_v=_view(f.lev_v, (S, nb, 4, 4), np.int16))
+        if f.params.frame_type == 0:
+            out["y_mode"], out["uv_mode"] = _view(f.y_mode, (S, nb), np.uint8), _view(f.uv_mode, (S, nb), np.uint8)
+        else:
+            out["mv"], out["skip"] = _view(f.mv, (S, nb, 2), np.int16), _view(f.skip, (S, nb), np.uint8)
+        return out
+
+    def download_reference(self):
+        S, w, h = self.segments, self.w, self.h
+        y, u, v = np.empty((S * h, w), self.dt), np.empty((S * h // 2, w // 2), self.dt), np.empty((S * h // 2, w // 2), self.dt)
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        self.ctx._chk(self.ctx.lib.av1mi_gop_download_reference(self.g, vp(y), vp(u), vp(v)))
+        return y, u, v
+
+    def close(self):
+        if self.g:
+            self.ctx.lib.av1mi_gop_close(self.g)
+            self.g = None
+
+
 N_KERNEL_KINDS = 16   # enum av1mi_kernel_kind
 _lib = None
 

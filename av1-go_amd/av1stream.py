@@ -80,3 +80,27 @@ def temporal_unit(width, height, bit_depth, base_q_idx, frame_type=0, with_seque
     if n > cap:
         raise RuntimeError("temporal unit of %d bytes exceeds the buffer" % n)
     return out[:n].tobytes()
+
+
+def header_from_params(p, width, height):
+    """keyword arguments of temporal_unit() for a frame whose filter parameters are an av1mi_frame_params (GOP session policy)"""
+    ur = lambda n: max(1, (n + p.lr_unit_size // 2) // p.lr_unit_size)
+    uy = np.tile(np.array(list(p.lr_unit_y), np.int8), (ur(height), ur(width), 1))
+    uc = np.tile(np.array(list(p.lr_unit_uv), np.int8), (ur(height // 2), ur(width // 2), 1))
+    shift = {64: 0, 128: 1, 256: 2}[p.lr_unit_size]
+    return dict(frame_type=p.frame_type, lf_level=tuple(p.lf_level), lf_sharpness=p.lf_sharpness, cdef_damping=p.cdef_damping,
+                cdef_y=(p.cdef_y,), cdef_uv=(p.cdef_uv,), lr_type=(int(p.lr_unit_y[0]), int(p.lr_unit_uv[0]), int(p.lr_unit_uv[0])),
+                lr_unit_shift=shift, lr_uv_shift=0, lr_units=(uy, uc, uc))
+
+
+def session_frame_unit(width, height, bit_depth, frame, seg, with_sequence_header=None, threads=1):
+    """the temporal unit of segment `seg` of a collected GOP-session batch (av1mi.GopSession.collect())"""
+    p = frame["params"]
+    hdr = header_from_params(p, width, height)
+    if p.frame_type == 0:
+        sym = dict(y_mode=frame["y_mode"][seg], uv_mode=frame["uv_mode"][seg])
+    else:
+        sym = dict(mv=frame["mv"][seg], skip=frame["skip"][seg])
+    sh = (p.frame_type == 0) if with_sequence_header is None else with_sequence_header
+    return temporal_unit(width, height, bit_depth, p.base_q_idx, with_sequence_header=sh, threads=threads, lev_y=frame["lev_y"][seg],
+                         lev_u=frame["lev_u"][seg], lev_v=frame["lev_v"][seg], **sym, **hdr)

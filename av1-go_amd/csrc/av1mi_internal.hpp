@@ -135,4 +135,9 @@ hipError_t launch_entropy_tokens(const EntropyLaunch &L, hipStream_t s);
 hipError_t launch_entropy_code(const EntropyLaunch &L, hipStream_t s);
 hipError_t launch_entropy_pack(const EntropyLaunch &L, hipStream_t s);
 
+// accessors of the opaque context for translation units other than capi.hip (gop_session.hip)
+hipStream_t ctx_stream(av1mi_ctx *ctx);
+int ctx_device(av1mi_ctx *ctx);
+int ctx_fail(av1mi_ctx *ctx, int code, const char *fmt, ...);
+
 }  // namespace av1mi

@@ -114,6 +114,20 @@ int check_tx_launch(av1mi_ctx *ctx, int tx_size, const void *coef, const void *p
 
 }  // namespace
 
+namespace av1mi {
+hipStream_t ctx_stream(av1mi_ctx *ctx) { return ctx->stream; }
+int ctx_device(av1mi_ctx *ctx) { return ctx->device; }
+int ctx_fail(av1mi_ctx *ctx, int code, const char *fmt, ...) {
+  if (ctx) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(ctx->err, sizeof(ctx->err), fmt, ap);
+    va_end(ap);
+  }
+  return code;
+}
+}  // namespace av1mi
+
 extern "C" {
 
 const char *av1mi_version(void) { return "av1mi 0.1.0 (gfx950)"; }

@@ -1,0 +1,320 @@
+// gop_session.hip — the GOP session of include/av1mi.h: closed-GOP orchestration, the encoder's filter-parameter policy and
+// the PCIe plumbing around the block pipeline, in ONE place (round 1 had two hand-kept copies, pipeline.py and
+// host/backend.cpp, that disagreed on the P-frame deblocking level).  What stands in for the encode the reference delegates
+// to its FFmpeg child (internal/ffmpeg/transcode.go:120,194); the caller it serves is internal/daemon/daemon.go:101.
+//
+// Streams.  The context's stream runs the kernels; the session adds an upload stream and a download stream.  Per batch:
+//   up:   wait slot.kernel_done (the kernel that last read this slot's source)  -> H2D of the three source planes -> uploaded
+//   main: wait uploaded -> k_intra_pipe | k_me_int + k_inter_pipe -> symbols_ready -> deblock x3, CDEF, LR x3 -> reference
+//   down: wait symbols_ready -> D2H of the symbols into pinned memory -> downloaded
+// Source and symbol buffers are double-buffered (slot = batch & 1), so batch t + 1 uploads while batch t computes and batch
+// t's symbols download while its filters run; the host codes batch t while the GPU works on t + 1.
+#include <stdio.h>
+#include <string.h>
+#include <new>
+#include <vector>
+#include "av1mi_internal.hpp"
+
+namespace {
+
+// ---- the policy (non-normative encoder choices; mirrored nowhere else) ---------------------------------------------------
+int lf_level_from_q(int ac_q, int bd, bool key) {   // libaom LPF_PICK_FROM_Q: a linear fit of the level to the AC step
+  long g;
+  if (bd == 8) g = key ? ((long)ac_q * 17563 - 421574 + (1 << 17)) >> 18 : ((long)ac_q * 6017 + 650707 + (1 << 17)) >> 18;
+  else g = ((long)ac_q * 20723 + 4060632 + (1 << 19)) >> 20;
+  return (int)(g < 0 ? 0 : g > 63 ? 63 : g);
+}
+void frame_params(int q, int bd, int frame_type, av1mi_frame_params *p) {
+  memset(p, 0, sizeof(*p));
+  const int ac_q = av1mi_ac_q(q, bd), q8 = ac_q >> (bd - 8);
+  p->frame_type = frame_type; p->base_q_idx = q;
+  const int lvl = lf_level_from_q(ac_q, bd, frame_type == 0);
+  p->lf_level[0] = p->lf_level[1] = p->lf_level[2] = p->lf_level[3] = lvl;
+  p->lf_sharpness = 0;
+  p->cdef_damping = 3 + (q8 > 100) + (q8 > 300);
+  int y = q8 < 700 ? (q8 * q8 * 3 + 32768) >> 16 : 15;     // one strength set per frame from the step
+  y = y > 15 ? 15 : y;
+  const int ypri = y + 2 > 15 ? 15 : (y + 2 < 1 ? 1 : y + 2), cpri = y < 1 ? 1 : y;
+  p->cdef_y = (uint8_t)(ypri << 2 | 1); p->cdef_uv = (uint8_t)(cpri << 2 | 1);
+  p->lr_unit_size = 64;
+  static const int8_t wy[8] = { 1, 3, -7, 15, 3, -7, 15, 0 }, wc[8] = { 1, 0, -7, 15, 0, -7, 15, 0 };   // Wiener, libaom's mid-range taps
+  memcpy(p->lr_unit_y, wy, 8); memcpy(p->lr_unit_uv, wc, 8);
+}
+
+struct Slot {
+  void *h_src[3] = { nullptr, nullptr, nullptr };       // pinned
+  void *d_src[3] = { nullptr, nullptr, nullptr };
+  // symbols: device + pinned host mirror
+  void *d_lev[3] = { nullptr, nullptr, nullptr }, *h_lev[3] = { nullptr, nullptr, nullptr };
+  void *d_modes[2] = { nullptr, nullptr }, *h_modes[2] = { nullptr, nullptr };
+  void *d_mv = nullptr, *h_mv = nullptr, *d_skip = nullptr, *h_skip = nullptr;
+  hipEvent_t uploaded = nullptr, kernel_done = nullptr, downloaded = nullptr;
+  bool upload_pending = false, kernel_pending = false;
+  int frame_type = 0;
+};
+
+}  // namespace
+
+struct av1mi_gop {
+  av1mi_ctx *ctx = nullptr;
+  av1mi_gop_config cfg{};
+  size_t ny = 0, nc = 0, nb = 0, bps = 1;      // per BATCH (segments stacked): luma samples, chroma samples, blocks
+  hipStream_t up = nullptr, down = nullptr;
+  Slot slot[2];
+  void *d_rec[3] = {}, *d_dbl[3] = {}, *d_cdef[3] = {}, *d_ref[3] = {};
+  void *d_mi[2][2] = {};                       // [key / inter][luma / chroma] deblocking mode-info maps (one frame, shared by the batch)
+  void *d_cdef_sb[2] = {}, *d_lr[2] = {}, *d_zero_skip = nullptr;
+  av1mi_frame_params params[2];                // key, inter
+  long submitted = 0, collected = 0;           // batches
+  int gop_pos = 0;
+  bool acquired = false;
+  std::vector<void *> dev_allocs, host_allocs;
+};
+
+namespace {
+
+#define G_HIP(expr)                                                                                          \
+  do {                                                                                                       \
+    hipError_t e_ = (expr);                                                                                  \
+    if (e_ != hipSuccess) return av1mi::ctx_fail(g->ctx, AV1MI_E_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+#define G_TRY(expr)                              \
+  do {                                           \
+    int rc_ = (expr);                            \
+    if (rc_ != AV1MI_OK) return rc_;             \
+  } while (0)
+
+int dev_alloc(av1mi_gop *g, void **p, size_t bytes) {
+  G_HIP(hipMalloc(p, bytes ? bytes : 8));
+  g->dev_allocs.push_back(*p);
+  return AV1MI_OK;
+}
+int host_alloc(av1mi_gop *g, void **p, size_t bytes) {
+  G_HIP(hipHostMalloc(p, bytes ? bytes : 8, hipHostMallocDefault));
+  g->host_allocs.push_back(*p);
+  return AV1MI_OK;
+}
+
+int setup(av1mi_gop *g) {
+  const av1mi_gop_config &c = g->cfg;
+  const int w = c.width, h = c.height, S = c.segments;
+  g->bps = c.bit_depth == 8 ? 1 : 2;
+  g->ny = (size_t)w * h * S; g->nc = g->ny / 4; g->nb = g->ny / 64;
+  G_HIP(hipSetDevice(av1mi::ctx_device(g->ctx)));
+  G_HIP(hipStreamCreateWithFlags(&g->up, hipStreamNonBlocking));
+  G_HIP(hipStreamCreateWithFlags(&g->down, hipStreamNonBlocking));
+  for (Slot &s : g->slot) {
+    for (int p = 0; p < 3; p++) {
+      const size_t n = (p ? g->nc : g->ny);
+      G_TRY(host_alloc(g, &s.h_src[p], n * g->bps)); G_TRY(dev_alloc(g, &s.d_src[p], n * g->bps));
+      G_TRY(host_alloc(g, &s.h_lev[p], n * 2)); G_TRY(dev_alloc(g, &s.d_lev[p], n * 2));
+    }
+    for (int k = 0; k < 2; k++) { G_TRY(host_alloc(g, &s.h_modes[k], g->nb)); G_TRY(dev_alloc(g, &s.d_modes[k], g->nb)); }
+    G_TRY(host_alloc(g, &s.h_mv, g->nb * 4)); G_TRY(dev_alloc(g, &s.d_mv, g->nb * 4));
+    G_TRY(host_alloc(g, &s.h_skip, g->nb)); G_TRY(dev_alloc(g, &s.d_skip, g->nb));
+    G_HIP(hipEventCreateWithFlags(&s.uploaded, hipEventDisableTiming));
+    G_HIP(hipEventCreateWithFlags(&s.kernel_done, hipEventDisableTiming));
+    G_HIP(hipEventCreateWithFlags(&s.downloaded, hipEventDisableTiming));
+  }
+  for (int p = 0; p < 3; p++) {
+    const size_t n = (p ? g->nc : g->ny) * g->bps;
+    G_TRY(dev_alloc(g, &g->d_rec[p], n)); G_TRY(dev_alloc(g, &g->d_dbl[p], n)); G_TRY(dev_alloc(g, &g->d_cdef[p], n)); G_TRY(dev_alloc(g, &g->d_ref[p], n));
+  }
+  G_TRY(dev_alloc(g, &g->d_zero_skip, g->nb));
+  G_TRY(av1mi_memset(g->ctx, g->d_zero_skip, 0, g->nb));
+  // constant side information: one map per frame type, shared by every frame of a batch (frame stride 0)
+  const size_t fy = (size_t)w * h, fc = fy / 4;
+  const int nsb = ((w + 63) / 64) * ((h + 63) / 64);
+  auto units = [](int n) { const int u = (n + 32) / 64; return u > 1 ? u : 1; };
+  const size_t uy = (size_t)units(h) * units(w), uc = (size_t)units(h / 2) * units(w / 2);
+  for (int t = 0; t < 2; t++) {
+    frame_params(c.base_q_idx, c.bit_depth, t, &g->params[t]);
+    const av1mi_frame_params &P = g->params[t];
+    // deblocking mode-info words (av1mi_deblock_plane): 8x8 luma / 4x4 chroma transforms, every block edge a prediction edge
+    std::vector<uint32_t> mi(fy / 16, 3u | (3u << 4) | ((uint32_t)P.lf_level[0] << 8) | ((uint32_t)P.lf_level[1] << 16) | (3u << 25));
+    std::vector<uint32_t> mic(fc / 16, 2u | (2u << 4) | ((uint32_t)P.lf_level[2] << 8) | ((uint32_t)P.lf_level[2] << 16) | (3u << 25));
+    G_TRY(dev_alloc(g, &g->d_mi[t][0], mi.size() * 4)); G_TRY(av1mi_upload(g->ctx, g->d_mi[t][0], mi.data(), mi.size() * 4));
+    G_TRY(dev_alloc(g, &g->d_mi[t][1], mic.size() * 4)); G_TRY(av1mi_upload(g->ctx, g->d_mi[t][1], mic.data(), mic.size() * 4));
+  }
+  {
+    const av1mi_frame_params &P = g->params[0];     // CDEF strengths and restoration units do not depend on the frame type
+    std::vector<uint8_t> sb((size_t)nsb * 4);
+    for (int i = 0; i < nsb; i++) { sb[4 * i] = P.cdef_y >> 2; sb[4 * i + 1] = P.cdef_y & 3; sb[4 * i + 2] = P.cdef_uv >> 2; sb[4 * i + 3] = P.cdef_uv & 3; }
+    G_TRY(dev_alloc(g, &g->d_cdef_sb[0], sb.size())); G_TRY(av1mi_upload(g->ctx, g->d_cdef_sb[0], sb.data(), sb.size()));
+    std::vector<int8_t> lr((uy > uc ? uy : uc) * 8);
+    for (size_t i = 0; i < uy; i++) memcpy(&lr[i * 8], P.lr_unit_y, 8);
+    G_TRY(dev_alloc(g, &g->d_lr[0], uy * 8)); G_TRY(av1mi_upload(g->ctx, g->d_lr[0], lr.data(), uy * 8));
+    for (size_t i = 0; i < uc; i++) memcpy(&lr[i * 8], P.lr_unit_uv, 8);
+    G_TRY(dev_alloc(g, &g->d_lr[1], uc * 8)); G_TRY(av1mi_upload(g->ctx, g->d_lr[1], lr.data(), uc * 8));
+  }
+  G_TRY(av1mi_sync(g->ctx));
+  return AV1MI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int av1mi_policy_frame_params(int base_q_idx, int bit_depth, int frame_type, av1mi_frame_params *out) {
+  if (!out || base_q_idx < 0 || base_q_idx > 255 || (bit_depth != 8 && bit_depth != 10) || frame_type < 0 || frame_type > 1) return AV1MI_E_INVAL;
+  frame_params(base_q_idx, bit_depth, frame_type, out);
+  return AV1MI_OK;
+}
+
+int av1mi_gop_open(av1mi_ctx *ctx, const av1mi_gop_config *cfg, av1mi_gop **out) {
+  if (!ctx || !out) return AV1MI_E_INVAL;
+  *out = nullptr;
+  if (!cfg) return av1mi::ctx_fail(ctx, AV1MI_E_INVAL, "null config");
+  if (cfg->width <= 0 || cfg->height <= 0 || (cfg->width & 7) || (cfg->height & 7) || cfg->width > 16384 || cfg->height > 16384)
+    return av1mi::ctx_fail(ctx, AV1MI_E_INVAL, "frame %dx%d must be a multiple of 8", cfg->width, cfg->height);
+  if (cfg->bit_depth != 8 && cfg->bit_depth != 10) return av1mi::ctx_fail(ctx, AV1MI_E_INVAL, "bit depth %d not supported (8 or 10)", cfg->bit_depth);
+  if (cfg->base_q_idx < 1 || cfg->base_q_idx > 255 || cfg->gop_length < 1 || cfg->segments < 1 || cfg->segments > 4096 || cfg->search_range < 0 ||
+      cfg->search_range > 15)
+    return av1mi::ctx_fail(ctx, AV1MI_E_INVAL, "bad base_q_idx / gop_length / segments / search_range");
+  if ((size_t)cfg->height * cfg->segments > 65535u * 8u) return av1mi::ctx_fail(ctx, AV1MI_E_INVAL, "segments x height too large for one launch");
+  av1mi_gop *g = new (std::nothrow) av1mi_gop();
+  if (!g) return AV1MI_E_NOMEM;
+  g->ctx = ctx; g->cfg = *cfg;
+  const int rc = setup(g);
+  if (rc != AV1MI_OK) { av1mi_gop_close(g); return rc; }
+  *out = g;
+  return AV1MI_OK;
+}
+
+void av1mi_gop_close(av1mi_gop *g) {
+  if (!g) return;
+  (void)hipSetDevice(av1mi::ctx_device(g->ctx));
+  (void)av1mi_sync(g->ctx);
+  if (g->up) { (void)hipStreamSynchronize(g->up); (void)hipStreamDestroy(g->up); }
+  if (g->down) { (void)hipStreamSynchronize(g->down); (void)hipStreamDestroy(g->down); }
+  for (Slot &s : g->slot) {
+    if (s.uploaded) (void)hipEventDestroy(s.uploaded);
+    if (s.kernel_done) (void)hipEventDestroy(s.kernel_done);
+    if (s.downloaded) (void)hipEventDestroy(s.downloaded);
+  }
+  for (void *p : g->dev_allocs) (void)hipFree(p);
+  for (void *p : g->host_allocs) (void)hipHostFree(p);
+  delete g;
+}
+
+int av1mi_gop_pending(av1mi_gop *g) { return g ? (int)(g->submitted - g->collected) : 0; }
+
+int av1mi_gop_acquire_input(av1mi_gop *g, void **y, void **u, void **v) {
+  if (!g || !y || !u || !v) return AV1MI_E_INVAL;
+  if (g->submitted - g->collected >= 2) return av1mi::ctx_fail(g->ctx, AV1MI_E_INVAL, "two batches in flight: collect before acquiring the next input");
+  G_HIP(hipSetDevice(av1mi::ctx_device(g->ctx)));
+  Slot &s = g->slot[g->submitted & 1];
+  if (s.upload_pending) { G_HIP(hipEventSynchronize(s.uploaded)); s.upload_pending = false; }   // the copy engine still reads these buffers
+  *y = s.h_src[0]; *u = s.h_src[1]; *v = s.h_src[2];
+  g->acquired = true;
+  return AV1MI_OK;
+}
+
+int av1mi_gop_submit(av1mi_gop *g, int frame_type) {
+  if (!g) return AV1MI_E_INVAL;
+  if (!g->acquired) return av1mi::ctx_fail(g->ctx, AV1MI_E_INVAL, "submit without av1mi_gop_acquire_input");
+  if (g->submitted - g->collected >= 2) return av1mi::ctx_fail(g->ctx, AV1MI_E_INVAL, "two batches in flight: collect first");
+  if (frame_type < -1 || frame_type > 1) return av1mi::ctx_fail(g->ctx, AV1MI_E_INVAL, "frame_type %d", frame_type);
+  if (frame_type < 0) frame_type = g->gop_pos == 0 ? 0 : 1;
+  if (frame_type == 1 && g->submitted == 0) return av1mi::ctx_fail(g->ctx, AV1MI_E_INVAL, "the first frame of a session must be a key frame");
+  G_HIP(hipSetDevice(av1mi::ctx_device(g->ctx)));
+  const av1mi_gop_config &c = g->cfg;
+  const int w = c.width, h = c.height, S = c.segments, bd = c.bit_depth;
+  Slot &s = g->slot[g->submitted & 1];
+  hipStream_t main = av1mi::ctx_stream(g->ctx);
+  // upload: not before the kernel that last read this slot's source has finished
+  if (s.kernel_pending) G_HIP(hipStreamWaitEvent(g->up, s.kernel_done, 0));
+  for (int p = 0; p < 3; p++) G_HIP(hipMemcpyAsync(s.d_src[p], s.h_src[p], (p ? g->nc : g->ny) * g->bps, hipMemcpyHostToDevice, g->up));
+  G_HIP(hipEventRecord(s.uploaded, g->up));
+  s.upload_pending = true;
+  G_HIP(hipStreamWaitEvent(main, s.uploaded, 0));
+  // the block pipeline (the symbols of this slot were downloaded before the slot was collected, so they may be overwritten)
+  if (frame_type == 0) {
+    av1mi_intra_job j;
+    memset(&j, 0, sizeof(j));
+    j.width = w; j.height = h; j.bit_depth = bd; j.nframes = S; j.qindex = c.base_q_idx; j.block_size = 8; j.stride_y = w; j.stride_uv = w / 2;
+    j.d_src_y = s.d_src[0]; j.d_src_u = s.d_src[1]; j.d_src_v = s.d_src[2];
+    j.d_rec_y = g->d_rec[0]; j.d_rec_u = g->d_rec[1]; j.d_rec_v = g->d_rec[2];
+    j.d_lev_y = (int16_t *)s.d_lev[0]; j.d_lev_u = (int16_t *)s.d_lev[1]; j.d_lev_v = (int16_t *)s.d_lev[2];
+    j.d_modes_y = (uint8_t *)s.d_modes[0]; j.d_modes_uv = (uint8_t *)s.d_modes[1];
+    G_TRY(av1mi_intra_encode(g->ctx, &j));
+  } else {
+    av1mi_inter_job j;
+    memset(&j, 0, sizeof(j));
+    j.width = w; j.height = h; j.bit_depth = bd; j.nframes = S; j.qindex = c.base_q_idx; j.search_range = c.search_range; j.stride_y = w; j.stride_uv = w / 2;
+    j.d_src_y = s.d_src[0]; j.d_src_u = s.d_src[1]; j.d_src_v = s.d_src[2];
+    j.d_ref_y = g->d_ref[0]; j.d_ref_u = g->d_ref[1]; j.d_ref_v = g->d_ref[2];
+    j.d_rec_y = g->d_rec[0]; j.d_rec_u = g->d_rec[1]; j.d_rec_v = g->d_rec[2];
+    j.d_lev_y = (int16_t *)s.d_lev[0]; j.d_lev_u = (int16_t *)s.d_lev[1]; j.d_lev_v = (int16_t *)s.d_lev[2];
+    j.d_mvs = (int16_t *)s.d_mv; j.d_skip = (uint8_t *)s.d_skip;
+    G_TRY(av1mi_inter_encode(g->ctx, &j));
+  }
+  G_HIP(hipEventRecord(s.kernel_done, main));
+  s.kernel_pending = true;
+  s.frame_type = frame_type;
+  // symbols -> pinned host memory, beside the filters
+  G_HIP(hipStreamWaitEvent(g->down, s.kernel_done, 0));
+  for (int p = 0; p < 3; p++) G_HIP(hipMemcpyAsync(s.h_lev[p], s.d_lev[p], (p ? g->nc : g->ny) * 2, hipMemcpyDeviceToHost, g->down));
+  if (frame_type == 0) {
+    for (int k = 0; k < 2; k++) G_HIP(hipMemcpyAsync(s.h_modes[k], s.d_modes[k], g->nb, hipMemcpyDeviceToHost, g->down));
+  } else {
+    G_HIP(hipMemcpyAsync(s.h_mv, s.d_mv, g->nb * 4, hipMemcpyDeviceToHost, g->down));
+    G_HIP(hipMemcpyAsync(s.h_skip, s.d_skip, g->nb, hipMemcpyDeviceToHost, g->down));
+  }
+  G_HIP(hipEventRecord(s.downloaded, g->down));
+  // in-loop filters: reconstruction -> reference of the next frame
+  const av1mi_frame_params &P = g->params[frame_type];
+  for (int p = 0; p < 3; p++) {
+    const int pw = p ? w / 2 : w, ph = p ? h / 2 : h;
+    G_TRY(av1mi_deblock_frames(g->ctx, g->d_rec[p], pw, g->d_dbl[p], pw, pw, ph, bd, p > 0, (const uint32_t *)g->d_mi[frame_type][p > 0], pw / 4, 0,
+                               P.lf_sharpness, S));
+  }
+  av1mi_cdef_job cj;
+  memset(&cj, 0, sizeof(cj));
+  cj.width = w; cj.height = h; cj.bit_depth = bd; cj.nframes = S; cj.damping = P.cdef_damping; cj.stride_y = w; cj.stride_uv = w / 2;
+  cj.d_src_y = g->d_dbl[0]; cj.d_src_u = g->d_dbl[1]; cj.d_src_v = g->d_dbl[2];
+  cj.d_dst_y = g->d_cdef[0]; cj.d_dst_u = g->d_cdef[1]; cj.d_dst_v = g->d_cdef[2];
+  cj.d_sb_strength = (const uint8_t *)g->d_cdef_sb[0]; cj.sb_frame_stride = 0;
+  // key frames are coded with skip = 0 everywhere (no block is exempt from CDEF); P frames: the kernel's skip flags, per frame
+  cj.d_skip8 = (const uint8_t *)(frame_type == 0 ? g->d_zero_skip : s.d_skip); cj.skip_frame_stride = frame_type == 0 ? 0 : (size_t)(w / 8) * (h / 8);
+  G_TRY(av1mi_cdef_frames(g->ctx, &cj));
+  for (int p = 0; p < 3; p++) {
+    const int pw = p ? w / 2 : w, ph = p ? h / 2 : h;
+    G_TRY(av1mi_lr_frames(g->ctx, g->d_cdef[p], g->d_dbl[p], g->d_ref[p], pw, pw, ph, bd, p > 0, P.lr_unit_size, (const int8_t *)g->d_lr[p > 0], 0, S));
+  }
+  if (frame_type == 1) {
+    // the skip flags are read by CDEF after symbols_ready: the slot's next inter kernel is two batches away and ordered behind
+    // this CDEF on the main stream, nothing else writes them
+  }
+  g->submitted++;
+  g->gop_pos = frame_type == 0 ? 1 % c.gop_length : (g->gop_pos + 1) % c.gop_length;
+  g->acquired = false;
+  return AV1MI_OK;
+}
+
+int av1mi_gop_collect(av1mi_gop *g, av1mi_gop_frame *out) {
+  if (!g || !out) return AV1MI_E_INVAL;
+  if (g->submitted == g->collected) return av1mi::ctx_fail(g->ctx, AV1MI_E_INVAL, "nothing in flight");
+  G_HIP(hipSetDevice(av1mi::ctx_device(g->ctx)));
+  Slot &s = g->slot[g->collected & 1];
+  G_HIP(hipEventSynchronize(s.downloaded));
+  memset(out, 0, sizeof(*out));
+  out->params = g->params[s.frame_type];
+  out->segments = g->cfg.segments;
+  out->blocks_per_frame = g->nb / (size_t)g->cfg.segments;
+  if (s.frame_type == 0) { out->y_mode = (const uint8_t *)s.h_modes[0]; out->uv_mode = (const uint8_t *)s.h_modes[1]; }
+  else { out->mv = (const int16_t *)s.h_mv; out->skip = (const uint8_t *)s.h_skip; }
+  out->lev_y = (const int16_t *)s.h_lev[0]; out->lev_u = (const int16_t *)s.h_lev[1]; out->lev_v = (const int16_t *)s.h_lev[2];
+  g->collected++;
+  return AV1MI_OK;
+}
+
+int av1mi_gop_download_reference(av1mi_gop *g, void *y, void *u, void *v) {
+  if (!g || !y || !u || !v) return AV1MI_E_INVAL;
+  G_TRY(av1mi_sync(g->ctx));
+  void *dst[3] = { y, u, v };
+  for (int p = 0; p < 3; p++) G_TRY(av1mi_download(g->ctx, dst[p], g->d_ref[p], (p ? g->nc : g->ny) * g->bps));
+  return AV1MI_OK;
+}
+
+}  // extern "C"

@@ -22,41 +22,7 @@
 #include <string>
 #include <vector>
 
-extern "C" {
-// Frame description (plain C: also bound from Python through libav1mi_host.so, and by the cgo shim of INTEGRATION.md).
-// All block arrays are raster order over the (width/8) x (height/8) grid of 8x8 luma blocks.
-typedef struct av1mi_obu_frame {
-  int32_t width, height;       // luma samples, multiples of 8
-  int32_t bit_depth;           // 8 or 10
-  int32_t frame_type;          // 0 key frame, 1 inter frame (reference LAST = the previously coded frame)
-  int32_t base_q_idx;          // 1..255
-  int32_t lf_level[4];         // deblocking levels: luma vertical edges, luma horizontal edges, U, V (0..63)
-  int32_t lf_sharpness;        // 0..7
-  int32_t cdef_damping;        // 3..6
-  int32_t cdef_bits;           // 0..3: 1 << cdef_bits strength sets
-  uint8_t cdef_y[8];           // per set: (primary strength 0..15) << 2 | secondary code 0..3 (3 stands for strength 4)
-  uint8_t cdef_uv[8];
-  const uint8_t *cdef_idx;     // per 64x64 superblock (raster), index of its strength set; NULL = all 0
-  int32_t lr_type[3];          // per plane: 0 none, 1 Wiener, 2 self-guided, 3 switchable (frame restoration type)
-  int32_t lr_unit_shift;       // luma restoration unit = 64 << shift (0..2)
-  int32_t lr_uv_shift;         // chroma unit = luma unit >> lr_uv_shift (0 or 1)
-  const int8_t *lr_units[3];   // per plane: unit rows x unit cols records of 8 bytes as in include/av1mi.h (av1mi_lr_frames)
-  int32_t reduced_tx_set;      // 0 or 1
-  int32_t disable_cdf_update;  // 0 or 1
-  int32_t tile_cols_log2, tile_rows_log2;  // -1 = one superblock per tile (what the GPU pipeline's prediction assumes)
-  const uint8_t *y_mode;       // intra blocks: 0 DC .. 12 PAETH
-  const int8_t *angle_y;       // -3..3 for directional modes; NULL = 0
-  const uint8_t *uv_mode;      // 0..12, 13 = chroma from luma
-  const int8_t *angle_uv;      // NULL = 0
-  const int8_t *cfl_alpha;     // 2 per block (U, V), -16..16, used where uv_mode == 13; NULL = none
-  const uint8_t *skip;         // 1 = block coded with skip (no residual); NULL = 0
-  const uint8_t *tx_type;      // luma transform type per block (enum av1mi_tx_type); NULL = DCT_DCT
-  const uint8_t *is_inter;     // inter frames: 1 = inter block (NULL = all inter)
-  const int16_t *mv;           // inter blocks: (x, y) in 1/8 luma samples, multiples of 2 (quarter-sample precision)
-  const int16_t *lev_y;        // 64 levels per block, row-major (row = vertical frequency)
-  const int16_t *lev_u, *lev_v;// 16 levels per block
-} av1mi_obu_frame;
-}
+#include "../../include/av1mi_host.h"
 
 namespace av1mi_host {
 namespace av1 {

@@ -4,6 +4,7 @@
 #include "daemon.hpp"
 #include "entropy.hpp"
 #include "av1_bitstream.hpp"
+#include "mux.hpp"
 
 using namespace av1mi_host;
 
@@ -20,6 +21,16 @@ int av1mi_host_transcode_args(const char *in, const char *out, int has_video, in
   strncpy(buf, j.c_str(), cap - 1); buf[cap - 1] = 0;
   return ok ? (int)a.size() : -1;
 }
+// The drop-in for internal/ffmpeg/transcode.go:194 `RunTranscode(ffmpegPath string, args []string) (int, error)`: what the cgo
+// shim of INTEGRATION.md binds.  Returns the exit code of the contract (0 = output written, -1 = could not run, else failed);
+// the error text (<= 800 chars + "...", transcode.go:295-297) goes to err.  Declared in include/av1mi_host.h.
+int av1mi_run_transcode(int argc, const char *const *argv, char *err, size_t errcap) {
+  std::vector<std::string> a;
+  for (int i = 0; i < argc; i++) a.push_back(argv[i] ? argv[i] : "");
+  const RunResult rr = RunTranscode("av1mi", a);
+  if (err && errcap) { strncpy(err, rr.err.c_str(), errcap - 1); err[errcap - 1] = 0; }
+  return rr.exitCode;
+}
 // runs the replacement RunTranscode on an argv joined with '\n'; error text into buf; returns the exit code
 int av1mi_host_run_transcode(const char *joined, char *buf, int cap) {
   std::vector<std::string> a; std::string s = joined; size_t p = 0, q;
@@ -30,10 +41,11 @@ int av1mi_host_run_transcode(const char *joined, char *buf, int cap) {
   return rr.exitCode;
 }
 // ProcessJob on a source file; returns 0 when the reference would return nil; status and reason into the buffers
-int av1mi_host_process_job(const char *source, long long orig_size, double ratio, const char *state_dir, int wait_s, char *status,
-                           char *reason, int cap) {
+int av1mi_host_process_job(const char *source, long long orig_size, double ratio, const char *state_dir, int wait_s, int replace_source,
+                           char *status, char *reason, int cap) {
   Job job; job.ID = "test"; job.SourcePath = source; job.OriginalSize = orig_size;
   TranscodeConfig cfg; cfg.MaxSizeRatio = ratio; cfg.JobStateDir = state_dir ? state_dir : ""; cfg.StableWaitSeconds = wait_s;
+  cfg.ReplaceSource = replace_source != 0;
   ProbeResult pr; pr.HasVideo = true; pr.has_video_stream = true; pr.VideoStream.Height = 720;
   const std::string e = ProcessJob(&job, "av1mi", pr, cfg);
   strncpy(status, job.Status.c_str(), cap - 1); status[cap - 1] = 0;
@@ -89,6 +101,19 @@ long long av1mi_obu_write_temporal_unit(const av1mi_obu_frame *f, int with_seque
   }
   if ((long long)b.size() <= cap && out) memcpy(out, b.data(), b.size());
   return (long long)b.size();
+}
+// container hook for the CPU tests: writes `n` temporal units (concatenated in data, sizes[i] bytes each) to path; 0 = OK
+int av1mi_host_mux_units(const char *path, int w, int h, int bd, int fps_n, int fps_d, const uint8_t *data, const long long *sizes,
+                         const uint8_t *keys, int n) {
+  StreamSink sink; std::string err;
+  av1::SequenceParams sp; sp.width = w; sp.height = h; sp.bit_depth = bd;
+  if (!sink.open(path, sp, fps_n, fps_d, &err)) return 1;
+  for (int i = 0; i < n; i++) {
+    std::vector<uint8_t> tu(data, data + sizes[i]);
+    data += sizes[i];
+    if (!sink.write(tu, keys[i] != 0, &err)) { sink.abort(); return 2; }
+  }
+  return sink.close(&err) ? 0 : 3;
 }
 // RunJobPool over `n` source files joined with '\n'; statuses joined with '\n' into buf; returns the number of successes
 int av1mi_host_job_pool(const char *sources, int workers, int ngpus, double ratio, const char *state_dir, char *buf, int cap) {

@@ -22,11 +22,24 @@ void split(const std::string &path, std::string *dir, std::string *stem, std::st
   *ext = dot == std::string::npos || dot == 0 ? "" : base.substr(dot);
 }
 void write_text(const std::string &path, const std::string &text) { std::ofstream f(path); f << text; }
+std::string json_escape(const std::string &s) {           // what encoding/json does for the strings of jobs.SaveJob
+  std::string o;
+  for (unsigned char c : s) {
+    if (c == '"' || c == '\\') { o += '\\'; o += (char)c; }
+    else if (c == '\n') o += "\\n";
+    else if (c == '\r') o += "\\r";
+    else if (c == '\t') o += "\\t";
+    else if (c < 0x20) { char b[8]; snprintf(b, sizeof(b), "\\u%04x", c); o += b; }
+    else o += (char)c;
+  }
+  return o;
+}
 void save_job(const Job &j, const std::string &dir) {     // jobs.SaveJob, jobs.go:61-79 (fields this path owns)
   if (dir.empty() || j.ID.empty()) return;
   std::ofstream f(dir + "/" + j.ID + ".json");
-  f << "{\n  \"id\": \"" << j.ID << "\",\n  \"source_path\": \"" << j.SourcePath << "\",\n  \"output_path\": \"" << j.OutputPath
-    << "\",\n  \"status\": \"" << j.Status << "\",\n  \"reason\": \"" << j.Reason << "\",\n  \"original_bytes\": " << j.OriginalSize
+  f << "{\n  \"id\": \"" << json_escape(j.ID) << "\",\n  \"source_path\": \"" << json_escape(j.SourcePath) << "\",\n  \"output_path\": \""
+    << json_escape(j.OutputPath) << "\",\n  \"status\": \"" << json_escape(j.Status) << "\",\n  \"reason\": \"" << json_escape(j.Reason)
+    << "\",\n  \"original_bytes\": " << j.OriginalSize
     << ",\n  \"new_bytes\": " << j.NewSize << ",\n  \"is_webrip_like\": " << (j.IsWebRipLike ? "true" : "false") << "\n}\n";
 }
 void write_why(const std::string &source, const std::string &reason) {   // metadata.WriteWhyFile, probe.go:398
@@ -93,6 +106,19 @@ std::string ProcessJob(Job *job, const std::string &backendPath, const ProbeResu
     write_why(job->SourcePath, job->Reason);
     write_text(dir + "/" + stem + ".av1qsvd-skip", "skip");
     remove(outputPath.c_str());
+    save_job(*job, cfg.JobStateDir);
+    return "";
+  }
+  if (!cfg.ReplaceSource) {
+    // NOT the reference's step (daemon.go:154 renames the output over the source): this backend's file has no audio / subtitle
+    // streams, so the source stays and the coded file is kept beside it.  See TranscodeConfig::ReplaceSource.
+    const std::string kept = dir + "/" + stem + ".av1mi.mkv";
+    if (rename(outputPath.c_str(), kept.c_str())) {
+      job->Status = "failed"; job->Reason = std::string("failed to move output: ") + strerror(errno); save_job(*job, cfg.JobStateDir); remove(outputPath.c_str());
+      return job->Reason;
+    }
+    job->OutputPath = kept;
+    job->Status = "success"; job->Reason = "source kept: video-only output, replace step disabled";
     save_job(*job, cfg.JobStateDir);
     return "";
   }

@@ -19,6 +19,11 @@ struct Job {                       // jobs.Job, the fields ProcessJob reads or w
 };
 struct TranscodeConfig {           // daemon.go:185-188; Device is this backend's addition (which GPU runs the job)
   std::string JobStateDir; double MaxSizeRatio = 0.90; int StableWaitSeconds = 10; int Device = 0;
+  // The reference renames its output over the source (daemon.go:154): there the output carries the copied audio and
+  // subtitle streams.  This backend's output is a VIDEO-ONLY AV1 file (no demuxer, no stream copy), so replacing the source
+  // would destroy its other streams: the step is off unless explicitly asked for, and the coded file is then kept beside
+  // the source as "<base>.av1mi.mkv".
+  bool ReplaceSource = false;
 };
 
 // daemon.go:57-182.  Returns "" where the reference returns nil, else the error text; job.Status / job.Reason are

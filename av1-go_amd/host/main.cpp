@@ -1,6 +1,7 @@
 // av1mi_transcode — CLI with the reference's process contract (exit code, stderr text, output file last):
 //   av1mi_transcode [ffmpeg-style args] -i in.y4m [-global_quality:v:0 Q] [-g GOP] out.av1-tmp.mkv
-//   av1mi_transcode --job in.y4m [--ratio 0.9] [--state DIR] [--wait S]     (the ProcessJob lifecycle)
+//   av1mi_transcode --job in.y4m [--ratio 0.9] [--state DIR] [--wait S] [--replace-source 1]   (the ProcessJob lifecycle;
+//                   the source is only replaced on request: the output is video-only)
 #include <cstdio>
 #include <cstring>
 #include <sys/stat.h>
@@ -16,6 +17,7 @@ int main(int argc, char **argv) {
       if (!strcmp(argv[i], "--ratio")) cfg.MaxSizeRatio = atof(argv[i + 1]);
       else if (!strcmp(argv[i], "--state")) cfg.JobStateDir = argv[i + 1];
       else if (!strcmp(argv[i], "--wait")) cfg.StableWaitSeconds = atoi(argv[i + 1]);
+      else if (!strcmp(argv[i], "--replace-source")) { cfg.ReplaceSource = atoi(argv[i + 1]) != 0; }
     }
     struct stat st;
     if (!stat(job.SourcePath.c_str(), &st)) job.OriginalSize = st.st_size;

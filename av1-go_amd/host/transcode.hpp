@@ -45,6 +45,8 @@ struct BackendJob {
   int quality = 25;        // FFmpeg global_quality; av1_vaapi uses it directly as the AV1 base_q_idx [ext]
   int gop = 30;            // closed-GOP segment length
   int device = 0;
+  int segments = 4;        // closed GOPs coded in lockstep (the GOP session's batch)
+  int threads = 0;         // host threads for entropy coding; 0 = all cores
 };
 bool ParseBackendJob(const std::vector<std::string> &args, BackendJob *job, std::string *err);
 

@@ -12,28 +12,31 @@ import av1mi
 import synth
 
 
-def lf_level_from_q(ac_q, bd, key_frame=True):
-    """encoder policy, not normative: libaom's LPF_PICK_FROM_Q guess of the deblocking level from the AC step."""
-    if bd == 8:
-        g = (ac_q * 17563 - 421574 + (1 << 17)) >> 18 if key_frame else (ac_q * 6017 + 650707 + (1 << 17)) >> 18
-    else:
-        g = (ac_q * 20723 + 4060632 + (1 << 19)) >> 20
-    return int(min(max(g, 0), 63))
-
-
 def lf_mi_word(tx_w_log2, tx_h_log2, lvl_v, lvl_h, skip_inter=0, blk_left=1, blk_top=1):
+    """one deblocking mode-info unit of av1mi_deblock_plane (include/av1mi.h): layout plumbing, not policy"""
     return (tx_w_log2 | (tx_h_log2 << 4) | (lvl_v << 8) | (lvl_h << 16) | (skip_inter << 24) | (blk_left << 25) | (blk_top << 26))
 
 
-def cdef_strength_from_q(ac_q, bd):
-    """encoder policy, not normative: one CDEF strength set per frame from the AC step (libaom's CDEF_PICK_FROM_Q idea)."""
-    q = ac_q >> (bd - 8)
-    y_pri = int(min(max((q * q * 3 + 32768) >> 16, 0), 15)) if q < 700 else 15
-    return np.array([min(15, max(1, y_pri + 2)), 1, min(15, max(1, y_pri)), 1], np.uint8)
+def frame_policy(qindex, bd, frame_type):
+    """The encoder's filter-parameter policy for one frame.  It lives in libav1mi.so ONLY (csrc/gop_session.hip,
+    av1mi_policy_frame_params): this module, host/backend.cpp and the tests all ask the library."""
+    return av1mi.policy_frame_params(qindex, bd, frame_type)
 
 
-WIENER_DEFAULT_LUMA = (1, 3, -7, 15, 3, -7, 15, 0)     # type, v0 v1 v2, h0 h1 h2: libaom's mid-range default taps
-WIENER_DEFAULT_CHROMA = (1, 0, -7, 15, 0, -7, 15, 0)   # chroma: 5 taps (outer tap 0)
+def policy_arrays(qindex, bd, frame_type, width, height, block_size=8):
+    """host-side arrays of a frame's filter parameters in the layouts the stage entry points take"""
+    p = frame_policy(qindex, bd, frame_type)
+    l2y, l2c = int(np.log2(block_size)), int(np.log2(block_size // 2))
+    nsb = ((height + 63) // 64) * ((width + 63) // 64)
+    ur = lambda n: max(1, (n + p.lr_unit_size // 2) // p.lr_unit_size)
+    return dict(params=p,
+                mi_y=np.full((height // 4, width // 4), lf_mi_word(l2y, l2y, p.lf_level[0], p.lf_level[1]), np.uint32),
+                mi_c=np.full((height // 8, width // 8), lf_mi_word(l2c, l2c, p.lf_level[2], p.lf_level[2]), np.uint32),
+                cdef_damping=p.cdef_damping,
+                cdef_sb=np.tile(np.array([p.cdef_y >> 2, p.cdef_y & 3, p.cdef_uv >> 2, p.cdef_uv & 3], np.uint8), (nsb, 1)),
+                lr_unit=p.lr_unit_size,
+                lr_units_y=np.tile(np.array(list(p.lr_unit_y), np.int8), (ur(height), ur(width), 1)),
+                lr_units_c=np.tile(np.array(list(p.lr_unit_uv), np.int8), (ur(height // 2), ur(width // 2), 1)))
 
 
 class IntraPipeline:
@@ -87,23 +90,20 @@ class IntraPipeline:
         self.job, self.ent_job = self.jobs[0], (self.ent_jobs[0] if self.ent_jobs else None)
         lib = ctx.lib
         self.dc_q, self.ac_q = lib.av1mi_dc_q(qindex, bd), lib.av1mi_ac_q(qindex, bd)
-        self.lf_level = lf_level_from_q(self.ac_q, bd)
-        l2y, l2c = int(np.log2(block_size)), int(np.log2(block_size // 2))
-        self.mi_y = np.full((height // 4, width // 4), lf_mi_word(l2y, l2y, self.lf_level, self.lf_level), np.uint32)
-        self.mi_c = np.full((height // 8, width // 8), lf_mi_word(l2c, l2c, self.lf_level, self.lf_level), np.uint32)
+        # filter parameters: the library's policy (key-frame and inter-frame sets: the deblocking level differs for 8-bit)
+        self.pol = [policy_arrays(qindex, bd, ft, width, height, block_size) for ft in (0, 1)]
+        k = self.pol[0]
+        self.lf_level = int(k["params"].lf_level[0])
+        self.mi_y, self.mi_c = k["mi_y"], k["mi_c"]
         self.d["mi_y"], self.d["mi_c"] = ctx.to_device(self.mi_y), ctx.to_device(self.mi_c)
+        self.d["mi_y_p"], self.d["mi_c_p"] = ctx.to_device(self.pol[1]["mi_y"]), ctx.to_device(self.pol[1]["mi_c"])
         self.samples = Y.size + U.size + V.size            # per step
-        # CDEF: one strength set for every superblock, nothing skipped; LR: every unit Wiener with the default taps
-        nsb = ((height + 63) // 64) * ((width + 63) // 64)
-        self.cdef_damping = 3 + (self.ac_q >> (bd - 8) > 100) + (self.ac_q >> (bd - 8) > 300)
-        self.cdef_sb = np.tile(cdef_strength_from_q(self.ac_q, bd), (nsb, 1))
+        # CDEF: one strength set for every superblock, nothing skipped on key frames; LR: every unit Wiener with the default taps
+        self.cdef_damping, self.cdef_sb = k["cdef_damping"], k["cdef_sb"]
         self.cdef_skip = np.zeros((height // 8, width // 8), np.uint8)
-        self.lr_unit = 64
-        ur = lambda n: max(1, (n + 32) // 64)
-        self.lr_units_y = np.tile(np.array(WIENER_DEFAULT_LUMA, np.int8), (ur(height), ur(width), 1))
-        self.lr_units_c = np.tile(np.array(WIENER_DEFAULT_CHROMA, np.int8), (ur(height // 2), ur(width // 2), 1))
-        for k, a in (("cdef_sb", self.cdef_sb), ("cdef_skip", self.cdef_skip), ("lr_y", self.lr_units_y), ("lr_c", self.lr_units_c)):
-            self.d[k] = ctx.to_device(a)
+        self.lr_unit, self.lr_units_y, self.lr_units_c = k["lr_unit"], k["lr_units_y"], k["lr_units_c"]
+        for name, a in (("cdef_sb", self.cdef_sb), ("cdef_skip", self.cdef_skip), ("lr_y", self.lr_units_y), ("lr_c", self.lr_units_c)):
+            self.d[name] = ctx.to_device(a)
         d = self.d
         self.cdef_job = av1mi.CdefJob(width, height, bd, frames, self.cdef_damping, width, width // 2,
                                       d["dbl_y"].ptr, d["dbl_u"].ptr, d["dbl_v"].ptr, d["cdef_y"].ptr, d["cdef_u"].ptr,
@@ -217,12 +217,13 @@ class GopPipeline:
                     % (self.entropy_tile, self.entropy_tile, "; side stream" if self.entropy_async else ""))
                    if self.entropy_tile else "symbols stay uncoded in HBM"))
 
-    def _filters(self, skip_buf, skip_stride):
+    def _filters(self, skip_buf, skip_stride, key):
         c, k, d = self.ctx, self.key, self.key.d
         w, h, f = self.width, self.height, self.segments
-        c.deblock_frames(d["rec_y"], w, d["dbl_y"], w, w, h, self.bd, 0, d["mi_y"], w // 4, 0, 0, f)
-        c.deblock_frames(d["rec_u"], w // 2, d["dbl_u"], w // 2, w // 2, h // 2, self.bd, 1, d["mi_c"], w // 8, 0, 0, f)
-        c.deblock_frames(d["rec_v"], w // 2, d["dbl_v"], w // 2, w // 2, h // 2, self.bd, 1, d["mi_c"], w // 8, 0, 0, f)
+        mi_y, mi_c = (d["mi_y"], d["mi_c"]) if key else (d["mi_y_p"], d["mi_c_p"])     # the policy's level depends on the frame type
+        c.deblock_frames(d["rec_y"], w, d["dbl_y"], w, w, h, self.bd, 0, mi_y, w // 4, 0, 0, f)
+        c.deblock_frames(d["rec_u"], w // 2, d["dbl_u"], w // 2, w // 2, h // 2, self.bd, 1, mi_c, w // 8, 0, 0, f)
+        c.deblock_frames(d["rec_v"], w // 2, d["dbl_v"], w // 2, w // 2, h // 2, self.bd, 1, mi_c, w // 8, 0, 0, f)
         job = av1mi.CdefJob(w, h, self.bd, f, k.cdef_damping, w, w // 2, d["dbl_y"].ptr, d["dbl_u"].ptr, d["dbl_v"].ptr,
                             d["cdef_y"].ptr, d["cdef_u"].ptr, d["cdef_v"].ptr, d["cdef_sb"].ptr, 0, skip_buf.ptr, skip_stride)
         c.cdef_frames(job)
@@ -258,9 +259,14 @@ class GopPipeline:
                     c.entropy_encode_async(ej, slot)
                 else:
                     c.entropy_encode(ej)
-            self._filters(self.zero_skip if t == 0 else y["skip"], 0 if t == 0 else nb)
+            self._filters(self.zero_skip if t == 0 else y["skip"], 0 if t == 0 else nb, t == 0)
             if on_frame:
                 on_frame(t)
+
+    def oracle_filter_args(self, t):
+        """(mi_y, mi_c, cdef_damping, cdef_sb, lr_unit, lr_units_y, lr_units_c) of the t-th frame of a GOP, for oracle chains"""
+        p = self.key.pol[0 if t == 0 else 1]
+        return p["mi_y"], p["mi_c"], p["cdef_damping"], p["cdef_sb"], p["lr_unit"], p["lr_units_y"], p["lr_units_c"]
 
     def coded_records(self, t):
         """records of the t-th frames of all segments written by the last step (entropy_tile > 0)"""

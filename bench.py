@@ -42,6 +42,9 @@ def parse():
                          "reported under \"entropy\"; gpu-async = the coder on the context's side stream, overlapping the next step")
     ap.add_argument("--entropy-tile", type=int, default=64, choices=[32, 64, 128])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end leg (upload + pipeline + download + host AV1 entropy coding)")
+    ap.add_argument("--e2e-segments", type=int, default=4)
+    ap.add_argument("--e2e-steps", type=int, default=2)
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="no GPU: exercise the rank/sharding/timing/aggregation plumbing with a stand-in step (gloo tests)")
     return ap.parse_args()
@@ -90,23 +93,23 @@ def cpu_baseline_gop(pipe, p_frames=2):
     k, gop = pipe.key, pipe.gop
     h, w = pipe.height, pipe.width
 
-    def filters(r, skip8):
-        dbl = [O.deblock_plane(r["rec_y"], pipe.bd, 0, k.mi_y), O.deblock_plane(r["rec_u"], pipe.bd, 1, k.mi_c),
-               O.deblock_plane(r["rec_v"], pipe.bd, 1, k.mi_c)]
-        cdef = O.cdef_frame(dbl[0], dbl[1], dbl[2], pipe.bd, k.cdef_damping, k.cdef_sb, skip8)
-        return [O.lr_plane(cdef[0], dbl[0], pipe.bd, 0, k.lr_unit, k.lr_units_y), O.lr_plane(cdef[1], dbl[1], pipe.bd, 1, k.lr_unit, k.lr_units_c),
-                O.lr_plane(cdef[2], dbl[2], pipe.bd, 1, k.lr_unit, k.lr_units_c)]
+    def filters(r, skip8, t):
+        mi_y, mi_c, damping, cdef_sb, lr_unit, lr_y, lr_c = pipe.oracle_filter_args(t)
+        dbl = [O.deblock_plane(r["rec_y"], pipe.bd, 0, mi_y), O.deblock_plane(r["rec_u"], pipe.bd, 1, mi_c), O.deblock_plane(r["rec_v"], pipe.bd, 1, mi_c)]
+        cdef = O.cdef_frame(dbl[0], dbl[1], dbl[2], pipe.bd, damping, cdef_sb, skip8)
+        return [O.lr_plane(cdef[0], dbl[0], pipe.bd, 0, lr_unit, lr_y), O.lr_plane(cdef[1], dbl[1], pipe.bd, 1, lr_unit, lr_c),
+                O.lr_plane(cdef[2], dbl[2], pipe.bd, 1, lr_unit, lr_c)]
 
     def one(worker):
         s = worker % pipe.segments
         t0 = time.perf_counter()
         src = [pipe.src[0][i][s] for i in range(3)]
-        ref = filters(O.intra_encode_frame(src[0], src[1], src[2], pipe.bd, 8, pipe.qindex), np.zeros((h // 8, w // 8), np.uint8))
+        ref = filters(O.intra_encode_frame(src[0], src[1], src[2], pipe.bd, 8, pipe.qindex), np.zeros((h // 8, w // 8), np.uint8), 0)
         t1 = time.perf_counter()
         for t in range(1, 1 + p_frames):
             src = [pipe.src[t][i][s] for i in range(3)]
             r = O.inter_encode_frame(src, ref, pipe.bd, pipe.qindex, pipe.range)
-            ref = filters(r, r["skip"].reshape(h // 8, w // 8))
+            ref = filters(r, r["skip"].reshape(h // 8, w // 8), t)
         return t1 - t0, (time.perf_counter() - t1) / p_frames
 
     t0 = time.perf_counter()
@@ -197,6 +200,122 @@ def entropy_leg(ctx, pipe, args, launches=5, host_seconds=6.0):
     return out
 
 
+def probe_baseline_tools():
+    """the preferred CPU baseline is FFmpeg + libsvtav1 on the same frames; record what this box actually has."""
+    import shutil
+    import subprocess
+    tools = {n: shutil.which(n) is not None for n in ("ffmpeg", "ffprobe", "SvtAv1EncApp", "aomenc", "aomdec", "dav1d", "go")}
+    tools["ffmpeg_has_libsvtav1"] = False
+    if tools["ffmpeg"]:
+        try:
+            enc = subprocess.run(["ffmpeg", "-hide_banner", "-encoders"], capture_output=True, text=True, timeout=20).stdout
+            tools["ffmpeg_has_libsvtav1"] = "libsvtav1" in enc
+        except Exception:
+            pass
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import dav1d_ref
+        tools["bundled_libavif"] = dav1d_ref.find_library() is not None
+        tools["bundled_dav1d"] = dav1d_ref.version() if dav1d_ref.available() else None
+    except Exception:
+        tools["bundled_libavif"], tools["bundled_dav1d"] = False, None
+    return tools
+
+
+def e2e_leg(ctx, W, H, bd, qindex, first_frame, segs=4, gop=30, steps=2, warmup_frames=2):
+    """END TO END: what the transcode job does per frame (reference: file in -> file out, internal/ffmpeg/transcode.go:194-203):
+    source planes from host memory into the session's pinned buffers, H2D upload, block pipeline + in-loop filters on the GPU,
+    D2H of the symbols, AV1 entropy coding + OBU packing on all host cores (north_star keeps that stage on the host).  Two
+    batches in flight: the host codes frame t while the GPU works on frame t + 1.  Timed with the wall clock; the product is
+    a decodable AV1 stream (its first frames are decoded with dav1d, when present, and compared with the GPU's reference)."""
+    from concurrent.futures import ThreadPoolExecutor
+    import av1mi
+    import av1stream
+    import synth
+    threads = os.cpu_count() or 1
+    t_gen = time.perf_counter()
+    Y, U, V = synth.frames(W, H, segs * gop, bd, first_frame)
+    src = [a.reshape(segs, gop, *a.shape[1:]) for a in (Y, U, V)]
+    t_gen = time.perf_counter() - t_gen
+    sess = av1mi.GopSession(ctx, W, H, bd, qindex, gop, segs)
+    pool = ThreadPoolExecutor(min(threads, 3 * segs))
+    coded = {"bytes": 0, "frames": 0, "t_fill": 0.0, "t_code": 0.0, "t_wait": 0.0}
+
+    def fill(t):
+        t0 = time.perf_counter()
+        planes = sess.input_planes()
+        jobs = []
+        for p in range(3):
+            hh = H if p == 0 else H // 2
+            for sg in range(segs):
+                jobs.append(pool.submit(np.copyto, planes[p][sg * hh:(sg + 1) * hh], src[p][sg, t]))
+        for j in jobs:
+            j.result()
+        coded["t_fill"] += time.perf_counter() - t0
+
+    def code(keep=None):
+        t0 = time.perf_counter()
+        fr = sess.collect()
+        t1 = time.perf_counter()
+        for sg in range(segs):
+            tu = av1stream.session_frame_unit(W, H, bd, fr, sg, threads=threads)
+            coded["bytes"] += len(tu)
+            coded["frames"] += 1
+            if keep is not None and sg == 0:
+                keep.append(tu)
+        coded["t_wait"] += t1 - t0
+        coded["t_code"] += time.perf_counter() - t1
+
+    def run_gop(nframes, keep=None):
+        for t in range(nframes):
+            fill(t)
+            sess.submit(0 if t == 0 else 1)
+            if t >= 1:
+                code(keep)
+        code(keep)
+
+    run_gop(warmup_frames)
+    for k in coded:
+        coded[k] = 0
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run_gop(gop)
+    ctx.sync()
+    dt = time.perf_counter() - t0
+    frames = coded["frames"]
+    out = {"frames_per_s": frames / dt, "frames": frames, "seconds": dt, "segments_in_lockstep": segs, "gop": gop, "host_threads": threads,
+           "bytes_per_frame": coded["bytes"] / frames, "mbit_per_s_at_30fps": coded["bytes"] / frames * 8 * 30 / 1e6,
+           "host_seconds": {"fill_pinned_input": coded["t_fill"], "wait_for_gpu": coded["t_wait"], "entropy_code": coded["t_code"]},
+           "pcie_bytes_per_frame": {"up": W * H * 3 // 2 * (1 if bd == 8 else 2), "down": W * H * 3 + (W // 8) * (H // 8) * 5},
+           "what": "pinned host source -> H2D -> block pipeline + deblock + CDEF + LR (GPU) -> D2H symbols -> AV1 entropy coding + OBU "
+                   "packing on %d host threads; synthetic source generated beforehand (%.1f s, not timed)" % (threads, t_gen)}
+    # the stream is real: decode the first frames of segment 0 and compare with the reference frames the GPU keeps
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import dav1d_ref as D
+        if D.available():
+            check = av1mi.GopSession(ctx, W, H, bd, qindex, gop, 1)
+            units, refs = [], []
+            for t in range(2):
+                planes = check.input_planes()
+                for p in range(3):
+                    np.copyto(planes[p], src[p][0, t])
+                check.submit(0 if t == 0 else 1)
+                fr = check.collect()
+                units.append(av1stream.session_frame_unit(W, H, bd, fr, 0, threads=threads))
+                refs.append(check.download_reference())
+            check.close()
+            dec = D.decode(b"".join(units))
+            ok = len(dec) == 2 and all((dec[t][p] == refs[t][p]).all() for t in range(2) for p in range(3))
+            out["decoder_check"] = {"decoder": "dav1d " + D.version(), "frames": 2, "bit_exact_vs_gpu_reference": bool(ok)}
+    except Exception as e:       # the check is a courtesy of the bench, the tests are the gate
+        out["decoder_check"] = {"error": repr(e)[:200]}
+    pool.shutdown()
+    sess.close()
+    return out
+
+
 PMC_KERNEL = {"intra_pipeline": "k_intra_pipe", "deblock": "k_deblock", "cdef": "k_cdef", "loop_restoration": "k_lr",
               "inter_pipeline": "k_inter_pipe", "me_integer": "k_me_int"}
 
@@ -257,11 +376,38 @@ def dry_run(args, rank, world, dist):
         dist.destroy_process_group()
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script (one per GPU) as CHILD processes — before
+    this process has imported torch or made any HIP call — with the environment torch.distributed.run would give them, relay
+    rank 0's JSON line and exit with the first non-zero status."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out = procs[0].communicate()[0]
+    codes = [p.wait() for p in procs]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    bad = [c for c in codes if c]
+    if bad:
+        sys.exit("bench.py: rank(s) failed with exit codes %s" % codes)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return spawn_ranks(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        sys.exit("bench.py: --gpus %d does not match WORLD_SIZE %d of the launcher" % (args.gpus, world))
     dist = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -329,7 +475,9 @@ def main():
         "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u8" if bd == 8 else "u16", "data": "synthetic",
-        "config": {"workload": pipe.describe(), "frames_per_step": frames, "qindex": args.qindex,
+        "config": {"workload": pipe.describe(), "value_is": "DEVICE-RESIDENT block pipeline + in-loop filters (source frames already in HBM, symbols left "
+                   "in HBM: the bench contract's definition of `value`); the end-to-end encode rate (PCIe both ways + AV1 entropy coding on "
+                   "the host cores, a decodable stream) is `e2e_frames_per_s`", "frames_per_step": frames, "qindex": args.qindex,
                    "sharding": "closed-GOP segment per GPU, no collective", "device": ctx.device_name},
     }
     if rank == 0:
@@ -353,14 +501,20 @@ def main():
         out["kernels"] = {k: {"launches": v[0], "avg_ms": v[1] / v[0],
                               "algorithmic_GBps": alg[k] / (v[1] / v[0] * 1e-3) / 1e9 if k in alg else None} for k, v in prof.items()}
         out["quality"] = quality(pipe, bd)
+        out["baseline_tools"] = probe_baseline_tools()
         if world == 1 and not args.workload.endswith("-gop"):
             out["entropy"] = entropy_leg(ctx, pipe, args)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_gop(pipe) if args.workload.endswith("-gop") else cpu_baseline(pipe)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
     pipe.close()
+    if rank == 0:
+        if world == 1 and not args.no_e2e and args.workload.endswith("-gop"):
+            e2e = e2e_leg(ctx, W, H, bd, args.qindex, segment_of_rank(rank, frames), segs=args.e2e_segments, steps=args.e2e_steps)
+            out["e2e"] = e2e
+            out["e2e_frames_per_s"] = e2e["frames_per_s"]
+        print(json.dumps(out))
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()

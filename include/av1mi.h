@@ -273,6 +273,75 @@ int av1mi_entropy_encode(av1mi_ctx *ctx, const av1mi_entropy_job *job);
 int av1mi_entropy_encode_async(av1mi_ctx *ctx, const av1mi_entropy_job *job, int slot);
 int av1mi_entropy_wait(av1mi_ctx *ctx, int slot);
 
+
+/* ---- GOP session: the encoder object a cgo replacement of RunTranscode drives (reference call site
+ * internal/daemon/daemon.go:101 -> internal/ffmpeg/transcode.go:194; SURVEY.md §8b "av1mi_open(config) / av1mi_encode /
+ * av1mi_flush").  It owns the closed-GOP orchestration and the encoder's filter-parameter POLICY, so that no caller
+ * re-implements them: `segments` independent closed GOPs are coded in lockstep (the t-th frames of all of them share every
+ * launch: SURVEY.md §8e shards by closed-GOP segment), frame t = 0 of a GOP is a key frame, the others are P frames
+ * predicted from the previous frame after deblocking + CDEF + loop restoration.
+ *
+ * Data path per frame batch: the caller fills the session's pinned host buffers with the source planes
+ * (av1mi_gop_acquire_input), av1mi_gop_submit() queues the upload (own copy stream), the block pipeline + in-loop filters
+ * (the context's stream) and the download of the frame's SYMBOLS (modes or vectors + skip flags + int16 levels; own copy
+ * stream) into pinned host memory; av1mi_gop_collect() waits for the oldest submitted batch and hands those symbols out
+ * together with the frame-header parameters the policy chose — exactly what the host bitstream writer
+ * (av1-go_amd/host/av1_bitstream.hpp, entropy coding stays on the host cores) needs.  Two batches can be in flight:
+ * submit(t + 1) before collect(t) overlaps PCIe traffic, kernels and the host's entropy coding. */
+typedef struct av1mi_gop_config {
+  int width, height;     /* luma samples, multiples of 8 */
+  int bit_depth;         /* 8 or 10 */
+  int base_q_idx;        /* 1..255 (the reference's only quality knob is DetermineQuality, transcode.go:157-165) */
+  int gop_length;        /* frames per closed GOP, >= 1 */
+  int segments;          /* closed GOPs coded in lockstep, >= 1 */
+  int search_range;      /* integer motion search range in samples, 0..15 */
+} av1mi_gop_config;
+
+/* Frame-header parameters chosen by the session's policy for one frame (non-normative encoder choices; the bitstream carries
+ * them): deblocking level from the quantiser step (libaom's LPF_PICK_FROM_Q fit, key / inter frames differ for 8-bit), one
+ * CDEF strength set and damping from the step, Wiener restoration with fixed taps on 64x64 units. */
+typedef struct av1mi_frame_params {
+  int frame_type;        /* 0 key frame, 1 inter frame */
+  int base_q_idx;
+  int lf_level[4];       /* luma vertical, luma horizontal, U, V */
+  int lf_sharpness;
+  int cdef_damping;
+  uint8_t cdef_y, cdef_uv;      /* (primary strength << 2) | secondary code */
+  int lr_unit_size;             /* luma and chroma restoration unit size in samples of the plane */
+  int8_t lr_unit_y[8], lr_unit_uv[8];   /* the unit record every unit of the plane uses (layout of av1mi_lr_frames) */
+} av1mi_frame_params;
+/* the policy alone (tests build the oracle's chain from it) */
+int av1mi_policy_frame_params(int base_q_idx, int bit_depth, int frame_type, av1mi_frame_params *out);
+
+typedef struct av1mi_gop_frame {    /* one collected frame batch; host pointers into the session's pinned buffers, valid until
+                                       the next av1mi_gop_submit that reuses the slot (i.e. for one more submit) */
+  av1mi_frame_params params;
+  int segments;                     /* batch size */
+  size_t blocks_per_frame;          /* (width / 8) * (height / 8); per-block arrays hold segments * blocks_per_frame entries */
+  const uint8_t *y_mode, *uv_mode;  /* key frames: intra modes per 8x8 block (0 DC .. 12 PAETH) */
+  const int16_t *mv;                /* inter frames: (x, y) per block in 1/8 luma samples */
+  const uint8_t *skip;              /* inter frames: 1 = no non-zero level in the block */
+  const int16_t *lev_y, *lev_u, *lev_v;   /* 64 / 16 / 16 levels per block, row-major inside a block */
+} av1mi_gop_frame;
+
+typedef struct av1mi_gop av1mi_gop;
+int av1mi_gop_open(av1mi_ctx *ctx, const av1mi_gop_config *cfg, av1mi_gop **out);
+void av1mi_gop_close(av1mi_gop *g);
+/* pinned host planes for the NEXT batch: segment s occupies rows [s * height, (s + 1) * height) of the luma plane
+ * (stride = width samples, uint8 for 8-bit, uint16 otherwise) and the matching rows of the half-size chroma planes.
+ * Blocks until the upload that last used these buffers has finished. */
+int av1mi_gop_acquire_input(av1mi_gop *g, void **y, void **u, void **v);
+/* queue the batch in the acquired buffers.  frame_type: 0 key, 1 inter, -1 = by position in the GOP (gop_length).
+ * AV1MI_E_INVAL when two batches are already in flight (collect first). */
+int av1mi_gop_submit(av1mi_gop *g, int frame_type);
+/* wait for the oldest batch in flight and describe its symbols; AV1MI_E_INVAL when nothing is in flight */
+int av1mi_gop_collect(av1mi_gop *g, av1mi_gop_frame *out);
+/* number of batches in flight (0..2) */
+int av1mi_gop_pending(av1mi_gop *g);
+/* the reference frame(s) produced by the LAST submitted batch (after all in-loop filters): host buffers of the stacked-plane
+ * sizes; synchronises the session.  For tests and PSNR. */
+int av1mi_gop_download_reference(av1mi_gop *g, void *y, void *u, void *v);
+
 /* ---- host-pointer single-block forms (SURVEY.md §8b "per-stage test entry points"): copy in, run the
  * same kernels, copy out, synchronous. */
 int av1mi_inv_txfm2d_add(av1mi_ctx *ctx, const int32_t *coef, void *dst, int stride, int tx_size, int tx_type, int bd);

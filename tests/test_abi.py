@@ -15,6 +15,36 @@ def test_library_exports_every_declared_symbol(av1mi):
         assert hasattr(lib, n), "libav1mi.so does not export %s" % n
 
 
+def test_host_library_exports_every_declared_symbol():
+    """include/av1mi_host.h: the RunTranscode drop-in and the bitstream writer, exported by libav1mi_host.so"""
+    import re
+    import av1stream
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(root, "include", "av1mi_host.h")).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(av1mi_[a-z0-9_]+)\s*\(", hdr)))
+    assert names == ["av1mi_obu_write_temporal_unit", "av1mi_run_transcode"]
+    lib = av1stream.lib()
+    for n in names:
+        assert hasattr(lib, n), "libav1mi_host.so does not export %s" % n
+    # the ctypes mirror of av1mi_obu_frame has the size the C compiler gives the header's struct
+    import subprocess
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "sz.c")
+        open(src, "w").write('#include "av1mi_host.h"\n#include <stdio.h>\nint main(void){printf("%zu", sizeof(av1mi_obu_frame));return 0;}\n')
+        subprocess.check_call(["gcc", "-I", os.path.join(root, "include"), src, "-o", os.path.join(d, "sz")])
+        assert int(subprocess.check_output([os.path.join(d, "sz")])) == C.sizeof(av1stream.ObuFrame)
+
+
+def test_policy_is_exported_and_frame_type_dependent(av1mi):
+    """the filter-parameter policy lives in libav1mi.so only (round 1 kept two copies that disagreed on the P-frame level)"""
+    k, p = av1mi.policy_frame_params(128, 8, 0), av1mi.policy_frame_params(128, 8, 1)
+    assert list(k.lf_level) == [10] * 4 and list(p.lf_level) == [7] * 4      # libaom's key / inter fits for 8-bit
+    assert k.cdef_y == p.cdef_y and k.cdef_damping == p.cdef_damping and list(k.lr_unit_y) == [1, 3, -7, 15, 3, -7, 15, 0]
+    k10, p10 = av1mi.policy_frame_params(128, 10, 0), av1mi.policy_frame_params(128, 10, 1)
+    assert list(k10.lf_level) == list(p10.lf_level)
+
+
 def test_version_and_geometry(av1mi, O):
     lib = av1mi.load()
     assert lib.av1mi_version().decode().startswith("av1mi ")

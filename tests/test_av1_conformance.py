@@ -15,26 +15,25 @@ import dav1d_ref as D
 pytestmark = pytest.mark.skipif(not D.available(), reason="no dav1d in this image (pillow.libs/libavif)")
 
 
+def _filters(O, P, r, bd, q, frame_type, w, h, skip8):
+    """deblock -> CDEF -> loop restoration of the oracle with the library's policy numbers; returns (header kwargs, stages)"""
+    import av1stream
+    a = P.policy_arrays(q, bd, frame_type, w, h)
+    dbl = [O.deblock_plane(r["rec_y"], bd, 0, a["mi_y"]), O.deblock_plane(r["rec_u"], bd, 1, a["mi_c"]), O.deblock_plane(r["rec_v"], bd, 1, a["mi_c"])]
+    cdef = O.cdef_frame(dbl[0], dbl[1], dbl[2], bd, a["cdef_damping"], a["cdef_sb"], skip8)
+    out = [O.lr_plane(cdef[0], dbl[0], bd, 0, a["lr_unit"], a["lr_units_y"]), O.lr_plane(cdef[1], dbl[1], bd, 1, a["lr_unit"], a["lr_units_c"]),
+           O.lr_plane(cdef[2], dbl[2], bd, 1, a["lr_unit"], a["lr_units_c"])]
+    hdr = av1stream.header_from_params(a["params"], w, h)
+    hdr.pop("frame_type")
+    return hdr, [dbl, list(cdef), out]
+
+
 def _chain(O, P, Y, U, V, bd, q):
-    """the oracle's key-frame chain with the pipeline's parameter policy; returns symbols + the four stages"""
+    """the oracle's key-frame chain with the library's parameter policy; returns symbols + header kwargs + the four stages"""
     h, w = Y.shape
     r = O.intra_encode_frame(Y, U, V, bd, 8, q)
-    acq = O.ac_q(q, bd)
-    lvl = P.lf_level_from_q(acq, bd)
-    mi_y = np.full((h // 4, w // 4), P.lf_mi_word(3, 3, lvl, lvl), np.uint32)
-    mi_c = np.full((h // 8, w // 8), P.lf_mi_word(2, 2, lvl, lvl), np.uint32)
-    dbl = [O.deblock_plane(r["rec_y"], bd, 0, mi_y), O.deblock_plane(r["rec_u"], bd, 1, mi_c), O.deblock_plane(r["rec_v"], bd, 1, mi_c)]
-    nsb = ((h + 63) // 64) * ((w + 63) // 64)
-    st = P.cdef_strength_from_q(acq, bd)
-    damping = 3 + (acq >> (bd - 8) > 100) + (acq >> (bd - 8) > 300)
-    cdef = O.cdef_frame(dbl[0], dbl[1], dbl[2], bd, damping, np.tile(st, (nsb, 1)), np.zeros((h // 8, w // 8), np.uint8))
-    ur = lambda n: max(1, (n + 32) // 64)
-    uy = np.tile(np.array(P.WIENER_DEFAULT_LUMA, np.int8), (ur(h), ur(w), 1))
-    uc = np.tile(np.array(P.WIENER_DEFAULT_CHROMA, np.int8), (ur(h // 2), ur(w // 2), 1))
-    out = [O.lr_plane(cdef[0], dbl[0], bd, 0, 64, uy), O.lr_plane(cdef[1], dbl[1], bd, 1, 64, uc), O.lr_plane(cdef[2], dbl[2], bd, 1, 64, uc)]
-    hdr = dict(lf_level=(lvl,) * 4, cdef_damping=damping, cdef_y=(int(st[0]) << 2 | int(st[1]),), cdef_uv=(int(st[2]) << 2 | int(st[3]),),
-               lr_type=(1, 1, 1), lr_units=(uy, uc, uc))
-    return r, hdr, [[r["rec_y"], r["rec_u"], r["rec_v"]], dbl, list(cdef), out]
+    hdr, st = _filters(O, P, r, bd, q, 0, w, h, np.zeros((h // 8, w // 8), np.uint8))
+    return r, hdr, [[r["rec_y"], r["rec_u"], r["rec_v"]]] + st
 
 
 @pytest.mark.parametrize("w,h,bd,q", [(64, 64, 8, 128), (192, 128, 8, 128), (200, 136, 10, 60), (328, 184, 8, 200), (72, 72, 10, 230),
@@ -87,18 +86,10 @@ def _gop(O, P, w, h, bd, q, nframes, first=3):
             ref = stages[3]
         else:
             r = O.inter_encode_frame((Y[t], U[t], V[t]), ref, bd, q, 8)
+            hdr_p, st = _filters(O, P, r, bd, q, 1, w, h, r["skip"].reshape(h // 8, w // 8))     # inter frames: their own deblocking level
             stream += av1stream.temporal_unit(w, h, bd, q, frame_type=1, with_sequence_header=False, mv=r["mvs"], skip=r["skip"],
-                                              lev_y=r["lev_y"], lev_u=r["lev_u"], lev_v=r["lev_v"], **hdr)
-            acq = O.ac_q(q, bd)
-            lvl = hdr["lf_level"][0]
-            mi_y = np.full((h // 4, w // 4), P.lf_mi_word(3, 3, lvl, lvl), np.uint32)
-            mi_c = np.full((h // 8, w // 8), P.lf_mi_word(2, 2, lvl, lvl), np.uint32)
-            dbl = [O.deblock_plane(r["rec_y"], bd, 0, mi_y), O.deblock_plane(r["rec_u"], bd, 1, mi_c), O.deblock_plane(r["rec_v"], bd, 1, mi_c)]
-            nsb = ((h + 63) // 64) * ((w + 63) // 64)
-            cdef = O.cdef_frame(dbl[0], dbl[1], dbl[2], bd, hdr["cdef_damping"], np.tile(P.cdef_strength_from_q(acq, bd), (nsb, 1)),
-                                r["skip"].reshape(h // 8, w // 8))
-            uy, uc = hdr["lr_units"][0], hdr["lr_units"][1]
-            ref = [O.lr_plane(cdef[0], dbl[0], bd, 0, 64, uy), O.lr_plane(cdef[1], dbl[1], bd, 1, 64, uc), O.lr_plane(cdef[2], dbl[2], bd, 1, 64, uc)]
+                                              lev_y=r["lev_y"], lev_u=r["lev_u"], lev_v=r["lev_v"], **hdr_p)
+            ref = st[2]
         refs.append(ref)
     return stream, refs
 

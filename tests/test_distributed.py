@@ -36,3 +36,23 @@ def test_segment_sharding_is_disjoint():
     import bench
     starts = [bench.segment_of_rank(r, 32) for r in range(8)]
     assert starts == [0, 32, 64, 96, 128, 160, 192, 224]
+
+
+def test_gpus_flag_spawns_the_ranks_itself():
+    """`python bench.py --gpus 2` with NO external launcher: the script starts its two ranks (the flag was parsed and
+    ignored, a driver-run `--gpus 8` would have measured one GPU)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run-cpu"],
+                         env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["ms_per_step"] >= 19.0
+
+
+def test_gpus_flag_must_match_the_launcher():
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run-cpu"], env=env, capture_output=True,
+                         text=True, timeout=120, cwd=ROOT)
+    assert out.returncode != 0 and "does not match WORLD_SIZE" in out.stderr

@@ -77,10 +77,11 @@ def test_closed_gop_chain_matches_oracle(ctx, O, w, h, bd, q, segs, gop, rng_):
             else:
                 r = O.inter_encode_frame(src, ref, bd, q, rng_)
                 skip8 = r["skip"].reshape(h // 8, w // 8)
-            dbl = [O.deblock_plane(r["rec_y"], bd, 0, k.mi_y), O.deblock_plane(r["rec_u"], bd, 1, k.mi_c), O.deblock_plane(r["rec_v"], bd, 1, k.mi_c)]
-            cdef = O.cdef_frame(dbl[0], dbl[1], dbl[2], bd, k.cdef_damping, k.cdef_sb, skip8)
-            ref = [O.lr_plane(cdef[0], dbl[0], bd, 0, k.lr_unit, k.lr_units_y), O.lr_plane(cdef[1], dbl[1], bd, 1, k.lr_unit, k.lr_units_c),
-                   O.lr_plane(cdef[2], dbl[2], bd, 1, k.lr_unit, k.lr_units_c)]
+            mi_y, mi_c, damping, cdef_sb, lr_unit, lr_y, lr_c = gp.oracle_filter_args(t)
+            dbl = [O.deblock_plane(r["rec_y"], bd, 0, mi_y), O.deblock_plane(r["rec_u"], bd, 1, mi_c), O.deblock_plane(r["rec_v"], bd, 1, mi_c)]
+            cdef = O.cdef_frame(dbl[0], dbl[1], dbl[2], bd, damping, cdef_sb, skip8)
+            ref = [O.lr_plane(cdef[0], dbl[0], bd, 0, lr_unit, lr_y), O.lr_plane(cdef[1], dbl[1], bd, 1, lr_unit, lr_c),
+                   O.lr_plane(cdef[2], dbl[2], bd, 1, lr_unit, lr_c)]
             for i in range(3):
                 assert (got[t][i][s] == ref[i]).all(), (s, t, i)
     gp.close()
@@ -145,10 +146,11 @@ def test_closed_gop_chain_coded_records(ctx, O, use_async):
                 r = O.inter_encode_frame(src, ref, bd, q, 6)
                 skip8 = r["skip"].reshape(h // 8, w // 8)
                 want[t][s] = O.entropy_encode_frame(w, h, 0, 64, r["lev_y"], r["lev_u"], r["lev_v"], mvs=r["mvs"], skip=r["skip"])
-            dbl = [O.deblock_plane(r["rec_y"], bd, 0, k.mi_y), O.deblock_plane(r["rec_u"], bd, 1, k.mi_c), O.deblock_plane(r["rec_v"], bd, 1, k.mi_c)]
-            cdef = O.cdef_frame(dbl[0], dbl[1], dbl[2], bd, k.cdef_damping, k.cdef_sb, skip8)
-            ref = [O.lr_plane(cdef[0], dbl[0], bd, 0, k.lr_unit, k.lr_units_y), O.lr_plane(cdef[1], dbl[1], bd, 1, k.lr_unit, k.lr_units_c),
-                   O.lr_plane(cdef[2], dbl[2], bd, 1, k.lr_unit, k.lr_units_c)]
+            mi_y, mi_c, damping, cdef_sb, lr_unit, lr_y, lr_c = gp.oracle_filter_args(t)
+            dbl = [O.deblock_plane(r["rec_y"], bd, 0, mi_y), O.deblock_plane(r["rec_u"], bd, 1, mi_c), O.deblock_plane(r["rec_v"], bd, 1, mi_c)]
+            cdef = O.cdef_frame(dbl[0], dbl[1], dbl[2], bd, damping, cdef_sb, skip8)
+            ref = [O.lr_plane(cdef[0], dbl[0], bd, 0, lr_unit, lr_y), O.lr_plane(cdef[1], dbl[1], bd, 1, lr_unit, lr_c),
+                   O.lr_plane(cdef[2], dbl[2], bd, 1, lr_unit, lr_c)]
     for _ in range(2):
         gp.step()
         for t in range(gop):

@@ -1,0 +1,114 @@
+"""The GOP session (include/av1mi.h av1mi_gop_*): orchestration + policy + PCIe plumbing inside libav1mi.so.
+ * its symbols and reference frames equal the oracle's closed-GOP chain built from the same policy numbers;
+ * the AV1 stream the host writer makes of its symbols decodes in dav1d to exactly the session's own reference frames —
+   at full 1080p 8-bit and 4K 10-bit sizes too (2 segments x 3 frames: lockstep, a P frame that references a P frame)."""
+import numpy as np
+import pytest
+
+import dav1d_ref as D
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_filters(O, r, bd, p, w, h, skip8):
+    mi_y = np.full((h // 4, w // 4), int(O.lf_mi(3, 3, p.lf_level[0], p.lf_level[1])), np.uint32)
+    mi_c = np.full((h // 8, w // 8), int(O.lf_mi(2, 2, p.lf_level[2], p.lf_level[2])), np.uint32)
+    dbl = [O.deblock_plane(r["rec_y"], bd, 0, mi_y, p.lf_sharpness), O.deblock_plane(r["rec_u"], bd, 1, mi_c, p.lf_sharpness),
+           O.deblock_plane(r["rec_v"], bd, 1, mi_c, p.lf_sharpness)]
+    nsb = ((h + 63) // 64) * ((w + 63) // 64)
+    st = np.array([p.cdef_y >> 2, p.cdef_y & 3, p.cdef_uv >> 2, p.cdef_uv & 3], np.uint8)
+    cdef = O.cdef_frame(dbl[0], dbl[1], dbl[2], bd, p.cdef_damping, np.tile(st, (nsb, 1)), skip8)
+    ur = lambda n: max(1, (n + 32) // 64)
+    uy = np.tile(np.array(list(p.lr_unit_y), np.int8), (ur(h), ur(w), 1))
+    uc = np.tile(np.array(list(p.lr_unit_uv), np.int8), (ur(h // 2), ur(w // 2), 1))
+    return [O.lr_plane(cdef[0], dbl[0], bd, 0, 64, uy), O.lr_plane(cdef[1], dbl[1], bd, 1, 64, uc), O.lr_plane(cdef[2], dbl[2], bd, 1, 64, uc)]
+
+
+@pytest.mark.parametrize("w,h,bd,q", [(192, 128, 8, 110), (136, 72, 10, 150)])
+def test_session_symbols_and_references_match_the_oracle_chain(ctx, av1mi, O, w, h, bd, q):
+    gop, segs = 3, 2
+    import synth
+    Y, U, V = synth.frames(w, h, segs * gop, bd, 4)
+    s = av1mi.GopSession(ctx, w, h, bd, q, gop, segs)
+    try:
+        ref = [None] * segs
+        for t in range(gop):
+            planes = s.input_planes()
+            for sgi in range(segs):
+                f = sgi * gop + t
+                planes[0][sgi * h:(sgi + 1) * h] = Y[f]
+                planes[1][sgi * h // 2:(sgi + 1) * h // 2] = U[f]
+                planes[2][sgi * h // 2:(sgi + 1) * h // 2] = V[f]
+            s.submit()
+            fr = s.collect()
+            gy, gu, gv = s.download_reference()
+            p = fr["params"]
+            assert p.frame_type == (0 if t == 0 else 1)
+            pol = av1mi.policy_frame_params(q, bd, p.frame_type)
+            assert list(pol.lf_level) == list(p.lf_level) and pol.cdef_y == p.cdef_y and pol.cdef_damping == p.cdef_damping
+            for sgi in range(segs):
+                f = sgi * gop + t
+                if t == 0:
+                    r = O.intra_encode_frame(Y[f], U[f], V[f], bd, 8, q)
+                    assert (fr["y_mode"][sgi] == r["modes_y"]).all() and (fr["uv_mode"][sgi] == r["modes_uv"]).all()
+                    skip8 = np.zeros((h // 8, w // 8), np.uint8)
+                else:
+                    r = O.inter_encode_frame((Y[f], U[f], V[f]), ref[sgi], bd, q, 8)
+                    assert (fr["mv"][sgi] == r["mvs"]).all() and (fr["skip"][sgi] == r["skip"]).all()
+                    skip8 = r["skip"].reshape(h // 8, w // 8)
+                for k in ("lev_y", "lev_u", "lev_v"):
+                    assert (fr[k][sgi] == r[k]).all(), (t, sgi, k)
+                ref[sgi] = _oracle_filters(O, r, bd, p, w, h, skip8)
+                for got, exp, hh in ((gy, ref[sgi][0], h), (gu, ref[sgi][1], h // 2), (gv, ref[sgi][2], h // 2)):
+                    assert (got[sgi * hh:(sgi + 1) * hh] == exp).all(), "frame %d segment %d: reference differs from the oracle chain" % (t, sgi)
+    finally:
+        s.close()
+
+
+@pytest.mark.skipif(not D.available(), reason="no dav1d in this image")
+@pytest.mark.parametrize("w,h,bd,q,gop,segs", [(192, 128, 8, 110, 4, 2), (1920, 1080, 8, 128, 3, 2), (3840, 2160, 10, 128, 3, 2)])
+def test_session_stream_decodes_in_dav1d_to_the_gpu_reference(ctx, av1mi, w, h, bd, q, gop, segs):
+    """GPU block pipeline + filters -> symbols -> host AV1 writer -> dav1d: the decoded frames equal the reference frames the GPU
+    keeps (BASELINE configs[2] at 1080p 8-bit and configs[3] at 4K 10-bit, full size, two GOPs in lockstep, P referencing P)."""
+    import av1stream
+    import synth
+    Y, U, V = synth.frames(w, h, segs * gop, bd, 4)
+    s = av1mi.GopSession(ctx, w, h, bd, q, gop, segs)
+    try:
+        streams, refs = [b""] * segs, []
+        for t in range(gop):
+            planes = s.input_planes()
+            for sgi in range(segs):
+                f = sgi * gop + t
+                planes[0][sgi * h:(sgi + 1) * h] = Y[f]
+                planes[1][sgi * h // 2:(sgi + 1) * h // 2] = U[f]
+                planes[2][sgi * h // 2:(sgi + 1) * h // 2] = V[f]
+            s.submit()
+            fr = s.collect()
+            refs.append(s.download_reference())
+            for sgi in range(segs):
+                streams[sgi] += av1stream.session_frame_unit(w, h, bd, fr, sgi, threads=8)
+        for sgi in range(segs):
+            got = D.decode(streams[sgi])
+            assert len(got) == gop
+            for t in range(gop):
+                for i, hh in ((0, h), (1, h // 2), (2, h // 2)):
+                    assert (got[t][i] == refs[t][i][sgi * hh:(sgi + 1) * hh]).all(), "segment %d frame %d plane %d: dav1d differs from the GPU" % (sgi, t, i)
+    finally:
+        s.close()
+
+
+def test_session_api_misuse_is_reported(ctx, av1mi):
+    s = av1mi.GopSession(ctx, 64, 64, 8, 100, 2, 1)
+    try:
+        with pytest.raises(av1mi.Av1miError):
+            s.submit()                      # nothing acquired
+        with pytest.raises(av1mi.Av1miError):
+            s.collect()                     # nothing in flight
+        s.input_planes()
+        with pytest.raises(av1mi.Av1miError):
+            s.submit(1)                     # a session starts with a key frame
+    finally:
+        s.close()
+    with pytest.raises(av1mi.Av1miError):
+        av1mi.GopSession(ctx, 60, 64, 8, 100, 2, 1)

@@ -16,7 +16,7 @@ def host():
         subprocess.check_call(["make", "-s", "-C", os.path.dirname(HOST)])
     lib = C.CDLL(HOST)
     lib.av1mi_host_check_size_gate.argtypes = [C.c_longlong, C.c_longlong, C.c_double]
-    lib.av1mi_host_process_job.argtypes = [C.c_char_p, C.c_longlong, C.c_double, C.c_char_p, C.c_int, C.c_char_p, C.c_char_p, C.c_int]
+    lib.av1mi_host_process_job.argtypes = [C.c_char_p, C.c_longlong, C.c_double, C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_int]
     return lib
 
 
@@ -73,43 +73,53 @@ def _write_y4m(path, w, h, n, bd=8):
                 f.write(p.astype("<u2" if bd == 10 else np.uint8).tobytes())
 
 
-def _varint(data, pos):
-    v = sh = 0
-    while True:
-        b = data[pos]
-        pos += 1
-        v |= (b & 127) << sh
-        sh += 7
-        if b < 128:
-            return v, pos
+def _obus(data):
+    """split a Section-5 stream into (type, payload) pairs (obu_has_size_field = 1, no extension)"""
+    out, pos = [], 0
+    while pos < len(data):
+        hdr = data[pos]
+        assert hdr & 0x86 == 0x02, "unexpected OBU header byte %#x" % hdr
+        size, sh, pos = 0, 0, pos + 1
+        while True:
+            b = data[pos]
+            pos += 1
+            size |= (b & 127) << sh
+            sh += 7
+            if b < 128:
+                break
+        out.append(((hdr >> 3) & 15, data[pos:pos + size]))
+        pos += size
+    return out
 
 
-def _check_first_segment_against_oracle(host, data, w, h, q, nframes):
-    """the coded file, decoded by the host entropy decoder, carries exactly the symbols the oracle's encoder loop produces"""
-    from oracle import oracle
-    import synth
-    oracle.build()
-    P = C.c_void_p
-    host.av1mi_host_entropy_decode.argtypes = [P, C.c_longlong, C.c_int, C.c_int, C.c_int, P, P, P, P, P, P, P]
-    Y, U, V = synth.frames(w, h, nframes, 8)       # same call as _write_y4m: the texture depends on the clip length
-    ok = oracle.intra_encode_frame(Y[0], U[0], V[0], 8, 8, q)
-    nb = (w // 8) * (h // 8)
-    pos = data.index(b"\n", data.index(b"SEG 3 ")) + 1
-    vp = lambda a: a.ctypes.data_as(P)
-    for t, key in ((0, 1), (1, 0)):
-        assert data[pos:pos + 1] == (b"K" if key else b"P")
-        n, pos = _varint(data, pos + 1)
-        payload = np.frombuffer(data[pos:pos + n], np.uint8).copy()
-        pos += n
-        ly, lu, lv = np.zeros((nb, 8, 8), np.int16), np.zeros((nb, 4, 4), np.int16), np.zeros((nb, 4, 4), np.int16)
-        my, muv, mvs, skip = np.zeros(nb, np.uint8), np.zeros(nb, np.uint8), np.zeros((nb, 2), np.int16), np.zeros(nb, np.uint8)
-        assert host.av1mi_host_entropy_decode(vp(payload), n, w, h, key, vp(ly), vp(lu), vp(lv), vp(my), vp(muv), vp(mvs), vp(skip)) == 0
-        if key:
-            assert np.array_equal(ly, ok["lev_y"]) and np.array_equal(lu, ok["lev_u"]) and np.array_equal(lv, ok["lev_v"])
-            assert np.array_equal(my, ok["modes_y"]) and np.array_equal(muv, ok["modes_uv"])
-        else:
-            assert skip.max() <= 1 and np.abs(mvs).max() <= 8 * 8 + 7     # +-8 integer search + sub-pel, 1/8 units
-            assert (ly[skip == 1] == 0).all()
+def _ebml_blocks(data):
+    """SimpleBlock payloads (frames) of a Matroska file written by host/mux.cpp, as (is_key, bytes); tiny EBML walker"""
+    def vint(pos, keep_marker):
+        first = data[pos]
+        n = 1
+        while not first & (0x80 >> (n - 1)):
+            n += 1
+        v = first if keep_marker else first & (0xFF >> n)
+        for k in range(1, n):
+            v = (v << 8) | data[pos + k]
+        return v, pos + n
+    frames, codec_private = [], None
+
+    def walk(pos, end):
+        nonlocal codec_private
+        while pos < end:
+            eid, pos = vint(pos, True)
+            size, pos = vint(pos, False)
+            if eid in (0x18538067, 0x1F43B675, 0x1654AE6B, 0xAE):      # Segment, Cluster, Tracks, TrackEntry: descend
+                walk(pos, pos + size)
+            elif eid == 0xA3:
+                assert data[pos] == 0x81
+                frames.append((bool(data[pos + 3] & 0x80), data[pos + 4:pos + size]))
+            elif eid == 0x63A2:
+                codec_private = data[pos:pos + size]
+            pos += size
+    walk(0, len(data))
+    return frames, codec_private
 
 
 def test_run_transcode_fails_cleanly_without_gpu_or_input(host, tmp_path, av1mi):
@@ -126,31 +136,80 @@ def test_run_transcode_fails_cleanly_without_gpu_or_input(host, tmp_path, av1mi)
 
 
 @pytest.mark.gpu
-def test_run_transcode_and_process_job_on_gpu(host, tmp_path):
+def test_run_transcode_and_process_job_on_gpu(host, tmp_path, O):
+    """RunTranscode end to end: Y4M in, AV1 out — the file decodes in dav1d, its frames equal what the oracle's closed-GOP
+    chain reconstructs (key AND P frames, the policy included: the levels come from av1mi_policy_frame_params), in all three
+    containers; then the ProcessJob lifecycle around it."""
+    import av1mi
+    import dav1d_ref as D
+    sys_path_synth()
+    import synth
+    w, h, n, q, gop = 192, 128, 7, 120, 3
     src = tmp_path / "clip.y4m"
-    _write_y4m(str(src), 192, 128, 7)
-    out = tmp_path / "clip.av1-tmp.mkv"
+    _write_y4m(str(src), w, h, n)
     buf = C.create_string_buffer(1024)
-    args = "\n".join(["-hide_banner", "-i", str(src), "-global_quality:v:0", "120", "-g", "3", str(out)])
-    assert host.av1mi_host_run_transcode(args.encode(), buf, 1024) == 0 and buf.value == b""
-    data = out.read_bytes()
-    assert data.startswith(b"AV1MI2 W192 H128 B8 F30:1 Q120 G3\n") and data.count(b"SEG 3 ") == 2 and data.count(b"SEG 1 ") == 1
-    # every segment starts with a key frame ('K' right after its header line), later frames are P frames
-    first = data.index(b"SEG 3 ")
-    assert data[data.index(b"\n", first) + 1:data.index(b"\n", first) + 2] == b"K"
-    assert len(data) < src.stat().st_size            # coarse quantiser: packed levels are smaller than the raw input
-    _check_first_segment_against_oracle(host, data, 192, 128, 120, 7)
-    out.unlink()
-    # lifecycle: generous ratio -> the source is replaced by the coded file; tight ratio -> skipped with markers
+    outs = {}
+    for ext in ("obu", "ivf", "av1-tmp.mkv"):
+        out = tmp_path / ("clip." + ext)
+        args = "\n".join(["-hide_banner", "-i", str(src), "-global_quality:v:0", str(q), "-g", str(gop), "-av1mi_segments", "2", str(out)])
+        assert host.av1mi_host_run_transcode(args.encode(), buf, 1024) == 0 and buf.value == b""
+        outs[ext] = out.read_bytes()
+    obu = outs["obu"]
+    kinds = [t for t, _ in _obus(obu)]
+    assert kinds.count(2) == n and kinds.count(1) == 3 and kinds.count(6) == n      # 7 temporal units, a sequence header per GOP
+    assert len(obu) < src.stat().st_size
+    # IVF and Matroska carry the same temporal units
+    ivf = outs["ivf"]
+    assert ivf[:4] == b"DKIF" and ivf[8:12] == b"AV01" and int.from_bytes(ivf[24:28], "little") == n
+    pos, units = 32, []
+    while pos < len(ivf):
+        sz = int.from_bytes(ivf[pos:pos + 4], "little")
+        units.append(ivf[pos + 12:pos + 12 + sz])
+        pos += 12 + sz
+    assert b"".join(units) == obu
+    frames, priv = _ebml_blocks(outs["av1-tmp.mkv"])
+    assert len(frames) == n and [k for k, _ in frames] == [i % gop == 0 for i in range(n)] and priv[0] == 0x81
+    assert b"".join(b"\x12\x00" + f for _, f in frames) == obu
+    if D.available():
+        Y, U, V = synth.frames(w, h, n, 8)
+        got = D.decode(obu)
+        assert len(got) == n
+        ref = None
+        for i in range(n):
+            key = i % gop == 0
+            p = av1mi.policy_frame_params(q, 8, 0 if key else 1)
+            if key:
+                r = O.intra_encode_frame(Y[i], U[i], V[i], 8, 8, q)
+                skip8 = np.zeros((h // 8, w // 8), np.uint8)
+            else:
+                r = O.inter_encode_frame((Y[i], U[i], V[i]), ref, 8, q, 8)
+                skip8 = r["skip"].reshape(h // 8, w // 8)
+            from test_gpu_session import _oracle_filters
+            ref = _oracle_filters(O, r, 8, p, w, h, skip8)
+            for pl in range(3):
+                assert (got[i][pl] == ref[pl]).all(), "frame %d plane %d: the decoded file differs from the oracle chain" % (i, pl)
+    # lifecycle: tight ratio -> skipped with markers; generous ratio -> success, and the SOURCE IS KEPT (video-only output)
     status, reason = C.create_string_buffer(256), C.create_string_buffer(1024)
     orig = src.stat().st_size
     src2 = tmp_path / "other.y4m"
     src2.write_bytes(src.read_bytes())
-    assert host.av1mi_host_process_job(str(src2).encode(), orig, 1e-4, str(tmp_path).encode(), 0, status, reason, 256) == 0
+    assert host.av1mi_host_process_job(str(src2).encode(), orig, 1e-4, str(tmp_path).encode(), 0, 0, status, reason, 256) == 0
     assert status.value == b"skipped" and reason.value.startswith(b"size gate: new ") and (tmp_path / "other.av1qsvd-skip").exists()
     assert (tmp_path / "other.av1qsvd-why.txt").exists() and not (tmp_path / "other.av1-tmp.mkv").exists() and src2.stat().st_size == orig
-    assert host.av1mi_host_process_job(str(src).encode(), orig, 5.0, str(tmp_path).encode(), 0, status, reason, 256) == 0
-    assert status.value == b"success" and src.read_bytes().startswith(b"AV1MI2 ") and (tmp_path / "test.json").exists()
+    before = src.read_bytes()
+    assert host.av1mi_host_process_job(str(src).encode(), orig, 5.0, str(tmp_path).encode(), 0, 0, status, reason, 256) == 0
+    assert status.value == b"success" and src.read_bytes() == before and (tmp_path / "clip.av1mi.mkv").exists()
+    assert not (tmp_path / "clip.av1-tmp.mkv").exists() and (tmp_path / "test.json").exists()
+    # only on request does the coded file take the source's place (the reference's daemon.go:154 step)
+    src3 = tmp_path / "third.y4m"
+    src3.write_bytes(before)
+    assert host.av1mi_host_process_job(str(src3).encode(), orig, 5.0, str(tmp_path).encode(), 0, 1, status, reason, 256) == 0
+    assert status.value == b"success" and src3.read_bytes()[:4] == b"\x1a\x45\xdf\xa3"
+
+
+def sys_path_synth():
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(HOST), ".."))
 
 
 def _pool(host, paths, workers, ngpus, ratio, state):
@@ -183,10 +242,57 @@ def test_job_pool_concurrent_contexts_are_deterministic(host, tmp_path):
     solo.write_bytes(clips[0].read_bytes())
     n, status = _pool(host, [str(solo)], 1, 1, 5.0, tmp_path)
     assert n == 1 and status == ["success"]
-    ref = solo.read_bytes()
-    assert ref.startswith(b"AV1MI2 ")
+    ref = (tmp_path / "solo.av1mi.mkv").read_bytes()
+    assert ref[:4] == b"\x1a\x45\xdf\xa3"            # EBML: a Matroska file
     n, status = _pool(host, [str(c) for c in clips], 3, 1, 5.0, tmp_path)
     assert n == 4 and status == ["success"] * 4
     for i, c in enumerate(clips):
-        assert c.read_bytes() == ref, "job %d differs from the solo run" % i
+        assert (tmp_path / ("c%d.av1mi.mkv" % i)).read_bytes() == ref, "job %d differs from the solo run" % i
         assert (tmp_path / ("pool%d.json" % i)).exists()
+
+
+def test_containers_carry_the_temporal_units_unchanged(host, tmp_path, O):
+    """host/mux.cpp on the CPU: an oracle-coded closed GOP written as .obu / .ivf / Matroska; the units read back from each
+    container are the same bytes, and (where dav1d is present) decode to the oracle's frames"""
+    import dav1d_ref as D
+    import pipeline as P
+    from test_av1_conformance import _gop
+    w, h, bd, q, n = 128, 64, 8, 140, 3
+    stream, refs = _gop(O, P, w, h, bd, q, n)
+    units, cur = [], b""
+    for t, payload in _obus(stream):
+        if t == 2 and cur:
+            units.append(cur)
+            cur = b""
+        hdr = bytes([t << 3 | 2])
+        size, lebs = len(payload), b""
+        while True:
+            b7 = size & 127
+            size >>= 7
+            lebs += bytes([b7 | (128 if size else 0)])
+            if not size:
+                break
+        cur += hdr + lebs + payload
+    units.append(cur)
+    assert len(units) == n and b"".join(units) == stream
+    data = np.frombuffer(stream, np.uint8)
+    sizes = np.array([len(u) for u in units], np.int64)
+    keys = np.array([1, 0, 0], np.uint8)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    host.av1mi_host_mux_units.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    got = {}
+    for ext in ("obu", "ivf", "mkv"):
+        path = tmp_path / ("g." + ext)
+        assert host.av1mi_host_mux_units(str(path).encode(), w, h, bd, 30000, 1001, vp(data), vp(sizes), vp(keys), n) == 0
+        got[ext] = path.read_bytes()
+    assert got["obu"] == stream
+    ivf = got["ivf"]
+    assert ivf[:4] == b"DKIF" and int.from_bytes(ivf[16:20], "little") == 30000 and int.from_bytes(ivf[24:28], "little") == n
+    frames, priv = _ebml_blocks(got["mkv"])
+    assert [k for k, _ in frames] == [True, False, False]
+    assert priv[:4] == bytes([0x81, 0x1F, 0x0C, 0x00]) and priv[4] == 0x0A      # av1C, then the sequence header OBU
+    rebuilt = b"".join(b"\x12\x00" + f for _, f in frames)
+    assert rebuilt == stream
+    if D.available():
+        dec = D.decode(rebuilt)
+        assert all((dec[t][i] == refs[t][i]).all() for t in range(n) for i in range(3))
