@@ -80,7 +80,11 @@ struct RangeEnc {
     carry();
     renorm();
   }
-  inline void bool_eq(int bit) { encode(bit ? 16384u : 32768u, bit ? 0u : 16384u, bit, 2); }   // read_bool(): cdf {1<<14, 1<<15, 0}
+  inline void bool_eq(int bit) {   // read_bool(): cdf {1 << 14, 1 << 15, 0}: v = ((r >> 8) * 256 >> 1) + 4
+    const uint32_t r = rng, v = ((r >> 8) << 7) + 4;
+    if (bit) { low += r - v; rng = v; carry(); } else { rng = r - v; }
+    renorm();
+  }
   void literal(uint32_t v, int n) { for (int i = n - 1; i >= 0; i--) bool_eq((v >> i) & 1); }     // L(n), spec 4.10.7
   // exit process (8.2.4): the minimum number of bits, then the trailing one, then zero padding to a byte
   void finish() {
@@ -98,17 +102,48 @@ struct RangeEnc {
   }
 };
 
-// adaptive symbol (8.2.6 + the CDF update of 8.2.6 / libaom update_cdf), icdf has n + 1 entries
-inline void put_symbol(RangeEnc &ec, uint16_t *icdf, int n, int s, bool adapt) {
-  ec.encode(s ? icdf[s - 1] : 32768u, icdf[s], s, n);
+// adaptive symbol (8.2.6 + the CDF update of 8.2.6 / libaom update_cdf), icdf has n + 1 entries.  The alphabet size is a
+// compile-time constant at every call site of the hot path (2, 3 and 4 symbols make up ~95 % of a frame's symbols): the update
+// loop unrolls and the rate's log2 term folds.
+template <int N> inline void put_symbol_n(RangeEnc &ec, uint16_t *icdf, int s, bool adapt) {
+  ec.encode(s ? icdf[s - 1] : 32768u, icdf[s], s, N);
   if (adapt) {
-    const int count = icdf[n];
-    const int rate = 3 + (count > 15) + (count > 31) + std::min(floor_log2((uint32_t)n), 2);
-    for (int i = 0; i < n - 1; i++) {
-      if (i < s) icdf[i] += (uint16_t)((32768 - icdf[i]) >> rate);
-      else icdf[i] -= (uint16_t)(icdf[i] >> rate);
+    const int count = icdf[N];
+    constexpr int lg = N >= 4 ? 2 : N >= 2 ? 1 : 0;
+    const int rate = 3 + lg + (count > 15) + (count > 31);
+#pragma GCC unroll 16
+    for (int i = 0; i < N - 1; i++) {
+      const int v = icdf[i];
+      icdf[i] = (uint16_t)(i < s ? v + ((32768 - v) >> rate) : v - (v >> rate));
     }
-    icdf[n] = (uint16_t)(count + (count < 32));
+    icdf[N] = (uint16_t)(count + (count < 32));
+  }
+}
+inline void put_symbol(RangeEnc &ec, uint16_t *icdf, int n, int s, bool adapt) {
+  switch (n) {
+    case 2: put_symbol_n<2>(ec, icdf, s, adapt); break;
+    case 3: put_symbol_n<3>(ec, icdf, s, adapt); break;
+    case 4: put_symbol_n<4>(ec, icdf, s, adapt); break;
+    case 5: put_symbol_n<5>(ec, icdf, s, adapt); break;
+    case 7: put_symbol_n<7>(ec, icdf, s, adapt); break;
+    case 8: put_symbol_n<8>(ec, icdf, s, adapt); break;
+    case 10: put_symbol_n<10>(ec, icdf, s, adapt); break;
+    case 11: put_symbol_n<11>(ec, icdf, s, adapt); break;
+    case 13: put_symbol_n<13>(ec, icdf, s, adapt); break;
+    case 14: put_symbol_n<14>(ec, icdf, s, adapt); break;
+    case 16: put_symbol_n<16>(ec, icdf, s, adapt); break;
+    default: {
+      ec.encode(s ? icdf[s - 1] : 32768u, icdf[s], s, n);
+      if (adapt) {
+        const int count = icdf[n];
+        const int rate = 3 + (count > 15) + (count > 31) + std::min(floor_log2((uint32_t)n), 2);
+        for (int i = 0; i < n - 1; i++) {
+          if (i < s) icdf[i] += (uint16_t)((32768 - icdf[i]) >> rate);
+          else icdf[i] -= (uint16_t)(icdf[i] >> rate);
+        }
+        icdf[n] = (uint16_t)(count + (count < 32));
+      }
+    }
   }
 }
 
@@ -216,7 +251,7 @@ const int8_t kInterSet1Sym[16] = { 7, 8, 9, 12, 10, 11, 13, 14, 15, 0, 1, 2, 3, 
 inline bool is_directional(int m) { return m >= V_PRED && m <= D67_PRED; }
 inline bool tx_class_2d(int t) { return t <= T_FLIPADST_ADST; }
 
-struct Scans { uint8_t s4[16], s8[64]; };
+struct Scans { uint8_t s4[16], s8[64]; };   // position = row * n + col
 const Scans &scans() {   // Default_Scan_4x4 / Default_Scan_8x8 for row-major blocks (row = vertical frequency): 0, 1, 8, 16, 9, 2, 3, 10, ...
   static Scans sc = [] {
     Scans t;
@@ -495,11 +530,16 @@ struct TileEnc {
   void mv_stack(int r8, int c8, MvCand *stack, int *num, int *new_ctx, int *ref_ctx);
   void write_mv_comp(MvCompCdf &m, int diff);
 
-  // ---- coeffs (5.11.39) of one square transform block of n x n (4 or 8) at plane position (x4, y4), tile / superblock relative
+  // ---- coeffs (5.11.39) of one square transform block of N x N (4 or 8) at plane position (x4, y4), tile / superblock relative
   void coeffs(int plane, int x4, int y4, int n, const int16_t *lev, int is_inter, int tx_type, int y_mode) {
-    const int w4 = n >> 2, ptype = plane > 0, txs = n == 4 ? 0 : 1;      // txSzCtx == txSzSqr for square sizes
-    const uint8_t *scan = n == 4 ? scans().s4 : scans().s8;
-    const int nc = n * n;
+    if (n == 8) coeffs_n<8>(plane, x4, y4, lev, is_inter, tx_type, y_mode);
+    else coeffs_n<4>(plane, x4, y4, lev, is_inter, tx_type, y_mode);
+  }
+  template <int N> void coeffs_n(int plane, int x4, int y4, const int16_t *lev, int is_inter, int tx_type, int y_mode) {
+    constexpr int w4 = N >> 2, txs = N == 4 ? 0 : 1, nc = N * N, LG = N == 4 ? 2 : 3;      // txSzCtx == txSzSqr for square sizes
+    constexpr int MS = N + 4;                                                                // stride of the magnitude array
+    const int ptype = plane > 0;
+    const uint8_t *scan = N == 4 ? scans().s4 : scans().s8;
     int eob = 0;
     for (int c = nc - 1; c >= 0; c--) if (lev[scan[c]]) { eob = c + 1; break; }
     // all_zero context (9.3)
@@ -511,55 +551,65 @@ struct TileEnc {
       for (int k = 0; k < w4; k++) { above |= a_lvl[plane][x4 + k] | a_dc[plane][x4 + k]; left |= l_lvl[plane][y4 + k] | l_dc[plane][y4 + k]; }
       ctx = 7 + (above != 0) + (left != 0);
     }
-    sym(cdf.txb_skip[txs][ctx], 2, eob == 0);
+    put_symbol_n<2>(ec, cdf.txb_skip[txs][ctx], eob == 0, adapt);
     int cul = 0, dc_cat = 0;
     if (eob) {
       if (plane == 0) {   // transform_type (5.11.47)
         if (is_inter) {
-          if (f.reduced_tx_set) sym(cdf.inter_tx3[txs], 2, tx_type == T_IDTX ? 0 : 1);
-          else sym(cdf.inter_tx1[txs], 16, kInterSet1Sym[tx_type]);
+          if (f.reduced_tx_set) put_symbol_n<2>(ec, cdf.inter_tx3[txs], tx_type == T_IDTX ? 0 : 1, adapt);
+          else put_symbol_n<16>(ec, cdf.inter_tx1[txs], kInterSet1Sym[tx_type], adapt);
         } else {
-          if (f.reduced_tx_set) sym(cdf.intra_tx2[txs][y_mode], 5, kIntraSet2Sym[tx_type]);
-          else sym(cdf.intra_tx1[txs][y_mode], 7, kIntraSet1Sym[tx_type]);
+          if (f.reduced_tx_set) put_symbol_n<5>(ec, cdf.intra_tx2[txs][y_mode], kIntraSet2Sym[tx_type], adapt);
+          else put_symbol_n<7>(ec, cdf.intra_tx1[txs][y_mode], kIntraSet1Sym[tx_type], adapt);
         }
       }
       // eob_pt_*, eob_extra, eob_extra_bit
       const int eob_pt = eob < 3 ? eob : floor_log2((uint32_t)(eob - 1)) + 2;   // eob in (2^(pt-2), 2^(pt-1)]
-      if (n == 4) sym(cdf.eob16[ptype][0], 5, eob_pt - 1);
-      else sym(cdf.eob64[ptype][0], 7, eob_pt - 1);
+      if (N == 4) put_symbol_n<5>(ec, cdf.eob16[ptype][0], eob_pt - 1, adapt);
+      else put_symbol_n<7>(ec, cdf.eob64[ptype][0], eob_pt - 1, adapt);
       if (eob_pt >= 3) {
         const int off = eob - ((1 << (eob_pt - 2)) + 1);
         int shift = eob_pt - 3;
-        sym(cdf.eob_extra[txs][ptype][eob_pt - 3], 2, (off >> shift) & 1);
-        for (shift--; shift >= 0; shift--) ec.literal((uint32_t)((off >> shift) & 1), 1);
+        put_symbol_n<2>(ec, cdf.eob_extra[txs][ptype][eob_pt - 3], (off >> shift) & 1, adapt);
+        for (shift--; shift >= 0; shift--) ec.bool_eq((off >> shift) & 1);
       }
-      // levels, last to first
-      uint8_t mag[8 + 4][8 + 4];      // min(|level|, 15) with a zero border on the right and bottom
+      // levels, last to first.  mag = min(|level|, 15) with a zero border on the right and bottom; only positions below eob are
+      // ever non-zero, so only those are written
+      uint8_t mag[MS * MS];
       memset(mag, 0, sizeof(mag));
-      for (int i = 0; i < nc; i++) { const int a = std::abs((int)lev[i]); mag[i / n][i % n] = (uint8_t)std::min(a, 15); }
+      for (int c = 0; c < eob; c++) {
+        const int pos = scan[c];
+        const int a = std::abs((int)lev[pos]);
+        mag[(pos >> LG) * MS + (pos & (N - 1))] = (uint8_t)(a > 15 ? 15 : a);
+      }
+      uint16_t(*base_cdf)[5] = cdf.base[txs][ptype];
+      uint16_t(*br_cdf)[5] = cdf.br[txs][ptype];
       for (int c = eob - 1; c >= 0; c--) {
-        const int pos = scan[c], row = pos / n, col = pos % n;
+        const int pos = scan[c], row = pos >> LG, col = pos & (N - 1);
+        const uint8_t *m = mag + row * MS + col;
         const int a = std::abs((int)lev[pos]);
         if (c == eob - 1) {
           const int ectx = c == 0 ? 0 : c <= nc / 8 ? 1 : c <= nc / 4 ? 2 : 3;
-          sym(cdf.base_eob[txs][ptype][ectx], 3, std::min(a, 3) - 1);
+          put_symbol_n<3>(ec, cdf.base_eob[txs][ptype][ectx], (a > 3 ? 3 : a) - 1, adapt);
         } else {
-          // get_coeff_base_ctx, TX_CLASS_2D (9.3)
-          int m = std::min<int>(mag[row][col + 1], 3) + std::min<int>(mag[row + 1][col], 3) + std::min<int>(mag[row + 1][col + 1], 3) +
-                  std::min<int>(mag[row][col + 2], 3) + std::min<int>(mag[row + 2][col], 3);
-          int bctx = std::min((m + 1) >> 1, 4);
+          // get_coeff_base_ctx, TX_CLASS_2D (9.3): neighbours (0,1) (1,0) (1,1) (0,2) (2,0), each capped at 3
+          auto c3 = [](int v) { return v > 3 ? 3 : v; };
+          const int mm = c3(m[1]) + c3(m[MS]) + c3(m[MS + 1]) + c3(m[2]) + c3(m[2 * MS]);
+          int bctx = (mm + 1) >> 1;
+          bctx = bctx > 4 ? 4 : bctx;
           if (pos == 0) bctx = 0;
           else bctx += row + col < 2 ? 1 : row + col < 4 ? 6 : 21;     // Coeff_Base_Ctx_Offset of the square sizes
-          sym(cdf.base[txs][ptype][bctx], 4, std::min(a, 3));
+          put_symbol_n<4>(ec, base_cdf[bctx], a > 3 ? 3 : a, adapt);
         }
         if (a > 2) {     // coeff_br: up to four increments of 0..3
-          int m = mag[row][col + 1] + mag[row + 1][col] + mag[row + 1][col + 1];
-          m = std::min((m + 1) >> 1, 6);
-          const int rctx = pos == 0 ? m : (row < 2 && col < 2) ? m + 7 : m + 14;
+          int mm = m[1] + m[MS] + m[MS + 1];
+          mm = (mm + 1) >> 1;
+          mm = mm > 6 ? 6 : mm;
+          const int rctx = pos == 0 ? mm : (row < 2 && col < 2) ? mm + 7 : mm + 14;
           int rem = a - 3;
           for (int i = 0; i < 4; i++) {
-            const int k = std::min(rem, 3);
-            sym(cdf.br[txs][ptype][rctx], 4, k);
+            const int k = rem > 3 ? 3 : rem;
+            put_symbol_n<4>(ec, br_cdf[rctx], k, adapt);
             rem -= k;
             if (k < 3) break;
           }
@@ -571,15 +621,15 @@ struct TileEnc {
         if (!v) continue;
         const int a = std::abs(v);
         if (c == 0) {
-          int s = 0;
+          int sg = 0;
           for (int k = 0; k < w4; k++) {
             const int ad = a_dc[plane][x4 + k], ld = l_dc[plane][y4 + k];
-            s += (ad == 2) - (ad == 1) + (ld == 2) - (ld == 1);
+            sg += (ad == 2) - (ad == 1) + (ld == 2) - (ld == 1);
           }
-          sym(cdf.dc_sign[ptype][s < 0 ? 1 : s > 0 ? 2 : 0], 2, v < 0);
+          put_symbol_n<2>(ec, cdf.dc_sign[ptype][sg < 0 ? 1 : sg > 0 ? 2 : 0], v < 0, adapt);
           dc_cat = v < 0 ? 1 : 2;
         } else {
-          ec.literal((uint32_t)(v < 0), 1);
+          ec.bool_eq(v < 0);
         }
         if (a > 14) {    // read_golomb: x = a - 14 >= 1, length - 1 zeros then x in `length` bits
           const uint32_t x = (uint32_t)(a - 14);

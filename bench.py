@@ -222,6 +222,25 @@ def probe_baseline_tools():
     return tools
 
 
+def usable_cpus(cap=16):
+    """host threads for the entropy stage: what this process may actually use (affinity mask, cgroup quota), capped at the GPU
+    box's per-GPU CPU share (16) unless AV1MI_HOST_THREADS says otherwise"""
+    if os.environ.get("AV1MI_HOST_THREADS"):
+        return max(1, int(os.environ["AV1MI_HOST_THREADS"]))
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(round(int(quota) / int(period)))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, cap))
+
+
 def e2e_leg(ctx, W, H, bd, qindex, first_frame, segs=4, gop=30, steps=2, warmup_frames=2):
     """END TO END: what the transcode job does per frame (reference: file in -> file out, internal/ffmpeg/transcode.go:194-203):
     source planes from host memory into the session's pinned buffers, H2D upload, block pipeline + in-loop filters on the GPU,
@@ -232,7 +251,7 @@ def e2e_leg(ctx, W, H, bd, qindex, first_frame, segs=4, gop=30, steps=2, warmup_
     import av1mi
     import av1stream
     import synth
-    threads = os.cpu_count() or 1
+    threads = usable_cpus()
     t_gen = time.perf_counter()
     Y, U, V = synth.frames(W, H, segs * gop, bd, first_frame)
     src = [a.reshape(segs, gop, *a.shape[1:]) for a in (Y, U, V)]
