@@ -4,8 +4,9 @@
 //                (tile + search range, coordinates clamped = the spec's edge extension) staged in LDS; one 8x8 block
 //                per wave at a time, ONE CANDIDATE VECTOR PER LANE, the 64 source samples broadcast from LDS;
 //                (SAD, raster rank) packed into one integer and min-reduced across the wave with xor-shuffles.
-//   k_inter_pipe per block, 8 lanes of one wave (8 blocks per wave, no dependency between blocks): half- and
-//                quarter-pel refinement with the real 8-tap sub-pel filter (K4 arithmetic, window in LDS), final
+//   k_inter_pipe per block, 8 lanes of one wave (8 blocks per wave, no dependency between blocks): half-pel refinement scored
+//                with the bilinear filter (= rounded averages, no filter passes), quarter-pel refinement with the real 8-tap
+//                sub-pel filter (K4 arithmetic, window in LDS), final
 //                luma + chroma motion compensation, then the shared residual tail (K1 + K8 + K2, block_code.hpp),
 //                skip flag and final vector.
 // Inter blocks only depend on the PREVIOUS frame, so a P frame is embarrassingly parallel; the serial dependency is
@@ -494,29 +495,60 @@ __global__ __launch_bounds__(256) void k_inter_pipe(InterLaunch L) {
   row_samples<8, ES>(wy + (lane + 4) * YWS + 4, 0, bp);
   pack4(bp, bpp);
   int best = sad_of(bpp), bfx = 0, bfy = 0;     // fractional part in 1/8 samples relative to the integer vector
-  for (int step = 4; step >= 2; step >>= 1) {
-    // the 8 neighbours of (cx, cy): column by column, one horizontal pass per column of candidates.  The oracle visits
-    // them in raster order k = 0..8 with strict improvement, i.e. the winner is the minimum of (SAD, k) and the centre
-    // keeps ties; that order is reproduced with an explicit rank.
-    const int cx = bfx, cy = bfy;
-    // (SAD, rank) as one key: rank 0 = the centre (it keeps ties), k + 1 = the neighbour visited k-th in raster order
-    unsigned bestkey = (unsigned)best << 4;
+  // ---- half-sample round, scored with the BILINEAR filter (encoder policy, mirrored by the oracle; libaom's USE_2_TAPS search):
+  // at phase 8 its taps are (64, 64), and through the spec's two rounding stages ((s + 4) >> 3, then (s + 1024) >> 11) the
+  // prediction is EXACTLY the rounded average of the 2 (one direction) or 4 (both) samples around the position.  So this round
+  // needs no filter passes at all: three window rows of ten samples per lane and adds.  Which half-sample neighbourhood a
+  // block lies in is decided as well this way as with the 8-tap filter (coded bytes and PSNR unchanged); the
+  // quarter-sample round below scores every position, its centre included, with the real filter.
+  {
+    int R[3][10];                                  // window rows lane + 3 .. lane + 5, columns 3 .. 12 = block rows -1 .. +1, columns -1 .. +8
+    constexpr int PER = 4 / (int)sizeof(ES);
+#pragma unroll
+    for (int j = 0; j < 3; j++) row_samples<10, ES>(wy + (lane + 3 + j) * YWS + (3 & ~(PER - 1)), 3 & (PER - 1), R[j]);
+    unsigned bestkey = (unsigned)best << 4;        // (SAD, rank): rank 0 = the centre (keeps ties), k + 1 = the neighbour visited k-th
+#pragma unroll
+    for (int iy = 0; iy < 3; iy++) {
+#pragma unroll
+      for (int ix = 0; ix < 3; ix++) {
+        if (ix == 1 && iy == 1) continue;
+        const int r0 = iy == 0 ? 0 : 1, r1 = iy == 2 ? 2 : 1, c0 = ix == 0 ? 0 : 1, c1 = ix == 2 ? 2 : 1;   // the 1, 2 or 4 samples averaged
+        int o[8];
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+          if (r0 == r1) o[c] = (R[r0][c + c0] + R[r0][c + c1] + 1) >> 1;
+          else if (c0 == c1) o[c] = (R[r0][c + c0] + R[r1][c + c0] + 1) >> 1;
+          else o[c] = (R[r0][c + c0] + R[r0][c + c1] + R[r1][c + c0] + R[r1][c + c1] + 2) >> 2;
+        }
+        uint32_t ow[4];
+        pack4(o, ow);
+        bestkey = min(bestkey, ((unsigned)sad_of(ow) << 4) | (unsigned)(iy * 3 + ix + 1));
+      }
+    }
+    const int rk = (int)(bestkey & 15u), kk = rk - 1, wy_ = (kk * 11) >> 5, wx_ = kk - 3 * wy_;   // kk / 3 for kk in 0..8
+    bfx = rk ? (wx_ - 1) * 4 : 0;
+    bfy = rk ? (wy_ - 1) * 4 : 0;
+  }
+  // ---- quarter-sample round with the real 8-tap filter: the centre (re-scored: rank 0) and its 8 neighbours, column by column,
+  // one horizontal pass per column.  The oracle visits the neighbours in raster order with strict improvement, i.e. the winner
+  // is the minimum of (SAD, rank) and the centre keeps ties; every position goes through the same (key, prediction) update, so
+  // the order of evaluation does not matter.
+  {
+    const int step = 2, cx = bfx, cy = bfy;
+    unsigned bestkey = 0xFFFFFFFFu;
 #pragma unroll 1
     for (int ix = 0; ix < 3; ix++) {
       const int fx = cx + (ix - 1) * step;
-      // half-pel round, centre column: every block of the wave is at a whole-sample horizontal position
-      if (step == 4 && ix == 1) mc_h16_copy<ES>(wy, YWS, im, lane);
-      else mc_h16<ES>(wy, YWS, im, lane, fx * 2, sizeof(ES) == 2 ? s_filt[2] : s_filt[0]);
+      mc_h16<ES>(wy, YWS, im, lane, fx * 2, sizeof(ES) == 2 ? s_filt[2] : s_filt[0]);
       AV1MI_GROUP_SYNC();
       uint32_t pr[5][8];
       mc_rows9(im, lane, pr);
 #pragma unroll
-      for (int iy = 0; iy < 3; iy++) {     // unrolled: the three vertical candidates of a column overlap (1.114 -> 1.080 ms, A/B on one box)
-        if (ix == 1 && iy == 1) continue;
+      for (int iy = 0; iy < 3; iy++) {     // unrolled: the three vertical candidates of a column overlap
         const int fy = cy + (iy - 1) * step, k = iy * 3 + ix;
         uint32_t ow[4];
         mc_v9(pr, fy * 2, s_filt[2], bd, ow);
-        const unsigned key = ((unsigned)sad_of(ow) << 4) | (unsigned)(k + 1);
+        const unsigned key = ((unsigned)sad_of(ow) << 4) | (unsigned)(k == 4 ? 0 : k + 1);
         const bool better = key < bestkey;
         bestkey = min(bestkey, key);
 #pragma unroll
@@ -524,8 +556,7 @@ __global__ __launch_bounds__(256) void k_inter_pipe(InterLaunch L) {
       }
       AV1MI_GROUP_SYNC();
     }
-    // the round's winner back from its key
-    const int rk = (int)(bestkey & 15u), kk = rk - 1, wy_ = (kk * 11) >> 5, wx_ = kk - 3 * wy_;   // kk / 3 for kk in 0..8
+    const int rk = (int)(bestkey & 15u), kk = rk - 1, wy_ = (kk * 11) >> 5, wx_ = kk - 3 * wy_;
     best = (int)(bestkey >> 4);
     bfx = rk ? cx + (wx_ - 1) * step : cx;
     bfy = rk ? cy + (wy_ - 1) * step : cy;
