@@ -151,7 +151,7 @@ def quality(pipe, bd):
         rec = pipe.d["out_y"].download(src.shape, src.dtype)
     mse = float(np.mean((rec.astype(np.float64) - src.astype(np.float64)) ** 2))
     return {"psnr_y_db": 10.0 * np.log10(peak * peak / mse) if mse > 0 else None, "frames": int(src.shape[0]),
-            "vs_libaom_db": None, "note": "fixed qindex, no rate control; libaom is not available on this box"}
+            "note": "fixed qindex, no rate control; the comparison with libaom on the same key frame is under e2e.vs_libaom"}
 
 
 def entropy_leg(ctx, pipe, args, launches=5, host_seconds=6.0):
@@ -241,6 +241,33 @@ def usable_cpus(cap=16):
     return max(1, min(n, cap))
 
 
+def libaom_leg(planes, bd, qindex, our_bytes, our_rec_y, threads):
+    """"PSNR-Y delta vs libaom" (BASELINE.json's metric, second half) for the KEY frame the decoder check just coded: libaom 3.13
+    (the AVIF encoder inside the image's bundled libavif; tools/libaom_compare.py) codes the same 4:2:0 planes as a still image at
+    the quantizer that maps to the same base_q_idx and at three finer ones; dav1d decodes; PSNR-Y against the source.  Reports the
+    delta at the same quantizer and at equal size (log-size interpolation), and libaom's own speed on this box's host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import libaom_compare as LC
+    import dav1d_ref as D
+    Y = planes[0]
+    ours_psnr = LC.psnr(our_rec_y, Y, bd)
+    qz = LC.quantizer_for_qindex(qindex)
+    pts = {}
+    for q in sorted({max(qz - d, 0) for d in (16, 8, 4, 0)}):
+        obus, dt = LC.libaom_encode_still(planes[0], planes[1], planes[2], bd, q, 6, threads)
+        dec = D.decode(obus, strict=False)[0]
+        pts[q] = (len(obus), LC.psnr(dec[0], Y, bd), dt)
+    xs = np.log([pts[q][0] for q in sorted(pts)][::-1])
+    ys = [pts[q][1] for q in sorted(pts)][::-1]
+    eq = float(np.interp(np.log(our_bytes), xs, ys)) if xs[0] <= np.log(our_bytes) <= xs[-1] else None
+    return {"frame": "key frame 0 of the workload", "ours": {"bytes": our_bytes, "psnr_y_db": ours_psnr},
+            "libaom": {"version": "3.13, all-intra still, AOM_Q, speed 6, %d threads" % threads, "matching_quantizer": qz,
+                       "by_quantizer": {str(q): {"bytes": v[0], "psnr_y_db": v[1], "seconds": v[2]} for q, v in pts.items()}},
+            "psnr_y_delta_db_at_same_quantizer": ours_psnr - pts[qz][1], "size_ratio_at_same_quantizer": our_bytes / pts[qz][0],
+            "psnr_y_delta_db_at_equal_size": None if eq is None else ours_psnr - eq,
+            "libaom_frames_per_s_on_host": 1.0 / pts[qz][2]}
+
+
 def e2e_leg(ctx, W, H, bd, qindex, first_frame, segs=4, gop=30, steps=2, warmup_frames=2):
     """END TO END: what the transcode job does per frame (reference: file in -> file out, internal/ffmpeg/transcode.go:194-203):
     source planes from host memory into the session's pinned buffers, H2D upload, block pipeline + in-loop filters on the GPU,
@@ -328,6 +355,7 @@ def e2e_leg(ctx, W, H, bd, qindex, first_frame, segs=4, gop=30, steps=2, warmup_
             dec = D.decode(b"".join(units))
             ok = len(dec) == 2 and all((dec[t][p] == refs[t][p]).all() for t in range(2) for p in range(3))
             out["decoder_check"] = {"decoder": "dav1d " + D.version(), "frames": 2, "bit_exact_vs_gpu_reference": bool(ok)}
+            out["vs_libaom"] = libaom_leg([src[p][0, 0] for p in range(3)], bd, qindex, len(units[0]), refs[0][0], threads)
     except Exception as e:       # the check is a courtesy of the bench, the tests are the gate
         out["decoder_check"] = {"error": repr(e)[:200]}
     pool.shutdown()
