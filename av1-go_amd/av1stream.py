@@ -32,6 +32,8 @@ def lib():
         _lib = C.CDLL(_HOST)
         _lib.av1mi_obu_write_temporal_unit.restype = C.c_longlong
         _lib.av1mi_obu_write_temporal_unit.argtypes = [C.POINTER(ObuFrame), C.c_int, C.c_int, C.c_void_p, C.c_longlong, C.c_char_p, C.c_int]
+        _lib.av1mi_host_opstream_temporal_unit.restype = C.c_longlong
+        _lib.av1mi_host_opstream_temporal_unit.argtypes = [C.POINTER(ObuFrame), C.c_int, C.c_void_p, C.c_longlong, C.c_char_p, C.c_int]
     return _lib
 
 
@@ -42,7 +44,8 @@ _PTR_FIELDS = {"cdef_idx": np.uint8, "y_mode": np.uint8, "angle_y": np.int8, "uv
 
 def temporal_unit(width, height, bit_depth, base_q_idx, frame_type=0, with_sequence_header=True, threads=1, lf_level=(0, 0, 0, 0),
                   lf_sharpness=0, cdef_damping=3, cdef_bits=0, cdef_y=(0,), cdef_uv=(0,), lr_type=(0, 0, 0), lr_unit_shift=0, lr_uv_shift=0,
-                  lr_units=(None, None, None), reduced_tx_set=0, disable_cdf_update=0, tile_cols_log2=-1, tile_rows_log2=-1, **arrays):
+                  lr_units=(None, None, None), reduced_tx_set=0, disable_cdf_update=0, tile_cols_log2=-1, tile_rows_log2=-1, opstream=False,
+                  **arrays):
     """arrays: y_mode, angle_y, uv_mode, angle_uv, cfl_alpha, skip, tx_type, is_inter, mv, lev_y, lev_u, lev_v, cdef_idx (numpy, raster
     order over 8x8 blocks; see av1_bitstream.hpp).  Returns bytes."""
     f = ObuFrame()
@@ -74,7 +77,10 @@ def temporal_unit(width, height, bit_depth, base_q_idx, frame_type=0, with_seque
     cap = width * height * 4 + (1 << 16)
     out = np.empty(cap, np.uint8)
     err = C.create_string_buffer(256)
-    n = lib().av1mi_obu_write_temporal_unit(C.byref(f), int(with_sequence_header), threads, out.ctypes.data, cap, err, 256)
+    if opstream:    # the op-stream formulation (the GPU tile coder's CPU twin, host/av1_opstream.cpp): must give the same bytes
+        n = lib().av1mi_host_opstream_temporal_unit(C.byref(f), int(with_sequence_header), out.ctypes.data, cap, err, 256)
+    else:
+        n = lib().av1mi_obu_write_temporal_unit(C.byref(f), int(with_sequence_header), threads, out.ctypes.data, cap, err, 256)
     if n < 0:
         raise ValueError("av1 bitstream writer: " + err.value.decode())
     if n > cap:

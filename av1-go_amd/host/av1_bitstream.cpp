@@ -956,6 +956,46 @@ std::vector<uint8_t> sequence_header_obu(const SequenceParams &sp) {   // sequen
   return make_obu(1, w.b);
 }
 
+// OBU_FRAME from finished tile payloads (raster order): frame header, tile group with the size prefixes
+static bool assemble_frame(const FrameInfo &fi, const uint8_t *const *tile_data, const size_t *tile_size, std::vector<uint8_t> *out) {
+  const int ntiles = fi.tile_cols * fi.tile_rows;
+  size_t largest = 0, total = 0;
+  for (int t = 0; t + 1 < ntiles; t++) largest = std::max(largest, tile_size[t]);
+  for (int t = 0; t < ntiles; t++) total += tile_size[t];
+  const int tsb = largest <= 0x100 ? 1 : largest <= 0x10000 ? 2 : largest <= 0x1000000 ? 3 : 4;   // tile_size_minus_1 must fit
+  BitWriter w;
+  write_frame_header(w, fi, tsb);
+  w.byte_align();                                 // frame_obu: byte_alignment after the header (5.10)
+  // tile_group_obu (5.11.1)
+  if (ntiles > 1) { w.put(0, 1); w.byte_align(); }   // tile_start_and_end_present_flag
+  std::vector<uint8_t> payload;
+  payload.swap(w.b);
+  payload.reserve(payload.size() + total + (size_t)ntiles * 4);
+  for (int t = 0; t < ntiles; t++) {
+    if (t + 1 < ntiles) {
+      const size_t sz = tile_size[t] - 1;         // tile_size_minus_1, little endian (le(TileSizeBytes))
+      for (int k = 0; k < tsb; k++) payload.push_back((uint8_t)(sz >> (8 * k)));
+    }
+    payload.insert(payload.end(), tile_data[t], tile_data[t] + tile_size[t]);
+  }
+  *out = make_obu(6, payload);
+  return true;
+}
+
+bool frame_obu_from_tiles(const av1mi_obu_frame &f, const uint8_t *payloads, const uint32_t *sizes, int ntiles, std::vector<uint8_t> *out,
+                          std::string *err) {
+  if (!check(f, err)) return false;
+  const FrameInfo fi = frame_info(f);
+  if (ntiles != fi.tile_cols * fi.tile_rows) { if (err) *err = "tile count does not match the frame"; return false; }
+  std::vector<const uint8_t *> data((size_t)ntiles);
+  std::vector<size_t> size((size_t)ntiles);
+  for (int t = 0; t < ntiles; t++) {
+    if (sizes[t] == 0) { if (err) *err = "empty tile payload"; return false; }
+    data[(size_t)t] = payloads; size[(size_t)t] = sizes[t]; payloads += sizes[t];
+  }
+  return assemble_frame(fi, data.data(), size.data(), out);
+}
+
 bool frame_obu(const av1mi_obu_frame &f, int threads, std::vector<uint8_t> *out, std::string *err) {
   if (!check(f, err)) return false;
   FrameInfo fi = frame_info(f);
@@ -979,28 +1019,10 @@ bool frame_obu(const av1mi_obu_frame &f, int threads, std::vector<uint8_t> *out,
     for (int i = 0; i < nt; i++) pool.emplace_back(work);
     for (auto &t : pool) t.join();
   }
-  size_t largest = 0, total = 0;
-  for (int t = 0; t + 1 < ntiles; t++) largest = std::max(largest, tiles[(size_t)t].size());
-  for (auto &t : tiles) total += t.size();
-  const int tsb = largest <= 0x100 ? 1 : largest <= 0x10000 ? 2 : largest <= 0x1000000 ? 3 : 4;   // tile_size_minus_1 must fit
-  BitWriter w;
-  write_frame_header(w, fi, tsb);
-  w.byte_align();                                 // frame_obu: byte_alignment after the header (5.10)
-  // tile_group_obu (5.11.1)
-  if (ntiles > 1) { w.put(0, 1); w.byte_align(); }   // tile_start_and_end_present_flag
-  std::vector<uint8_t> payload;
-  payload.swap(w.b);
-  payload.reserve(payload.size() + total + (size_t)ntiles * 4);
-  for (int t = 0; t < ntiles; t++) {
-    const std::vector<uint8_t> &d = tiles[(size_t)t];
-    if (t + 1 < ntiles) {
-      const size_t sz = d.size() - 1;             // tile_size_minus_1, little endian (le(TileSizeBytes))
-      for (int k = 0; k < tsb; k++) payload.push_back((uint8_t)(sz >> (8 * k)));
-    }
-    payload.insert(payload.end(), d.begin(), d.end());
-  }
-  *out = make_obu(6, payload);
-  return true;
+  std::vector<const uint8_t *> data((size_t)ntiles);
+  std::vector<size_t> size((size_t)ntiles);
+  for (int t = 0; t < ntiles; t++) { data[(size_t)t] = tiles[(size_t)t].data(); size[(size_t)t] = tiles[(size_t)t].size(); }
+  return assemble_frame(fi, data.data(), size.data(), out);
 }
 
 bool temporal_unit(const av1mi_obu_frame &f, bool with_sequence_header, int threads, std::vector<uint8_t> *out, std::string *err) {

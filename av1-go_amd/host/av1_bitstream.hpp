@@ -39,6 +39,13 @@ std::vector<uint8_t> sequence_header_obu(const SequenceParams &sp);
 // OBU_FRAME (spec 5.10: frame header + tile group).  threads > 1 codes tiles on that many host threads.
 // Returns false and fills *err when the description cannot be coded with the tool set above.
 bool frame_obu(const av1mi_obu_frame &f, int threads, std::vector<uint8_t> *out, std::string *err);
+// the same OBU from tile payloads coded elsewhere (the GPU tile entropy coder): `payloads` = the ntiles finished tile payloads
+// back to back in raster order, sizes[t] bytes each
+bool frame_obu_from_tiles(const av1mi_obu_frame &f, const uint8_t *payloads, const uint32_t *sizes, int ntiles, std::vector<uint8_t> *out,
+                          std::string *err);
+// the op-stream formulation of the tile syntax (csrc/av1_ops.hpp) run on the host: the GPU coder's CPU twin (av1_opstream.cpp)
+bool opstream_supported(const av1mi_obu_frame &f, std::string *why);
+bool opstream_tiles(const av1mi_obu_frame &f, std::vector<std::vector<uint8_t>> *tiles, std::string *err);
 // one temporal unit: delimiter [+ sequence header] + frame
 bool temporal_unit(const av1mi_obu_frame &f, bool with_sequence_header, int threads, std::vector<uint8_t> *out, std::string *err);
 

@@ -1,0 +1,83 @@
+// av1_opstream.cpp — the CPU twin of the GPU tile entropy coder: the op-stream formulation of csrc/av1_ops.hpp (tokenize per
+// block with all contexts from neighbour data, then one serial coder pass per tile) run on the host, so that its logic is
+// checked byte for byte against the block-sequential writer of av1_bitstream.cpp on every machine, GPU or not
+// (tests/test_av1_opstream.py).  Also the reference the GPU kernels' output is compared with.
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../csrc/av1_ops_cdfs.hpp"
+#include "av1_bitstream.hpp"
+
+namespace av1mi_host {
+namespace av1 {
+
+// true when the description stays inside the GPU coder's tool set (what the GPU block pipeline produces)
+bool opstream_supported(const av1mi_obu_frame &f, std::string *why) {
+  auto no = [&](const char *m) { if (why) *why = m; return false; };
+  if (f.cdef_bits || f.reduced_tx_set || f.disable_cdf_update) return no("cdef_bits / reduced_tx_set / disable_cdf_update must be 0");
+  if (f.tile_cols_log2 >= 0 || f.tile_rows_log2 >= 0) return no("one superblock per tile only");
+  if (f.angle_y || f.angle_uv || f.cfl_alpha || f.tx_type || f.is_inter) return no("angle deltas, chroma from luma, transform types and intra blocks in inter frames are host-writer only");
+  if (f.frame_type == 0 && f.skip) return no("key frames are coded with skip = 0");
+  for (int p = 0; p < 3; p++) if (f.lr_type[p] > 1) return no("Wiener restoration only");
+  if (f.lr_unit_shift || f.lr_uv_shift) return no("64x64 restoration units only");
+  return true;
+}
+
+// tile payloads (range-coded, finished) of a frame through tokenize + code; tiles in raster order
+bool opstream_tiles(const av1mi_obu_frame &f, std::vector<std::vector<uint8_t>> *tiles, std::string *err) {
+  using namespace av1ops;
+  if (!opstream_supported(f, err)) return false;
+  FrameView v;
+  memset(&v, 0, sizeof(v));
+  v.w8 = f.width / 8; v.h8 = f.height / 8; v.key = f.frame_type == 0;
+  v.y_mode = f.y_mode; v.uv_mode = f.uv_mode; v.mv = f.mv; v.skip = f.skip; v.lev_y = f.lev_y; v.lev_u = f.lev_u; v.lev_v = f.lev_v;
+  std::vector<uint8_t> zskip;
+  if (!v.key && !v.skip) { zskip.assign((size_t)v.w8 * v.h8, 0); v.skip = zskip.data(); }
+  for (int p = 0; p < 3; p++) {
+    v.lr_on[p] = f.lr_type[p] == 1;
+    const int ph = p ? f.height / 2 : f.height, pw = p ? f.width / 2 : f.width;
+    v.lr_rows[p] = std::max((ph + 32) / 64, 1); v.lr_cols[p] = std::max((pw + 32) / 64, 1);
+  }
+  // the op-stream coder takes ONE unit record per plane class (what the session's policy produces): check and copy it
+  for (int p = 0; p < 3; p++) {
+    if (!v.lr_on[p]) continue;
+    const int8_t *u = f.lr_units[p];
+    const size_t n = (size_t)v.lr_rows[p] * v.lr_cols[p];
+    for (size_t i = 1; i < n; i++) if (memcmp(u, u + i * 8, 8)) { if (err) *err = "restoration units must be uniform per plane"; return false; }
+    if (p == 2 && v.lr_on[1] && memcmp(u, f.lr_units[1], 8)) { if (err) *err = "U and V restoration units must be equal"; return false; }
+    memcpy(v.lr_unit[p ? 1 : 0], u, 8);
+  }
+  const size_t nb = (size_t)v.w8 * v.h8;
+  std::vector<BlockInfo> info(nb);
+  v.info = info.data();
+  for (size_t b = 0; b < nb; b++) { memset(&info[b], 0, sizeof(BlockInfo)); block_summary(v, (int)b, &info[b]); }
+  if (!v.key) for (int r = 0; r < v.h8; r++) for (int c = 0; c < v.w8; c++) inter_mode_decision(v, r, c, &info[(size_t)r * v.w8 + c]);
+  const int qcat = f.base_q_idx <= 20 ? 0 : f.base_q_idx <= 60 ? 1 : f.base_q_idx <= 120 ? 2 : 3;
+  SlotTable tab;
+  const std::vector<uint16_t> image = default_slot_image(v.key != 0, qcat, &tab);
+  const int sbr_n = (v.h8 + 7) / 8, sbc_n = (v.w8 + 7) / 8;
+  tiles->assign((size_t)sbr_n * sbc_n, {});
+  std::vector<op_t> ops;
+  std::vector<uint16_t> cdf;
+  for (int sbr = 0; sbr < sbr_n; sbr++)
+    for (int sbc = 0; sbc < sbc_n; sbc++) {
+      Sink count = { nullptr, 0 };
+      for (int zi = 0; zi < 64; zi++) tok_block(v, count, sbr, sbc, zi);
+      ops.resize((size_t)count.n);
+      Sink w = { ops.data(), 0 };
+      for (int zi = 0; zi < 64; zi++) tok_block(v, w, sbr, sbc, zi);
+      cdf = image;
+      std::vector<uint8_t> &out = (*tiles)[(size_t)sbr * sbc_n + sbc];
+      out.resize((size_t)count.n * 2 + 64);
+      Coder c;
+      c.init(out.data(), (int)out.size());
+      for (int i = 0; i < w.n; i++) code_op(c, cdf.data(), tab, ops[(size_t)i]);
+      const int n = c.finish();
+      if (n < 0) { if (err) *err = "tile payload overflow"; return false; }
+      out.resize((size_t)n);
+    }
+  return true;
+}
+
+}  // namespace av1
+}  // namespace av1mi_host

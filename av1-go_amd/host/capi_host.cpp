@@ -102,6 +102,26 @@ long long av1mi_obu_write_temporal_unit(const av1mi_obu_frame *f, int with_seque
   if ((long long)b.size() <= cap && out) memcpy(out, b.data(), b.size());
   return (long long)b.size();
 }
+// the op-stream path on the host (av1_opstream.cpp): same contract as av1mi_obu_write_temporal_unit; -2 = outside its tool set
+long long av1mi_host_opstream_temporal_unit(const av1mi_obu_frame *f, int with_sequence_header, uint8_t *out, long long cap, char *err, int errcap) {
+  std::vector<std::vector<uint8_t>> tiles; std::string e;
+  auto fail = [&](long long code) { if (err && errcap > 0) { strncpy(err, e.c_str(), errcap - 1); err[errcap - 1] = 0; } return code; };
+  if (!av1::opstream_supported(*f, &e)) return fail(-2);
+  if (!av1::opstream_tiles(*f, &tiles, &e)) return fail(-1);
+  std::vector<uint8_t> cat; std::vector<uint32_t> sizes;
+  for (auto &t : tiles) { sizes.push_back((uint32_t)t.size()); cat.insert(cat.end(), t.begin(), t.end()); }
+  std::vector<uint8_t> fr;
+  if (!av1::frame_obu_from_tiles(*f, cat.data(), sizes.data(), (int)sizes.size(), &fr, &e)) return fail(-1);
+  std::vector<uint8_t> b = av1::temporal_delimiter_obu();
+  if (with_sequence_header) {
+    av1::SequenceParams sp; sp.width = f->width; sp.height = f->height; sp.bit_depth = f->bit_depth;
+    const std::vector<uint8_t> sh = av1::sequence_header_obu(sp);
+    b.insert(b.end(), sh.begin(), sh.end());
+  }
+  b.insert(b.end(), fr.begin(), fr.end());
+  if ((long long)b.size() <= cap && out) memcpy(out, b.data(), b.size());
+  return (long long)b.size();
+}
 // container hook for the CPU tests: writes `n` temporal units (concatenated in data, sizes[i] bytes each) to path; 0 = OK
 int av1mi_host_mux_units(const char *path, int w, int h, int bd, int fps_n, int fps_d, const uint8_t *data, const long long *sizes,
                          const uint8_t *keys, int n) {

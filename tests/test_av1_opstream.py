@@ -1,0 +1,80 @@
+"""The op-stream formulation of the tile syntax (av1-go_amd/csrc/av1_ops.hpp: tokenize every block in parallel with all contexts
+taken from neighbour data, then one serial range-coder pass per tile) — the code the GPU tile entropy coder runs — compiled for
+the host (host/av1_opstream.cpp) must produce EXACTLY the bytes of the block-sequential writer (host/av1_bitstream.cpp, which
+dav1d verifies in test_av1_conformance.py).  CPU only."""
+import numpy as np
+import pytest
+
+
+def _key(O, P, w, h, bd, q, first=3):
+    import synth
+    from test_av1_conformance import _chain
+    Y, U, V = synth.frames(w, h, 1, bd, first)
+    r, hdr, _ = _chain(O, P, Y[0], U[0], V[0], bd, q)
+    return dict(y_mode=r["modes_y"], uv_mode=r["modes_uv"], lev_y=r["lev_y"], lev_u=r["lev_u"], lev_v=r["lev_v"]), hdr
+
+
+@pytest.mark.parametrize("w,h,bd,q", [(64, 64, 8, 128), (192, 128, 8, 128), (200, 136, 10, 60), (328, 184, 8, 200), (72, 72, 10, 230),
+                                      (128, 320, 8, 15), (1920, 1080, 8, 128)])
+def test_key_frame_bytes_equal_the_sequential_writer(O, w, h, bd, q):
+    import av1stream
+    import pipeline as P
+    sym, hdr = _key(O, P, w, h, bd, q)
+    a = av1stream.temporal_unit(w, h, bd, q, **sym, **hdr)
+    b = av1stream.temporal_unit(w, h, bd, q, opstream=True, **sym, **hdr)
+    assert a == b
+
+
+@pytest.mark.parametrize("w,h,bd,q,n", [(64, 64, 8, 128, 2), (192, 128, 8, 128, 4), (200, 136, 10, 60, 3), (328, 184, 8, 200, 3), (640, 360, 8, 128, 3)])
+def test_inter_frame_bytes_equal_the_sequential_writer(O, w, h, bd, q, n):
+    """P frames of the oracle's closed-GOP chain: the MV prediction list, the mode contexts and the NEWMV flags come out of two
+    parallel passes over neighbour data instead of a sequential walk"""
+    import av1stream
+    import pipeline as P
+    import synth
+    from test_av1_conformance import _chain, _filters
+    Y, U, V = synth.frames(w, h, n, bd, 3)
+    r, hdr, st = _chain(O, P, Y[0], U[0], V[0], bd, q)
+    ref = st[3]
+    for t in range(1, n):
+        r = O.inter_encode_frame((Y[t], U[t], V[t]), ref, bd, q, 8)
+        hp, st = _filters(O, P, r, bd, q, 1, w, h, r["skip"].reshape(h // 8, w // 8))
+        ref = st[2]
+        sym = dict(frame_type=1, with_sequence_header=False, mv=r["mvs"], skip=r["skip"], lev_y=r["lev_y"], lev_u=r["lev_u"], lev_v=r["lev_v"])
+        assert av1stream.temporal_unit(w, h, bd, q, **sym, **hp) == av1stream.temporal_unit(w, h, bd, q, opstream=True, **sym, **hp), "frame %d" % t
+
+
+def test_random_vectors_and_escape_levels(O):
+    """arbitrary vectors (clustered + far outliers), skip flags and levels large enough for the Golomb escape"""
+    import av1stream
+    rng = np.random.default_rng(5)
+    w, h, bd, q = 192, 136, 10, 90
+    nb = (w // 8) * (h // 8)
+    base = rng.integers(-6, 7, (4, 2)) * 2
+    mv = base[rng.integers(0, 4, nb)].astype(np.int16)
+    far = rng.random(nb) < 0.2
+    mv[far] = (rng.integers(-300, 301, (int(far.sum()), 2)) * 2).astype(np.int16)
+    mv[rng.random(nb) < 0.1] = 0
+    skip = (rng.random(nb) < 0.25).astype(np.uint8)
+
+    def levels(k):
+        a = np.zeros((nb, k), np.int16)
+        m = rng.random((nb, k)) < 0.3 * np.linspace(1, 0.05, k)[None, :]
+        a[m] = rng.integers(-4, 5, int(m.sum()))
+        big = rng.random((nb, k)) < 0.01
+        a[big] = rng.integers(-900, 901, int(big.sum()))
+        return a
+    sym = dict(frame_type=1, with_sequence_header=False, mv=mv, skip=skip, lev_y=levels(64), lev_u=levels(16), lev_v=levels(16), lf_level=(5, 5, 5, 5))
+    assert av1stream.temporal_unit(w, h, bd, q, **sym) == av1stream.temporal_unit(w, h, bd, q, opstream=True, **sym)
+
+
+def test_outside_the_tool_set_is_refused(O):
+    import av1stream
+    w, h = 64, 64
+    nb = 64
+    z = dict(y_mode=np.zeros(nb, np.uint8), uv_mode=np.zeros(nb, np.uint8), lev_y=np.zeros((nb, 64), np.int16), lev_u=np.zeros((nb, 16), np.int16),
+             lev_v=np.zeros((nb, 16), np.int16))
+    with pytest.raises(ValueError):
+        av1stream.temporal_unit(w, h, 8, 100, opstream=True, angle_y=np.ones(nb, np.int8), **z)
+    with pytest.raises(ValueError):
+        av1stream.temporal_unit(w, h, 8, 100, opstream=True, reduced_tx_set=1, **z)
