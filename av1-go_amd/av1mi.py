@@ -81,7 +81,7 @@ class EntropyJob(C.Structure):
 
 class GopConfig(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("bit_depth", C.c_int), ("base_q_idx", C.c_int), ("gop_length", C.c_int),
-                ("segments", C.c_int), ("search_range", C.c_int)]
+                ("segments", C.c_int), ("search_range", C.c_int), ("gpu_entropy", C.c_int)]
 
 
 class FrameParams(C.Structure):
@@ -93,7 +93,8 @@ class FrameParams(C.Structure):
 class GopFrame(C.Structure):
     _fields_ = [("params", FrameParams), ("segments", C.c_int), ("blocks_per_frame", C.c_size_t), ("y_mode", C.c_void_p),
                 ("uv_mode", C.c_void_p), ("mv", C.c_void_p), ("skip", C.c_void_p), ("lev_y", C.c_void_p), ("lev_u", C.c_void_p),
-                ("lev_v", C.c_void_p)]
+                ("lev_v", C.c_void_p), ("tiles_per_frame", C.c_int), ("tile_size", C.c_void_p), ("tile_payload", C.c_void_p),
+                ("payload_bytes", C.c_uint64)]
 
 
 def policy_frame_params(base_q_idx, bit_depth, frame_type):
@@ -113,9 +114,9 @@ def _view(ptr, shape, dtype):
 class GopSession:
     """av1mi_gop_* (include/av1mi.h): closed GOPs in lockstep, policy and PCIe plumbing inside the library."""
 
-    def __init__(self, ctx, width, height, bit_depth, base_q_idx, gop_length, segments=1, search_range=8):
+    def __init__(self, ctx, width, height, bit_depth, base_q_idx, gop_length, segments=1, search_range=8, gpu_entropy=0):
         self.ctx, self.w, self.h, self.bd, self.segments = ctx, width, height, bit_depth, segments
-        self.cfg = GopConfig(width, height, bit_depth, base_q_idx, gop_length, segments, search_range)
+        self.cfg = GopConfig(width, height, bit_depth, base_q_idx, gop_length, segments, search_range, gpu_entropy)
         self.g = C.c_void_p()
         ctx.lib.av1mi_gop_open.argtypes = [C.c_void_p, C.POINTER(GopConfig), C.POINTER(C.c_void_p)]
         ctx._chk(ctx.lib.av1mi_gop_open(ctx.h, C.byref(self.cfg), C.byref(self.g)))
@@ -147,8 +148,13 @@ class GopSession:
         """dict of numpy views (valid for one more submit) + params"""
         f = self.collect_raw()
         S, nb = f.segments, f.blocks_per_frame
-        out = dict(params=f.params, frame_type=f.params.frame_type, lev_y=_view(f.lev_y, (S, nb, 8, 8), np.int16),
-                   lev_u=_view(f.lev_u, (S, nb, 4, 4), np.int16), lev_v=_view(f.lev_v, (S, nb, 4, 4), np.int16))
+        out = dict(params=f.params, frame_type=f.params.frame_type)
+        if f.lev_y:
+            out.update(lev_y=_view(f.lev_y, (S, nb, 8, 8), np.int16), lev_u=_view(f.lev_u, (S, nb, 4, 4), np.int16),
+                       lev_v=_view(f.lev_v, (S, nb, 4, 4), np.int16))
+        if f.tile_size:
+            out.update(tiles_per_frame=f.tiles_per_frame, tile_size=_view(f.tile_size, (S * f.tiles_per_frame,), np.uint32),
+                       tile_payload=_view(f.tile_payload, (max(int(f.payload_bytes), 1),), np.uint8)[:int(f.payload_bytes)])
         if f.params.frame_type == 0:
             out["y_mode"], out["uv_mode"] = _view(f.y_mode, (S, nb), np.uint8), _view(f.uv_mode, (S, nb), np.uint8)
         else:

@@ -88,6 +88,51 @@ def temporal_unit(width, height, bit_depth, base_q_idx, frame_type=0, with_seque
     return out[:n].tobytes()
 
 
+def assemble_temporal_unit(width, height, bit_depth, base_q_idx, payloads, sizes, with_sequence_header=True, **hdr):
+    """temporal unit around tile payloads coded on the GPU (av1mi_obu_assemble_temporal_unit); hdr = header_from_params(...)"""
+    f = ObuFrame()
+    f.width, f.height, f.bit_depth, f.base_q_idx = width, height, bit_depth, base_q_idx
+    f.frame_type = hdr.get("frame_type", 0)
+    for i in range(4):
+        f.lf_level[i] = int(hdr.get("lf_level", (0,) * 4)[i])
+    f.lf_sharpness, f.cdef_damping, f.cdef_bits = hdr.get("lf_sharpness", 0), hdr.get("cdef_damping", 3), 0
+    f.cdef_y[0], f.cdef_uv[0] = int(hdr.get("cdef_y", (0,))[0]), int(hdr.get("cdef_uv", (0,))[0])
+    keep = []
+    for p in range(3):
+        f.lr_type[p] = int(hdr.get("lr_type", (0, 0, 0))[p])
+        u = hdr.get("lr_units", (None,) * 3)[p]
+        if u is not None:
+            a = np.ascontiguousarray(u, np.int8)
+            keep.append(a)
+            f.lr_units[p] = a.ctypes.data
+    f.lr_unit_shift, f.lr_uv_shift = hdr.get("lr_unit_shift", 0), hdr.get("lr_uv_shift", 0)
+    f.tile_cols_log2 = f.tile_rows_log2 = -1
+    pay = np.ascontiguousarray(payloads, np.uint8)
+    sz = np.ascontiguousarray(sizes, np.uint32)
+    cap = int(pay.size) + (1 << 16) + 4 * int(sz.size)
+    out = np.empty(cap, np.uint8)
+    err = C.create_string_buffer(256)
+    L = lib()
+    L.av1mi_obu_assemble_temporal_unit.restype = C.c_longlong
+    L.av1mi_obu_assemble_temporal_unit.argtypes = [C.POINTER(ObuFrame), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_longlong, C.c_char_p, C.c_int]
+    n = L.av1mi_obu_assemble_temporal_unit(C.byref(f), pay.ctypes.data, sz.ctypes.data, int(sz.size), int(with_sequence_header), out.ctypes.data, cap, err, 256)
+    if n < 0 or n > cap:
+        raise ValueError("assemble: " + err.value.decode())
+    return out[:n].tobytes()
+
+
+def session_frame_unit_gpu(width, height, bit_depth, frame, seg, with_sequence_header=None):
+    """the temporal unit of segment `seg` of a collected batch whose tiles were entropy-coded on the GPU (gpu_entropy != 0)"""
+    p = frame["params"]
+    hdr = header_from_params(p, width, height)
+    nt = frame["tiles_per_frame"]
+    sizes = frame["tile_size"][seg * nt:(seg + 1) * nt]
+    start = int(frame["tile_size"][:seg * nt].sum(dtype=np.uint64))
+    pay = frame["tile_payload"][start:start + int(sizes.sum(dtype=np.uint64))]
+    sh = (p.frame_type == 0) if with_sequence_header is None else with_sequence_header
+    return assemble_temporal_unit(width, height, bit_depth, p.base_q_idx, pay, sizes, with_sequence_header=sh, **hdr)
+
+
 def header_from_params(p, width, height):
     """keyword arguments of temporal_unit() for a frame whose filter parameters are an av1mi_frame_params (GOP session policy)"""
     ur = lambda n: max(1, (n + p.lr_unit_size // 2) // p.lr_unit_size)

@@ -16,7 +16,8 @@
 #include <stdint.h>
 
 #if defined(__HIPCC__)
-#define AV1_HD __host__ __device__ __forceinline__
+#include <hip/hip_runtime.h>
+#define AV1_HD __host__ __device__ inline
 #else
 #define AV1_HD inline
 #endif
@@ -479,7 +480,7 @@ AV1_HD void tok_block(const FrameView &f, Sink &k, int sbr, int sbc, int zi) {
 // ------------------------------------------------------------------------------------------------ op coder
 // The range coder of the host writer (RangeEnc, av1_bitstream.cpp) over one tile's op list.  `cdf` = the tile's slot storage
 // (offsets from SlotTable), bytes go to `out` (capacity `cap`); returns the payload size, or -1 on overflow.
-struct SlotTable { uint16_t off[S_MAX]; uint8_t nsym[S_MAX]; int words; };
+struct SlotTable { uint16_t off[S_MAX]; uint8_t nsym[(S_MAX + 3) & ~3]; int words; };     // a whole number of dwords
 
 AV1_HD void build_slot_table(bool key, SlotTable *t) {
   const int n = key ? S_KEY_END : S_INTER_END;

@@ -135,6 +135,15 @@ hipError_t launch_entropy_tokens(const EntropyLaunch &L, hipStream_t s);
 hipError_t launch_entropy_code(const EntropyLaunch &L, hipStream_t s);
 hipError_t launch_entropy_pack(const EntropyLaunch &L, hipStream_t s);
 
+// the AV1 tile entropy coder's per-context scratch (av1_entropy_kernels.hip); created on first use, freed by av1mi_close
+struct av1mi_av1ent_state_fwd;
+}  // namespace av1mi
+struct av1mi_av1ent_state;
+namespace av1mi {
+av1mi_av1ent_state *av1ent_new();
+void av1ent_free(av1mi_av1ent_state *st);
+av1mi_av1ent_state *ctx_av1ent(av1mi_ctx *ctx);
+hipStream_t ctx_side_stream(av1mi_ctx *ctx);
 // accessors of the opaque context for translation units other than capi.hip (gop_session.hip)
 hipStream_t ctx_stream(av1mi_ctx *ctx);
 int ctx_device(av1mi_ctx *ctx);

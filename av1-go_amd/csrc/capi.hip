@@ -22,6 +22,7 @@ struct av1mi_ctx {
   size_t scratch_bytes = 0;
   void *ent_scratch = nullptr;  // K9: tile slots + layout arrays
   size_t ent_bytes = 0;
+  av1mi_av1ent_state *av1ent = nullptr;   // the AV1-syntax tile coder's scratch (av1_entropy_kernels.hip)
   // per-kernel profile: one event pair per launch while enabled
   bool prof_on = false;
   struct ProfRec { int kind; hipEvent_t e0, e1; };
@@ -117,6 +118,16 @@ int check_tx_launch(av1mi_ctx *ctx, int tx_size, const void *coef, const void *p
 namespace av1mi {
 hipStream_t ctx_stream(av1mi_ctx *ctx) { return ctx->stream; }
 int ctx_device(av1mi_ctx *ctx) { return ctx->device; }
+av1mi_av1ent_state *ctx_av1ent(av1mi_ctx *ctx) {
+  if (!ctx->av1ent) ctx->av1ent = av1ent_new();
+  return ctx->av1ent;
+}
+hipStream_t ctx_side_stream(av1mi_ctx *ctx) {
+  if (!ctx->side) {
+    if (hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) != hipSuccess) return nullptr;
+  }
+  return ctx->side;
+}
 int ctx_fail(av1mi_ctx *ctx, int code, const char *fmt, ...) {
   if (ctx) {
     va_list ap;
@@ -168,6 +179,7 @@ void av1mi_close(av1mi_ctx *ctx) {
   for (hipEvent_t ev : ctx->slot_done) if (ev) (void)hipEventDestroy(ev);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->ent_scratch) (void)hipFree(ctx->ent_scratch);
+  if (ctx->av1ent) av1mi::av1ent_free(ctx->av1ent);
   for (auto &r : ctx->prof_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   for (auto e : ctx->prof_pool) (void)hipEventDestroy(e);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);

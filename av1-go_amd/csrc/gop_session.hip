@@ -51,6 +51,10 @@ struct Slot {
   hipEvent_t uploaded = nullptr, kernel_done = nullptr, downloaded = nullptr;
   bool upload_pending = false, kernel_pending = false;
   int frame_type = 0;
+  // GPU entropy coding (gpu_entropy != 0): coded tile payloads + sizes, device + pinned host mirror
+  void *d_ent_out = nullptr, *h_ent_out = nullptr, *d_tile_size = nullptr, *h_tile_size = nullptr, *d_total = nullptr, *h_total = nullptr;
+  hipEvent_t ent_done = nullptr;      // coder + download of sizes / total finished (side stream)
+  bool ent_pending = false;
 };
 
 }  // namespace
@@ -65,6 +69,7 @@ struct av1mi_gop {
   void *d_mi[2][2] = {};                       // [key / inter][luma / chroma] deblocking mode-info maps (one frame, shared by the batch)
   void *d_cdef_sb[2] = {}, *d_lr[2] = {}, *d_zero_skip = nullptr;
   av1mi_frame_params params[2];                // key, inter
+  size_t ent_cap = 0; int tiles = 0;           // GPU entropy coding: payload capacity of a batch, tiles per frame
   long submitted = 0, collected = 0;           // batches
   int gop_pos = 0;
   bool acquired = false;
@@ -115,6 +120,14 @@ int setup(av1mi_gop *g) {
     G_HIP(hipEventCreateWithFlags(&s.uploaded, hipEventDisableTiming));
     G_HIP(hipEventCreateWithFlags(&s.kernel_done, hipEventDisableTiming));
     G_HIP(hipEventCreateWithFlags(&s.downloaded, hipEventDisableTiming));
+    if (c.gpu_entropy) {
+      g->tiles = ((w + 63) / 64) * ((h + 63) / 64);
+      g->ent_cap = (size_t)w * h * S;            // one byte per luma sample: several times what a frame codes to at any sane quantiser
+      G_TRY(dev_alloc(g, &s.d_ent_out, g->ent_cap)); G_TRY(host_alloc(g, &s.h_ent_out, g->ent_cap));
+      G_TRY(dev_alloc(g, &s.d_tile_size, (size_t)g->tiles * S * 4)); G_TRY(host_alloc(g, &s.h_tile_size, (size_t)g->tiles * S * 4));
+      G_TRY(dev_alloc(g, &s.d_total, 16)); G_TRY(host_alloc(g, &s.h_total, 16));
+      G_HIP(hipEventCreateWithFlags(&s.ent_done, hipEventDisableTiming));
+    }
   }
   for (int p = 0; p < 3; p++) {
     const size_t n = (p ? g->nc : g->ny) * g->bps;
@@ -169,8 +182,9 @@ int av1mi_gop_open(av1mi_ctx *ctx, const av1mi_gop_config *cfg, av1mi_gop **out)
     return av1mi::ctx_fail(ctx, AV1MI_E_INVAL, "frame %dx%d must be a multiple of 8", cfg->width, cfg->height);
   if (cfg->bit_depth != 8 && cfg->bit_depth != 10) return av1mi::ctx_fail(ctx, AV1MI_E_INVAL, "bit depth %d not supported (8 or 10)", cfg->bit_depth);
   if (cfg->base_q_idx < 1 || cfg->base_q_idx > 255 || cfg->gop_length < 1 || cfg->segments < 1 || cfg->segments > 4096 || cfg->search_range < 0 ||
-      cfg->search_range > 15)
-    return av1mi::ctx_fail(ctx, AV1MI_E_INVAL, "bad base_q_idx / gop_length / segments / search_range");
+      cfg->search_range > 15 || cfg->gpu_entropy < 0 || cfg->gpu_entropy > 2)
+    return av1mi::ctx_fail(ctx, AV1MI_E_INVAL, "bad base_q_idx / gop_length / segments / search_range / gpu_entropy");
+  if (cfg->gpu_entropy && (cfg->width > 4096 || cfg->height > 4096)) return av1mi::ctx_fail(ctx, AV1MI_E_INVAL, "the AV1 tile coder takes frames up to 4096x4096");
   if ((size_t)cfg->height * cfg->segments > 65535u * 8u) return av1mi::ctx_fail(ctx, AV1MI_E_INVAL, "segments x height too large for one launch");
   av1mi_gop *g = new (std::nothrow) av1mi_gop();
   if (!g) return AV1MI_E_NOMEM;
@@ -191,6 +205,7 @@ void av1mi_gop_close(av1mi_gop *g) {
     if (s.uploaded) (void)hipEventDestroy(s.uploaded);
     if (s.kernel_done) (void)hipEventDestroy(s.kernel_done);
     if (s.downloaded) (void)hipEventDestroy(s.downloaded);
+    if (s.ent_done) (void)hipEventDestroy(s.ent_done);
   }
   for (void *p : g->dev_allocs) (void)hipFree(p);
   for (void *p : g->host_allocs) (void)hipHostFree(p);
@@ -228,6 +243,7 @@ int av1mi_gop_submit(av1mi_gop *g, int frame_type) {
   G_HIP(hipEventRecord(s.uploaded, g->up));
   s.upload_pending = true;
   G_HIP(hipStreamWaitEvent(main, s.uploaded, 0));
+  if (s.ent_pending) G_HIP(hipStreamWaitEvent(main, s.ent_done, 0));      // the GPU coder of two batches ago still reads this slot's symbols
   // the block pipeline (the symbols of this slot were downloaded before the slot was collected, so they may be overwritten)
   if (frame_type == 0) {
     av1mi_intra_job j;
@@ -252,9 +268,31 @@ int av1mi_gop_submit(av1mi_gop *g, int frame_type) {
   G_HIP(hipEventRecord(s.kernel_done, main));
   s.kernel_pending = true;
   s.frame_type = frame_type;
+  if (c.gpu_entropy) {
+    // the AV1 tile entropy coder on the context's side stream, beside the filters and the next batch's block pipeline
+    hipStream_t side = av1mi::ctx_side_stream(g->ctx);
+    if (!side) return av1mi::ctx_fail(g->ctx, AV1MI_E_DEVICE, "no side stream");
+    G_HIP(hipStreamWaitEvent(side, s.kernel_done, 0));
+    const av1mi_frame_params &P = g->params[frame_type];
+    av1mi_av1_entropy_job ej;
+    memset(&ej, 0, sizeof(ej));
+    ej.width = w; ej.height = h; ej.nframes = S; ej.key = frame_type == 0; ej.base_q_idx = c.base_q_idx;
+    ej.d_lev_y = (const int16_t *)s.d_lev[0]; ej.d_lev_u = (const int16_t *)s.d_lev[1]; ej.d_lev_v = (const int16_t *)s.d_lev[2];
+    ej.d_modes_y = (const uint8_t *)s.d_modes[0]; ej.d_modes_uv = (const uint8_t *)s.d_modes[1];
+    ej.d_mvs = (const int16_t *)s.d_mv; ej.d_skip = (const uint8_t *)s.d_skip;
+    ej.lr_on[0] = P.lr_unit_y[0] == 1; ej.lr_on[1] = ej.lr_on[2] = P.lr_unit_uv[0] == 1;
+    memcpy(ej.lr_unit_y, P.lr_unit_y, 8); memcpy(ej.lr_unit_uv, P.lr_unit_uv, 8);
+    ej.d_out = (uint8_t *)s.d_ent_out; ej.out_cap = g->ent_cap; ej.d_tile_size = (uint32_t *)s.d_tile_size; ej.d_total = (uint64_t *)s.d_total;
+    G_TRY(av1mi_av1_entropy_encode_on(g->ctx, &ej, side));
+    G_HIP(hipMemcpyAsync(s.h_tile_size, s.d_tile_size, (size_t)g->tiles * S * 4, hipMemcpyDeviceToHost, side));
+    G_HIP(hipMemcpyAsync(s.h_total, s.d_total, 16, hipMemcpyDeviceToHost, side));
+    G_HIP(hipEventRecord(s.ent_done, side));
+    s.ent_pending = true;
+  }
   // symbols -> pinned host memory, beside the filters
   G_HIP(hipStreamWaitEvent(g->down, s.kernel_done, 0));
-  for (int p = 0; p < 3; p++) G_HIP(hipMemcpyAsync(s.h_lev[p], s.d_lev[p], (p ? g->nc : g->ny) * 2, hipMemcpyDeviceToHost, g->down));
+  if (c.gpu_entropy != 1)
+    for (int p = 0; p < 3; p++) G_HIP(hipMemcpyAsync(s.h_lev[p], s.d_lev[p], (p ? g->nc : g->ny) * 2, hipMemcpyDeviceToHost, g->down));
   if (frame_type == 0) {
     for (int k = 0; k < 2; k++) G_HIP(hipMemcpyAsync(s.h_modes[k], s.d_modes[k], g->nb, hipMemcpyDeviceToHost, g->down));
   } else {
@@ -304,7 +342,17 @@ int av1mi_gop_collect(av1mi_gop *g, av1mi_gop_frame *out) {
   out->blocks_per_frame = g->nb / (size_t)g->cfg.segments;
   if (s.frame_type == 0) { out->y_mode = (const uint8_t *)s.h_modes[0]; out->uv_mode = (const uint8_t *)s.h_modes[1]; }
   else { out->mv = (const int16_t *)s.h_mv; out->skip = (const uint8_t *)s.h_skip; }
-  out->lev_y = (const int16_t *)s.h_lev[0]; out->lev_u = (const int16_t *)s.h_lev[1]; out->lev_v = (const int16_t *)s.h_lev[2];
+  if (g->cfg.gpu_entropy != 1) { out->lev_y = (const int16_t *)s.h_lev[0]; out->lev_u = (const int16_t *)s.h_lev[1]; out->lev_v = (const int16_t *)s.h_lev[2]; }
+  if (g->cfg.gpu_entropy) {
+    G_HIP(hipEventSynchronize(s.ent_done));
+    const uint64_t total = ((const uint64_t *)s.h_total)[0], status = ((const uint64_t *)s.h_total)[1];
+    if (status || total > g->ent_cap)
+      return av1mi::ctx_fail(g->ctx, AV1MI_E_INVAL, "the GPU tile coder ran out of capacity (status %llu, %llu bytes): code this batch on the host (gpu_entropy = 0)",
+                             (unsigned long long)status, (unsigned long long)total);
+    hipStream_t side = av1mi::ctx_side_stream(g->ctx);
+    if (total) { G_HIP(hipMemcpyAsync(s.h_ent_out, s.d_ent_out, total, hipMemcpyDeviceToHost, side)); G_HIP(hipStreamSynchronize(side)); }
+    out->tiles_per_frame = g->tiles; out->tile_size = (const uint32_t *)s.h_tile_size; out->tile_payload = (const uint8_t *)s.h_ent_out; out->payload_bytes = total;
+  }
   g->collected++;
   return AV1MI_OK;
 }

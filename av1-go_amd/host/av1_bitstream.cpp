@@ -282,7 +282,7 @@ struct FrameInfo {
   std::vector<uint8_t> *newmv;   // per block: coded with NEWMV (has_newmv of the MV prediction process); written by the tile coders
 };
 
-bool check(const av1mi_obu_frame &f, std::string *err) {
+bool check(const av1mi_obu_frame &f, std::string *err, bool need_symbols = true) {
   auto bad = [&](const char *m) { if (err) *err = m; return false; };
   if (f.width <= 0 || f.height <= 0 || (f.width & 7) || (f.height & 7) || f.width > 4096 || f.height > 4096)
     return bad("frame size must be a multiple of 8 and at most 4096x4096 (64 superblock tiles per dimension)");
@@ -297,6 +297,7 @@ bool check(const av1mi_obu_frame &f, std::string *err) {
     if (f.lr_type[p] && !f.lr_units[p]) return bad("restoration units missing");
   }
   if (f.lr_unit_shift < 0 || f.lr_unit_shift > 2 || f.lr_uv_shift < 0 || f.lr_uv_shift > 1) return bad("restoration unit size out of range");
+  if (!need_symbols) return true;      // header + tile payloads coded elsewhere (frame_obu_from_tiles)
   if (!f.lev_y || !f.lev_u || !f.lev_v) return bad("levels missing");
   if (f.frame_type == 0 && (!f.y_mode || !f.uv_mode)) return bad("key frame without prediction modes");
   if (f.frame_type == 1 && !f.mv) return bad("inter frame without motion vectors");
@@ -984,7 +985,7 @@ static bool assemble_frame(const FrameInfo &fi, const uint8_t *const *tile_data,
 
 bool frame_obu_from_tiles(const av1mi_obu_frame &f, const uint8_t *payloads, const uint32_t *sizes, int ntiles, std::vector<uint8_t> *out,
                           std::string *err) {
-  if (!check(f, err)) return false;
+  if (!check(f, err, false)) return false;
   const FrameInfo fi = frame_info(f);
   if (ntiles != fi.tile_cols * fi.tile_rows) { if (err) *err = "tile count does not match the frame"; return false; }
   std::vector<const uint8_t *> data((size_t)ntiles);

@@ -102,6 +102,27 @@ long long av1mi_obu_write_temporal_unit(const av1mi_obu_frame *f, int with_seque
   if ((long long)b.size() <= cap && out) memcpy(out, b.data(), b.size());
   return (long long)b.size();
 }
+// One temporal unit from tile payloads coded by the GPU tile entropy coder (include/av1mi.h av1mi_av1_entropy_encode / the GOP
+// session with gpu_entropy): `f` needs only its header fields (geometry, quantiser, filter parameters); payloads = the frame's
+// ntiles finished tile payloads back to back in raster order, sizes[t] bytes each.  Same return convention as
+// av1mi_obu_write_temporal_unit.  Declared in include/av1mi_host.h.
+long long av1mi_obu_assemble_temporal_unit(const av1mi_obu_frame *f, const uint8_t *payloads, const uint32_t *sizes, int ntiles,
+                                           int with_sequence_header, uint8_t *out, long long cap, char *err, int errcap) {
+  std::vector<uint8_t> fr; std::string e;
+  if (!av1::frame_obu_from_tiles(*f, payloads, sizes, ntiles, &fr, &e)) {
+    if (err && errcap > 0) { strncpy(err, e.c_str(), errcap - 1); err[errcap - 1] = 0; }
+    return -1;
+  }
+  std::vector<uint8_t> b = av1::temporal_delimiter_obu();
+  if (with_sequence_header) {
+    av1::SequenceParams sp; sp.width = f->width; sp.height = f->height; sp.bit_depth = f->bit_depth;
+    const std::vector<uint8_t> sh = av1::sequence_header_obu(sp);
+    b.insert(b.end(), sh.begin(), sh.end());
+  }
+  b.insert(b.end(), fr.begin(), fr.end());
+  if ((long long)b.size() <= cap && out) memcpy(out, b.data(), b.size());
+  return (long long)b.size();
+}
 // the op-stream path on the host (av1_opstream.cpp): same contract as av1mi_obu_write_temporal_unit; -2 = outside its tool set
 long long av1mi_host_opstream_temporal_unit(const av1mi_obu_frame *f, int with_sequence_header, uint8_t *out, long long cap, char *err, int errcap) {
   std::vector<std::vector<uint8_t>> tiles; std::string e;

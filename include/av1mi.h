@@ -274,6 +274,32 @@ int av1mi_entropy_encode_async(av1mi_ctx *ctx, const av1mi_entropy_job *job, int
 int av1mi_entropy_wait(av1mi_ctx *ctx, int slot);
 
 
+/* ---- K9 for the real syntax: the AV1 tile entropy coder on the GPU (av1-go_amd/csrc/av1_entropy_kernels.hip).  Codes the outputs
+ * of av1mi_intra_encode (key = 1) or av1mi_inter_encode (key = 0) of `nframes` stacked frames in AV1's tile syntax — the tool
+ * set of the block pipeline: 8x8 blocks, one 64x64 superblock per tile, TX_MODE_LARGEST, DCT_DCT luma, cdef_bits = 0, Wiener
+ * restoration on 64x64 units — byte-identical to the host writer (include/av1mi_host.h), which dav1d verifies.  Output: the tile
+ * payloads of all frames back to back in tile order (frame-major, raster inside a frame) in d_out, their sizes in d_tile_size
+ * (nframes * tiles entries; tiles = ceil(w / 64) * ceil(h / 64)), and d_total[0] = total bytes, d_total[1] = status (0 = OK; bit 0 /
+ * 1: a tile exceeded the coder's op / payload capacity, bit 2: out_cap too small — then the batch must be coded on the host).
+ * The frame header and the tile-size fields are added by the host (av1mi_obu_assemble_temporal_unit): they depend on the
+ * largest tile.  lr_on / lr_unit_*: the restoration parameters the frames were filtered with (av1mi_frame_params). */
+typedef struct av1mi_av1_entropy_job {
+  int width, height, nframes, key, base_q_idx;
+  const int16_t *d_lev_y, *d_lev_u, *d_lev_v;
+  const uint8_t *d_modes_y, *d_modes_uv;       /* key = 1 */
+  const int16_t *d_mvs; const uint8_t *d_skip; /* key = 0 */
+  int lr_on[3];
+  int8_t lr_unit_y[8], lr_unit_uv[8];
+  uint8_t *d_out; size_t out_cap;
+  uint32_t *d_tile_size;
+  uint64_t *d_total;                           /* 2 entries, 8-byte aligned */
+} av1mi_av1_entropy_job;
+int av1mi_av1_entropy_encode(av1mi_ctx *ctx, const av1mi_av1_entropy_job *job);
+/* the same on another HIP stream of the caller's (hipStream_t passed as void *; NULL = the context's stream) */
+int av1mi_av1_entropy_encode_on(av1mi_ctx *ctx, const av1mi_av1_entropy_job *job, void *stream);
+uint32_t av1mi_av1_entropy_ops_per_tile(void);
+uint32_t av1mi_av1_entropy_slot_bytes(void);
+
 /* ---- GOP session: the encoder object a cgo replacement of RunTranscode drives (reference call site
  * internal/daemon/daemon.go:101 -> internal/ffmpeg/transcode.go:194; SURVEY.md §8b "av1mi_open(config) / av1mi_encode /
  * av1mi_flush").  It owns the closed-GOP orchestration and the encoder's filter-parameter POLICY, so that no caller
@@ -295,6 +321,9 @@ typedef struct av1mi_gop_config {
   int gop_length;        /* frames per closed GOP, >= 1 */
   int segments;          /* closed GOPs coded in lockstep, >= 1 */
   int search_range;      /* integer motion search range in samples, 0..15 */
+  int gpu_entropy;       /* 0: the symbols are downloaded, the host entropy-codes them (north_star's split);
+                            1: the AV1 tile entropy coder runs on the GPU (side stream), only tile payloads are downloaded;
+                            2: both (tests compare the two) */
 } av1mi_gop_config;
 
 /* Frame-header parameters chosen by the session's policy for one frame (non-normative encoder choices; the bitstream carries
@@ -321,7 +350,12 @@ typedef struct av1mi_gop_frame {    /* one collected frame batch; host pointers 
   const uint8_t *y_mode, *uv_mode;  /* key frames: intra modes per 8x8 block (0 DC .. 12 PAETH) */
   const int16_t *mv;                /* inter frames: (x, y) per block in 1/8 luma samples */
   const uint8_t *skip;              /* inter frames: 1 = no non-zero level in the block */
-  const int16_t *lev_y, *lev_u, *lev_v;   /* 64 / 16 / 16 levels per block, row-major inside a block */
+  const int16_t *lev_y, *lev_u, *lev_v;   /* 64 / 16 / 16 levels per block, row-major inside a block (NULL with gpu_entropy = 1) */
+  /* gpu_entropy != 0: the finished tile payloads of the batch, frame-major / raster inside a frame, back to back */
+  int tiles_per_frame;
+  const uint32_t *tile_size;        /* segments * tiles_per_frame entries */
+  const uint8_t *tile_payload;
+  uint64_t payload_bytes;
 } av1mi_gop_frame;
 
 typedef struct av1mi_gop av1mi_gop;

@@ -4,6 +4,7 @@
  * cgo replacement of the reference's transcode step binds:
  *
  *   av1mi_run_transcode            stands in for  internal/ffmpeg/transcode.go:194  RunTranscode(ffmpegPath, args) (int, error)
+ *   av1mi_obu_assemble_temporal_unit  frame header + tile group around tile payloads the GPU coder produced
  *   av1mi_obu_write_temporal_unit  the bitstream writer alone, for callers that drive the GOP session (av1mi.h av1mi_gop_*)
  *                                  themselves: symbols of one frame in, one AV1 temporal unit (Section-5 OBUs) out
  *
@@ -59,6 +60,12 @@ typedef struct av1mi_obu_frame {
  * cannot be coded (text in err). */
 long long av1mi_obu_write_temporal_unit(const av1mi_obu_frame *f, int with_sequence_header, int threads, uint8_t *out, long long cap,
                                         char *err, int errcap);
+
+/* The same temporal unit when the tile payloads were coded by the GPU tile entropy coder (av1mi.h: av1mi_av1_entropy_encode, or
+ * the GOP session with gpu_entropy != 0): f carries only the header fields (geometry, base_q_idx, filter parameters; the symbol
+ * pointers are not read), payloads = the frame's ntiles finished tile payloads back to back in raster order, sizes[t] bytes each. */
+long long av1mi_obu_assemble_temporal_unit(const av1mi_obu_frame *f, const uint8_t *payloads, const uint32_t *sizes, int ntiles,
+                                           int with_sequence_header, uint8_t *out, long long cap, char *err, int errcap);
 
 /* The drop-in for RunTranscode (transcode.go:194-315): argv as TranscodeArgs (transcode.go:17) builds it — the backend reads
  * "-i <input.y4m>", "-global_quality:v:0 <q>" and the output path (last argument), plus its own "-g", "-av1mi_device",

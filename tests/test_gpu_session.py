@@ -112,3 +112,65 @@ def test_session_api_misuse_is_reported(ctx, av1mi):
         s.close()
     with pytest.raises(av1mi.Av1miError):
         av1mi.GopSession(ctx, 60, 64, 8, 100, 2, 1)
+
+
+@pytest.mark.parametrize("w,h,bd,q,gop,segs", [(192, 128, 8, 110, 4, 2), (136, 72, 10, 40, 3, 3), (1920, 1080, 8, 128, 3, 2), (3840, 2160, 10, 128, 3, 2)])
+def test_gpu_tile_entropy_coder_bytes_equal_the_host_writer(ctx, av1mi, w, h, bd, q, gop, segs):
+    """K9 for the real syntax: the AV1 tile entropy coder on the GPU (csrc/av1_entropy_kernels.hip).  With gpu_entropy = 2 the
+    session hands out both the symbols and the GPU-coded tile payloads: the temporal unit assembled around the GPU's payloads
+    must be byte-identical to the one the host writer makes of the symbols — key and inter frames, partial superblocks at the
+    frame edge (1080 and 2160 are not multiples of 64), 8 and 10 bit, full 1080p / 4K sizes — and dav1d (when present) decodes it
+    to the GPU's reference frames."""
+    import av1stream
+    import synth
+    Y, U, V = synth.frames(w, h, segs * gop, bd, 4)
+    s = av1mi.GopSession(ctx, w, h, bd, q, gop, segs, gpu_entropy=2)
+    try:
+        streams, refs = [b""] * segs, []
+        for t in range(gop):
+            planes = s.input_planes()
+            for sgi in range(segs):
+                f = sgi * gop + t
+                planes[0][sgi * h:(sgi + 1) * h] = Y[f]
+                planes[1][sgi * h // 2:(sgi + 1) * h // 2] = U[f]
+                planes[2][sgi * h // 2:(sgi + 1) * h // 2] = V[f]
+            s.submit()
+            fr = s.collect()
+            refs.append(s.download_reference())
+            assert fr["tiles_per_frame"] == ((w + 63) // 64) * ((h + 63) // 64) and (fr["tile_size"] > 0).all()
+            for sgi in range(segs):
+                host = av1stream.session_frame_unit(w, h, bd, fr, sgi, threads=8)
+                gpu = av1stream.session_frame_unit_gpu(w, h, bd, fr, sgi)
+                assert gpu == host, "frame %d segment %d: GPU-coded temporal unit differs from the host writer's (%d vs %d bytes)" % (t, sgi, len(gpu), len(host))
+                streams[sgi] += gpu
+        if D.available():
+            for sgi in range(segs):
+                got = D.decode(streams[sgi])
+                assert len(got) == gop
+                for t in range(gop):
+                    for i, hh in ((0, h), (1, h // 2), (2, h // 2)):
+                        assert (got[t][i] == refs[t][i][sgi * hh:(sgi + 1) * hh]).all()
+    finally:
+        s.close()
+
+
+def test_gpu_entropy_only_mode_downloads_no_levels(ctx, av1mi):
+    import av1stream
+    import synth
+    w, h, bd, q = 192, 128, 8, 120
+    Y, U, V = synth.frames(w, h, 2, bd, 1)
+    a = av1mi.GopSession(ctx, w, h, bd, q, 2, 1, gpu_entropy=1)
+    b = av1mi.GopSession(ctx, w, h, bd, q, 2, 1, gpu_entropy=0)
+    try:
+        for t in range(2):
+            for s in (a, b):
+                planes = s.input_planes()
+                for dst, src in zip(planes, (Y[t], U[t], V[t])):
+                    dst[:] = src
+                s.submit()
+            fa, fb = a.collect(), b.collect()
+            assert "lev_y" not in fa and "tile_size" not in fb
+            assert av1stream.session_frame_unit_gpu(w, h, bd, fa, 0) == av1stream.session_frame_unit(w, h, bd, fb, 0)
+    finally:
+        a.close()
+        b.close()
