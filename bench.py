@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end leg (upload + pipeline + download + host AV1 entropy coding)")
     ap.add_argument("--e2e-segments", type=int, default=4)
     ap.add_argument("--e2e-steps", type=int, default=2)
+    ap.add_argument("--e2e-gpu-segments", type=int, default=8, help="segments in lockstep of the end-to-end leg with GPU entropy coding")
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="no GPU: exercise the rank/sharding/timing/aggregation plumbing with a stand-in step (gloo tests)")
     return ap.parse_args()
@@ -268,7 +269,7 @@ def libaom_leg(planes, bd, qindex, our_bytes, our_rec_y, threads):
             "libaom_frames_per_s_on_host": 1.0 / pts[qz][2]}
 
 
-def e2e_leg(ctx, W, H, bd, qindex, first_frame, segs=4, gop=30, steps=2, warmup_frames=2):
+def e2e_leg(ctx, W, H, bd, qindex, first_frame, segs=4, gop=30, steps=2, warmup_frames=2, gpu_entropy=0, compare_libaom=True):
     """END TO END: what the transcode job does per frame (reference: file in -> file out, internal/ffmpeg/transcode.go:194-203):
     source planes from host memory into the session's pinned buffers, H2D upload, block pipeline + in-loop filters on the GPU,
     D2H of the symbols, AV1 entropy coding + OBU packing on all host cores (north_star keeps that stage on the host).  Two
@@ -283,7 +284,7 @@ def e2e_leg(ctx, W, H, bd, qindex, first_frame, segs=4, gop=30, steps=2, warmup_
     Y, U, V = synth.frames(W, H, segs * gop, bd, first_frame)
     src = [a.reshape(segs, gop, *a.shape[1:]) for a in (Y, U, V)]
     t_gen = time.perf_counter() - t_gen
-    sess = av1mi.GopSession(ctx, W, H, bd, qindex, gop, segs)
+    sess = av1mi.GopSession(ctx, W, H, bd, qindex, gop, segs, gpu_entropy=gpu_entropy)
     pool = ThreadPoolExecutor(min(threads, 3 * segs))
     coded = {"bytes": 0, "frames": 0, "t_fill": 0.0, "t_code": 0.0, "t_wait": 0.0}
 
@@ -304,7 +305,10 @@ def e2e_leg(ctx, W, H, bd, qindex, first_frame, segs=4, gop=30, steps=2, warmup_
         fr = sess.collect()
         t1 = time.perf_counter()
         for sg in range(segs):
-            tu = av1stream.session_frame_unit(W, H, bd, fr, sg, threads=threads)
+            if gpu_entropy:      # the tiles were coded on the GPU: the host only wraps them (frame header, tile-size fields)
+                tu = av1stream.session_frame_unit_gpu(W, H, bd, fr, sg)
+            else:
+                tu = av1stream.session_frame_unit(W, H, bd, fr, sg, threads=threads)
             coded["bytes"] += len(tu)
             coded["frames"] += 1
             if keep is not None and sg == 0:
@@ -332,16 +336,21 @@ def e2e_leg(ctx, W, H, bd, qindex, first_frame, segs=4, gop=30, steps=2, warmup_
     frames = coded["frames"]
     out = {"frames_per_s": frames / dt, "frames": frames, "seconds": dt, "segments_in_lockstep": segs, "gop": gop, "host_threads": threads,
            "bytes_per_frame": coded["bytes"] / frames, "mbit_per_s_at_30fps": coded["bytes"] / frames * 8 * 30 / 1e6,
-           "host_seconds": {"fill_pinned_input": coded["t_fill"], "wait_for_gpu": coded["t_wait"], "entropy_code": coded["t_code"]},
-           "pcie_bytes_per_frame": {"up": W * H * 3 // 2 * (1 if bd == 8 else 2), "down": W * H * 3 + (W // 8) * (H // 8) * 5},
-           "what": "pinned host source -> H2D -> block pipeline + deblock + CDEF + LR (GPU) -> D2H symbols -> AV1 entropy coding + OBU "
-                   "packing on %d host threads; synthetic source generated beforehand (%.1f s, not timed)" % (threads, t_gen)}
+           "host_seconds": {"fill_pinned_input": coded["t_fill"], "wait_for_gpu": coded["t_wait"],
+                            "assemble_obu" if gpu_entropy else "entropy_code": coded["t_code"]},
+           "pcie_bytes_per_frame": {"up": W * H * 3 // 2 * (1 if bd == 8 else 2),
+                                    "down": coded["bytes"] / frames if gpu_entropy else W * H * 3 + (W // 8) * (H // 8) * 5},
+           "entropy_coding": "GPU (k_av1_*: AV1 tile syntax, one lane per tile, side stream)" if gpu_entropy else "host, %d threads" % threads,
+           "what": ("pinned host source -> H2D -> block pipeline + deblock + CDEF + LR + AV1 tile entropy coder (GPU) -> D2H tile payloads -> "
+                    "frame header + tile group assembly on the host" if gpu_entropy else
+                    "pinned host source -> H2D -> block pipeline + deblock + CDEF + LR (GPU) -> D2H symbols -> AV1 entropy coding + OBU "
+                    "packing on %d host threads" % threads) + "; synthetic source generated beforehand (%.1f s, not timed)" % t_gen}
     # the stream is real: decode the first frames of segment 0 and compare with the reference frames the GPU keeps
     try:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import dav1d_ref as D
         if D.available():
-            check = av1mi.GopSession(ctx, W, H, bd, qindex, gop, 1)
+            check = av1mi.GopSession(ctx, W, H, bd, qindex, gop, 1, gpu_entropy=gpu_entropy)
             units, refs = [], []
             for t in range(2):
                 planes = check.input_planes()
@@ -349,13 +358,14 @@ def e2e_leg(ctx, W, H, bd, qindex, first_frame, segs=4, gop=30, steps=2, warmup_
                     np.copyto(planes[p], src[p][0, t])
                 check.submit(0 if t == 0 else 1)
                 fr = check.collect()
-                units.append(av1stream.session_frame_unit(W, H, bd, fr, 0, threads=threads))
+                units.append(av1stream.session_frame_unit_gpu(W, H, bd, fr, 0) if gpu_entropy else av1stream.session_frame_unit(W, H, bd, fr, 0, threads=threads))
                 refs.append(check.download_reference())
             check.close()
             dec = D.decode(b"".join(units))
             ok = len(dec) == 2 and all((dec[t][p] == refs[t][p]).all() for t in range(2) for p in range(3))
             out["decoder_check"] = {"decoder": "dav1d " + D.version(), "frames": 2, "bit_exact_vs_gpu_reference": bool(ok)}
-            out["vs_libaom"] = libaom_leg([src[p][0, 0] for p in range(3)], bd, qindex, len(units[0]), refs[0][0], threads)
+            if compare_libaom:
+                out["vs_libaom"] = libaom_leg([src[p][0, 0] for p in range(3)], bd, qindex, len(units[0]), refs[0][0], threads)
     except Exception as e:       # the check is a courtesy of the bench, the tests are the gate
         out["decoder_check"] = {"error": repr(e)[:200]}
     pool.shutdown()
@@ -523,8 +533,9 @@ def main():
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u8" if bd == 8 else "u16", "data": "synthetic",
         "config": {"workload": pipe.describe(), "value_is": "DEVICE-RESIDENT block pipeline + in-loop filters (source frames already in HBM, symbols left "
-                   "in HBM: the bench contract's definition of `value`); the end-to-end encode rate (PCIe both ways + AV1 entropy coding on "
-                   "the host cores, a decodable stream) is `e2e_frames_per_s`", "frames_per_step": frames, "qindex": args.qindex,
+                   "in HBM: the bench contract's definition of `value`); the end-to-end encode rates (PCIe both ways + AV1 entropy coding, a "
+                   "decodable stream verified by dav1d) are `e2e_frames_per_s` (entropy coding on the host cores, north_star's split) and "
+                   "`e2e_gpu_entropy_frames_per_s` (the same bytes from the GPU tile entropy coder)", "frames_per_step": frames, "qindex": args.qindex,
                    "sharding": "closed-GOP segment per GPU, no collective", "device": ctx.device_name},
     }
     if rank == 0:
@@ -559,8 +570,12 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_e2e and args.workload.endswith("-gop"):
             e2e = e2e_leg(ctx, W, H, bd, args.qindex, segment_of_rank(rank, frames), segs=args.e2e_segments, steps=args.e2e_steps)
-            out["e2e"] = e2e
+            out["e2e"] = e2e                      # north_star's split: entropy coding on the host cores
             out["e2e_frames_per_s"] = e2e["frames_per_s"]
+            g = e2e_leg(ctx, W, H, bd, args.qindex, segment_of_rank(rank, frames), segs=args.e2e_gpu_segments, steps=args.e2e_steps, gpu_entropy=1,
+                        compare_libaom=False)
+            out["e2e_gpu_entropy"] = g            # the same stream, byte for byte, with the tile entropy coder on the GPU
+            out["e2e_gpu_entropy_frames_per_s"] = g["frames_per_s"]
         print(json.dumps(out))
     ctx.close()
     if dist is not None:
