@@ -23,7 +23,7 @@ struct Av1EntLaunch {
   FrameView fv;                 // pointers of frame 0; frame f adds f * per-frame strides
   int nframes, sbr_n, sbc_n;
   BlockInfo *info;              // nframes * blocks
-  op_t *ops; uint32_t ops_cap;  // per tile
+  op_t *ops; uint32_t ops_cap;  // per tile (32-bit ops)
   uint32_t *nops;               // per tile
   uint8_t *slots; uint32_t slot_cap;   // per tile payload slot
   uint32_t *tile_size;          // per tile: payload bytes (0 = overflow)
@@ -60,7 +60,14 @@ __global__ __launch_bounds__(64) void k_av1_tokens(Av1EntLaunch L) {
   const int tiles = L.sbr_n * L.sbc_n, t = blockIdx.x, f = t / tiles, tt = t - f * tiles, sbr = tt / L.sbc_n, sbc = tt - sbr * L.sbc_n;
   const FrameView v = frame_view(L, f);
   const int zi = threadIdx.x;
-  Sink cnt = { nullptr, 0 };
+  __shared__ SlotTable s_tab;          // per-thread indexed lookups when the ops are written: from LDS, not from the kernel arguments
+  {
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(&L.tab);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(&s_tab);
+    for (int i = zi; i < (int)(sizeof(SlotTable) / 4); i += 64) dst[i] = src[i];
+  }
+  __syncthreads();
+  Sink cnt = { nullptr, 0, &s_tab };
   tok_block(v, cnt, sbr, sbc, zi);
   // exclusive scan of the 64 counts (one wave)
   int x = cnt.n;
@@ -75,7 +82,7 @@ __global__ __launch_bounds__(64) void k_av1_tokens(Av1EntLaunch L) {
     if (zi == 0) { atomicOr(L.status, 1u); L.nops[t] = 0; }
     return;
   }
-  Sink w = { L.ops + (size_t)t * L.ops_cap + off, 0 };
+  Sink w = { L.ops + (size_t)t * L.ops_cap + off, 0, &s_tab };
   tok_block(v, w, sbr, sbc, zi);
 }
 
@@ -84,13 +91,6 @@ __global__ __launch_bounds__(64) void k_av1_tokens(Av1EntLaunch L) {
 __global__ __launch_bounds__(32) void k_av1_code(Av1EntLaunch L, int ntiles_all, int stride) {
   const int LPW = (int)blockDim.x;
   extern __shared__ uint16_t s_cdf[];
-  __shared__ SlotTable s_tab;          // per-lane indexed lookups: from LDS, not from the kernel arguments
-  {
-    const uint32_t *src = reinterpret_cast<const uint32_t *>(&L.tab);
-    uint32_t *dst = reinterpret_cast<uint32_t *>(&s_tab);
-    for (int i = threadIdx.x; i < (int)(sizeof(SlotTable) / 4); i += LPW) dst[i] = src[i];
-  }
-  __syncthreads();
   const int lane = threadIdx.x, t = blockIdx.x * LPW + lane;
   const bool live = t < ntiles_all;
   uint16_t *cdf = s_cdf + lane * stride;
@@ -98,8 +98,61 @@ __global__ __launch_bounds__(32) void k_av1_code(Av1EntLaunch L, int ntiles_all,
   Coder c;
   c.init(L.slots + (size_t)(live ? t : 0) * L.slot_cap, (int)L.slot_cap);
   const int n = live ? (int)L.nops[t] : 0;
-  const op_t *ops = L.ops + (size_t)(live ? t : 0) * L.ops_cap;
-  for (int i = 0; i < n; i++) code_op(c, cdf, s_tab, ops[i]);
+  // ONE interval update per loop iteration for every lane, whatever the op: an adaptive symbol, or one bit of a literal (a
+  // literal of k bits takes k iterations).  The lanes of a wave code different tiles and meet different ops at every step; with
+  // "symbol" and "literal" as separate paths the wave executed both, literal loop included, at almost every step (measured:
+  // 4 us per op).  Here the paths differ only in where (fl, fh) come from and whether the CDF adapts.
+  // The op list is read four ops (one 16-byte load) at a time, the next chunk requested before the current one is coded.
+  const uint4 *ops4 = reinterpret_cast<const uint4 *>(L.ops + (size_t)(live ? t : 0) * L.ops_cap);
+  uint4 cur = n > 0 ? ops4[0] : make_uint4(0, 0, 0, 0), nxt = n > 4 ? ops4[1] : make_uint4(0, 0, 0, 0);
+  int i = 0, lit_left = 0;
+  uint32_t lit_val = 0;
+  while (__any(lit_left > 0 || i < n)) {
+    if (!(lit_left > 0 || i < n)) continue;
+    uint32_t fl = 32768u, fh = 0;
+    int sym = 0, ns = 2;
+    uint16_t *v = nullptr;
+    if (lit_left == 0) {
+      const int k = i & 3;
+      const uint32_t op = k == 0 ? cur.x : k == 1 ? cur.y : k == 2 ? cur.z : cur.w;
+      i++;
+      if ((i & 3) == 0) { cur = nxt; if (i + 4 < n) nxt = ops4[(i >> 2) + 1]; }
+      if (op & 0x80000000u) {
+        const int nbits = (op >> 27) & 15;
+        if (nbits) { lit_left = nbits; lit_val = op & 0x7FFu; }
+        else {   // split_or_horz / split_or_vert: "split" with the probability gathered from the partition CDF as it stands
+          const uint16_t *p = cdf + (op & 0xFFF);
+          const uint32_t p1 = p[0] - p[1], p2 = p[1] - p[2], p3 = p[2] - p[3], p4 = p[3] - p[4], p5 = p[4] - p[5], p6 = p[5] - p[6], p7 = p[6] - p[7],
+                         p8 = p[7] - p[8], p9 = p[8];
+          fl = ((op >> 26) & 1) == 0 ? p2 + p3 + p4 + p6 + p7 + p9 : p1 + p3 + p4 + p5 + p6 + p8;
+          fh = 0; sym = 1; ns = 2;
+        }
+      } else {
+        sym = op & 15; ns = (op >> 4) & 31;
+        v = cdf + ((op >> 9) & 0xFFF);
+        fl = sym ? v[sym - 1] : 32768u;
+        fh = sym == ns - 1 ? 0u : v[sym];
+      }
+    }
+    if (lit_left > 0) {
+      lit_left--;
+      sym = (lit_val >> lit_left) & 1;
+      fl = sym ? 16384u : 32768u; fh = sym ? 0u : 16384u; ns = 2;
+    }
+    c.encode(fl, fh, sym, ns);
+    if (v) {   // adaptation (8.2.6): alphabets of up to four symbols (95 % of all) without a loop
+      const int count = v[ns - 1];
+      const int rate = 3 + (count > 15) + (count > 31) + (ns >= 4 ? 2 : 1);
+      if (ns <= 4) {
+#pragma unroll
+        for (int q = 0; q < 3; q++)
+          if (q < ns - 1) { const int x = v[q]; v[q] = (uint16_t)(q < sym ? x + ((32768 - x) >> rate) : x - (x >> rate)); }
+      } else {
+        for (int q = 0; q < ns - 1; q++) { const int x = v[q]; v[q] = (uint16_t)(q < sym ? x + ((32768 - x) >> rate) : x - (x >> rate)); }
+      }
+      v[ns - 1] = (uint16_t)(count + (count < 32));
+    }
+  }
   if (!live) return;
   int sz = n ? c.finish() : -1;          // n == 0: the op list overflowed (k_av1_tokens), nothing to code
   if (sz < 0) { if (n) atomicOr(L.status, 2u); sz = 0; }

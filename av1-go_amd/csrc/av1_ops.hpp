@@ -95,24 +95,29 @@ AV1_HD int slot_nsym(int s, bool key) {
   }
   return 16;
 }
-AV1_HD int slot_words(int nsym) { return (nsym + 3) & ~3; }      // uint16 entries of a slot: nsym - 1 values + counter, padded
+AV1_HD int slot_words(int nsym) { return nsym; }      // uint16 entries of a slot: nsym - 1 values + the counter, no padding (LDS is the coder's scarce resource)
 
 // ------------------------------------------------------------------------------------------------ ops
-// symbol op:  0 | slot (11 bits) | symbol (4 bits)
-// literal op: 1 | n (4 bits, 1..11) | value (11 bits)          n equiprobable bits, most significant first
-// split op:   1 | 0000 | kind (1 bit: 0 = split_or_horz, 1 = split_or_vert) | partition slot (10 bits): the bit "split" coded
-//             with the probability gathered from the CURRENT partition CDF (frame edges, spec 9.3); no adaptation
-typedef uint16_t op_t;
-AV1_HD op_t op_sym(int slot, int s) { return (op_t)((slot << 4) | s); }
-AV1_HD op_t op_lit(int n, unsigned v) { return (op_t)(0x8000u | (unsigned)(n << 11) | (v & 0x7FFu)); }
-AV1_HD op_t op_split(int kind, int slot) { return (op_t)(0x8000u | (unsigned)(kind << 10) | (unsigned)slot); }
+// 32-bit ops, RESOLVED by the tokenizer (the slot's storage offset and alphabet size travel in the op, so the serial coder has no
+// table lookup on its dependent chain):
+// symbol op:  0 | offset of the slot in uint16 (12 bits, << 9) | alphabet size (5 bits, << 4) | symbol (4 bits)
+// literal op: 1 | n (4 bits, 1..11, << 27) | value (11 bits)          n equiprobable bits, most significant first
+// split op:   1 | n = 0 | kind (bit 26: 0 = split_or_horz, 1 = split_or_vert) | offset of the partition slot (12 bits): the bit
+//             "split" coded with the probability gathered from the CURRENT partition CDF (frame edges, spec 9.3); no adaptation
+typedef uint32_t op_t;
+struct SlotTable { uint16_t off[S_MAX]; uint8_t nsym[(S_MAX + 3) & ~3]; int words; };     // a whole number of dwords
+AV1_HD op_t op_sym(int off, int nsym, int s) { return (op_t)(((unsigned)off << 9) | ((unsigned)nsym << 4) | (unsigned)s); }
+AV1_HD op_t op_lit(int n, unsigned v) { return (op_t)(0x80000000u | ((unsigned)n << 27) | (v & 0x7FFu)); }
+AV1_HD op_t op_split(int kind, int off) { return (op_t)(0x80000000u | ((unsigned)kind << 26) | (unsigned)off); }
 
 // where the ops of one block go: a counting pass (out == nullptr) and a writing pass share the code
 struct Sink {
   op_t *out;
   int n;
+  const SlotTable *tab;
   AV1_HD void put(op_t o) { if (out) out[n] = o; n++; }
-  AV1_HD void sym(int slot, int s) { put(op_sym(slot, s)); }
+  AV1_HD void sym(int slot, int s) { if (out) out[n] = op_sym(tab->off[slot], tab->nsym[slot], s); n++; }
+  AV1_HD void split(int kind, int slot) { if (out) out[n] = op_split(kind, tab->off[slot]); n++; }
   AV1_HD void lit(unsigned v, int nbits) {                // most significant bits first, at most 11 per op
     while (nbits > 11) { nbits -= 11; put(op_lit(11, v >> nbits)); }
     if (nbits > 0) put(op_lit(nbits, v & ((1u << nbits) - 1u)));
@@ -140,7 +145,7 @@ struct FrameView {
 AV1_HD int iabs(int v) { return v < 0 ? -v : v; }
 AV1_HD int imin(int a, int b) { return a < b ? a : b; }
 AV1_HD int imax(int a, int b) { return a > b ? a : b; }
-AV1_HD int ilog2(unsigned v) { int r = 0; while (v >>= 1) r++; return r; }
+AV1_HD int ilog2(unsigned v) { return 31 - __builtin_clz(v | 1u); }      // floor(log2 v), v >= 1
 AV1_HD unsigned morton8(unsigned x, unsigned y) {
   unsigned m = 0;
   for (int i = 0; i < 3; i++) m |= ((x >> i) & 1u) << (2 * i) | ((y >> i) & 1u) << (2 * i + 1);
@@ -306,8 +311,8 @@ AV1_HD void tok_partition_prefix(const FrameView &f, Sink &k, int sbr, int sbc, 
     const bool au = by > 0, al = bx > 0;                   // tile = superblock
     const int slot = (bsize == 16 ? S_PART16 : bsize == 32 ? S_PART32 : S_PART64) + (al ? 2 : 0) + (au ? 1 : 0);
     if (has_rows && has_cols) k.sym(slot, 3);              // PARTITION_SPLIT
-    else if (has_cols) k.put(op_split(0, slot));           // split_or_horz = 1
-    else if (has_rows) k.put(op_split(1, slot));           // split_or_vert = 1
+    else if (has_cols) k.split(0, slot);                   // split_or_horz = 1
+    else if (has_rows) k.split(1, slot);                   // split_or_vert = 1
   }
   k.sym(S_PART8, 0);                                       // PARTITION_NONE
 }
@@ -315,16 +320,11 @@ AV1_HD void tok_partition_prefix(const FrameView &f, Sink &k, int sbr, int sbc, 
 // coeffs (5.11.39) of an N x N block (N = 8 luma, 4 chroma)
 template <int N> AV1_HD void tok_coeffs(Sink &k, int plane, const int16_t *lev, int above_cul, int above_dc, int left_cul, int left_dc, bool key, int y_mode) {
   const int nc = N * N, LG = N == 4 ? 2 : 3, MS = N + 4;
-  // Default_Scan: diagonals, odd ones walked downwards from the top row (row-major positions)
-  uint8_t scan[N * N];
-  {
-    int q = 0;
-    for (int d = 0; d < 2 * N - 1; d++)
-      for (int i = 0; i <= d; i++) {
-        const int r = (d & 1) ? i : d - i, c = d - r;
-        if (r < N && c < N) scan[q++] = (uint8_t)(r * N + c);
-      }
-  }
+  // Default_Scan_4x4 / Default_Scan_8x8 for row-major blocks: diagonals, odd ones walked downwards from the top row
+  static constexpr uint8_t kScan4[16] = { 0, 1, 4, 8, 5, 2, 3, 6, 9, 12, 13, 10, 7, 11, 14, 15 };
+  static constexpr uint8_t kScan8[64] = { 0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+                                          35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63 };
+  const uint8_t *scan = N == 4 ? kScan4 : kScan8;
   int eob = 0;
   for (int c = nc - 1; c >= 0; c--) if (lev[scan[c]]) { eob = c + 1; break; }
   const bool chroma = plane > 0;
@@ -480,8 +480,6 @@ AV1_HD void tok_block(const FrameView &f, Sink &k, int sbr, int sbc, int zi) {
 // ------------------------------------------------------------------------------------------------ op coder
 // The range coder of the host writer (RangeEnc, av1_bitstream.cpp) over one tile's op list.  `cdf` = the tile's slot storage
 // (offsets from SlotTable), bytes go to `out` (capacity `cap`); returns the payload size, or -1 on overflow.
-struct SlotTable { uint16_t off[S_MAX]; uint8_t nsym[(S_MAX + 3) & ~3]; int words; };     // a whole number of dwords
-
 AV1_HD void build_slot_table(bool key, SlotTable *t) {
   const int n = key ? S_KEY_END : S_INTER_END;
   int o = 0;
@@ -547,23 +545,23 @@ struct Coder {
 };
 
 // one op on a tile's CDF storage
-template <class CdfPtr> AV1_HD void code_op(Coder &c, CdfPtr cdf, const SlotTable &t, op_t op) {
-  if (op & 0x8000u) {
-    const int n = (op >> 11) & 15;
+template <class CdfPtr> AV1_HD void code_op(Coder &c, CdfPtr cdf, op_t op) {
+  if (op & 0x80000000u) {
+    const int n = (op >> 27) & 15;
     if (n) {
       for (int i = n - 1; i >= 0; i--) c.bit((op >> i) & 1);
     } else {
       // split_or_horz / split_or_vert: "split" with the probability gathered from the partition CDF as it stands now
-      const int slot = op & 0x3FF, kind = (op >> 10) & 1;
-      const uint16_t *p = &cdf[t.off[slot]];
+      const int kind = (op >> 26) & 1;
+      const uint16_t *p = &cdf[op & 0xFFF];
       auto prob = [&](int q) { return (uint32_t)((q ? p[q - 1] : 32768) - (q == 9 ? 0 : p[q])); };
       const uint32_t psum = kind == 0 ? prob(2) + prob(3) + prob(4) + prob(6) + prob(7) + prob(9) : prob(1) + prob(3) + prob(4) + prob(5) + prob(6) + prob(8);
       c.encode(psum, 0, 1, 2);
     }
     return;
   }
-  const int slot = op >> 4, s = op & 15, n = t.nsym[slot];
-  auto *v = &cdf[t.off[slot]];
+  const int s = op & 15, n = (op >> 4) & 31;
+  auto *v = &cdf[(op >> 9) & 0xFFF];
   c.encode(s ? v[s - 1] : 32768u, s == n - 1 ? 0u : v[s], s, n);
   const int count = v[n - 1];
   const int rate = 3 + (count > 15) + (count > 31) + (n >= 4 ? 2 : 1);

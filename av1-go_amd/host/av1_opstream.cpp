@@ -61,17 +61,17 @@ bool opstream_tiles(const av1mi_obu_frame &f, std::vector<std::vector<uint8_t>> 
   std::vector<uint16_t> cdf;
   for (int sbr = 0; sbr < sbr_n; sbr++)
     for (int sbc = 0; sbc < sbc_n; sbc++) {
-      Sink count = { nullptr, 0 };
+      Sink count = { nullptr, 0, &tab };
       for (int zi = 0; zi < 64; zi++) tok_block(v, count, sbr, sbc, zi);
       ops.resize((size_t)count.n);
-      Sink w = { ops.data(), 0 };
+      Sink w = { ops.data(), 0, &tab };
       for (int zi = 0; zi < 64; zi++) tok_block(v, w, sbr, sbc, zi);
       cdf = image;
       std::vector<uint8_t> &out = (*tiles)[(size_t)sbr * sbc_n + sbc];
-      out.resize((size_t)count.n * 2 + 64);
+      out.resize((size_t)count.n * 2 + 64);       // a step adds at most 15 bits
       Coder c;
       c.init(out.data(), (int)out.size());
-      for (int i = 0; i < w.n; i++) code_op(c, cdf.data(), tab, ops[(size_t)i]);
+      for (int i = 0; i < w.n; i++) code_op(c, cdf.data(), ops[(size_t)i]);
       const int n = c.finish();
       if (n < 0) { if (err) *err = "tile payload overflow"; return false; }
       out.resize((size_t)n);
