@@ -10,7 +10,7 @@ python3 $ROOT/bench.py > $ROOT/gpurun_out/${TAG}_bench_4k10-gop.json 2> $ROOT/gp
 python3 $ROOT/tools/bench_stages.py --json $ROOT/gpurun_out/${TAG}_stages.json > $ROOT/gpurun_out/${TAG}_stages.log 2>&1 || exit 1
 cd /tmp && export TMPDIR=/tmp
 for w in 4k10-gop 1080p8-gop 1080p8; do
-  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/${TAG}_kt_$w -- python3 $ROOT/bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline \
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/${TAG}_kt_$w -- python3 $ROOT/bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline --no-e2e \
     > $ROOT/gpurun_out/${TAG}_bench_${w}_under_rocprof.json 2> $ROOT/gpurun_out/${TAG}_kt_$w.err || exit 1
 done
-cd $ROOT && bash tools/prof_pmc.sh $TAG "--steps 1 --warmup 1 --no-cpu-baseline"
+cd $ROOT && bash tools/prof_pmc.sh $TAG "--steps 1 --warmup 1 --no-cpu-baseline --no-e2e"

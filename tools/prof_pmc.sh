@@ -3,7 +3,7 @@
 # (no sys/hip/hsa tracing), as the pool requires.  Output: gpurun_out/pmc_<tag>/*counter_collection.csv
 set -u
 TAG=${1:-r01}
-ARGS=${2:-"--steps 3 --warmup 1 --no-cpu-baseline"}
+ARGS=${2:-"--steps 3 --warmup 1 --no-cpu-baseline --no-e2e"}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 i=0
