@@ -139,6 +139,10 @@ class GopSession:
     def pending(self):
         return self.ctx.lib.av1mi_gop_pending(self.g)
 
+    def entropy_fallbacks(self):
+        self.ctx.lib.av1mi_gop_entropy_fallbacks.restype = C.c_long
+        return self.ctx.lib.av1mi_gop_entropy_fallbacks(self.g)
+
     def collect_raw(self):
         f = GopFrame()
         self.ctx._chk(self.ctx.lib.av1mi_gop_collect(self.g, C.byref(f)))

@@ -71,6 +71,7 @@ struct av1mi_gop {
   av1mi_frame_params params[2];                // key, inter
   size_t ent_cap = 0; int tiles = 0;           // GPU entropy coding: payload capacity of a batch, tiles per frame
   long submitted = 0, collected = 0;           // batches
+  long fallbacks = 0;                          // batches the GPU coder could not hold (handed out as symbols instead)
   int gop_pos = 0;
   bool acquired = false;
   std::vector<void *> dev_allocs, host_allocs;
@@ -213,6 +214,7 @@ void av1mi_gop_close(av1mi_gop *g) {
 }
 
 int av1mi_gop_pending(av1mi_gop *g) { return g ? (int)(g->submitted - g->collected) : 0; }
+long av1mi_gop_entropy_fallbacks(av1mi_gop *g) { return g ? g->fallbacks : 0; }
 
 int av1mi_gop_acquire_input(av1mi_gop *g, void **y, void **u, void **v) {
   if (!g || !y || !u || !v) return AV1MI_E_INVAL;
@@ -346,12 +348,21 @@ int av1mi_gop_collect(av1mi_gop *g, av1mi_gop_frame *out) {
   if (g->cfg.gpu_entropy) {
     G_HIP(hipEventSynchronize(s.ent_done));
     const uint64_t total = ((const uint64_t *)s.h_total)[0], status = ((const uint64_t *)s.h_total)[1];
-    if (status || total > g->ent_cap)
-      return av1mi::ctx_fail(g->ctx, AV1MI_E_INVAL, "the GPU tile coder ran out of capacity (status %llu, %llu bytes): code this batch on the host (gpu_entropy = 0)",
-                             (unsigned long long)status, (unsigned long long)total);
     hipStream_t side = av1mi::ctx_side_stream(g->ctx);
-    if (total) { G_HIP(hipMemcpyAsync(s.h_ent_out, s.d_ent_out, total, hipMemcpyDeviceToHost, side)); G_HIP(hipStreamSynchronize(side)); }
-    out->tiles_per_frame = g->tiles; out->tile_size = (const uint32_t *)s.h_tile_size; out->tile_payload = (const uint8_t *)s.h_ent_out; out->payload_bytes = total;
+    if (status || total > g->ent_cap) {
+      // A tile exceeded the coder's op-list / payload capacity (very fine quantisers on dense content).  The batch is not lost:
+      // its symbols are still in the slot's device buffers (the next kernel that overwrites them is two submits away), so they
+      // are downloaded now and handed out like in host mode: tile_size stays NULL, the caller entropy-codes this batch itself.
+      if (g->cfg.gpu_entropy == 1) {
+        for (int p = 0; p < 3; p++) G_HIP(hipMemcpyAsync(s.h_lev[p], s.d_lev[p], (p ? g->nc : g->ny) * 2, hipMemcpyDeviceToHost, side));
+        G_HIP(hipStreamSynchronize(side));
+        out->lev_y = (const int16_t *)s.h_lev[0]; out->lev_u = (const int16_t *)s.h_lev[1]; out->lev_v = (const int16_t *)s.h_lev[2];
+      }
+      g->fallbacks++;
+    } else {
+      if (total) { G_HIP(hipMemcpyAsync(s.h_ent_out, s.d_ent_out, total, hipMemcpyDeviceToHost, side)); G_HIP(hipStreamSynchronize(side)); }
+      out->tiles_per_frame = g->tiles; out->tile_size = (const uint32_t *)s.h_tile_size; out->tile_payload = (const uint8_t *)s.h_ent_out; out->payload_bytes = total;
+    }
   }
   g->collected++;
   return AV1MI_OK;

@@ -86,7 +86,7 @@ void DescribeSessionFrame(const av1mi_gop_frame &fr, int seg, int width, int hei
   const size_t nb = fr.blocks_per_frame, o = (size_t)seg * nb;
   if (p.frame_type == 0) { f.y_mode = fr.y_mode + o; f.uv_mode = fr.uv_mode + o; }
   else { f.mv = fr.mv + o * 2; f.skip = fr.skip + o; }
-  f.lev_y = fr.lev_y + o * 64; f.lev_u = fr.lev_u + o * 16; f.lev_v = fr.lev_v + o * 16;
+  if (fr.lev_y) { f.lev_y = fr.lev_y + o * 64; f.lev_u = fr.lev_u + o * 16; f.lev_v = fr.lev_v + o * 16; }     // absent when the tiles were coded on the GPU
 }
 
 int RunBackend(const BackendJob &job, std::string *err) {
@@ -112,6 +112,7 @@ int RunBackend(const BackendJob &job, std::string *err) {
     av1mi_gop_config cfg;
     cfg.width = w; cfg.height = h; cfg.bit_depth = y.bd; cfg.base_q_idx = job.quality < 1 ? 1 : job.quality; cfg.gop_length = G; cfg.segments = S;
     cfg.search_range = 8;
+    cfg.gpu_entropy = job.gpu_entropy ? 1 : 0;
     CHK(av1mi_gop_open(ctx, &cfg, &gop));
     av1::SequenceParams sp; sp.width = w; sp.height = h; sp.bit_depth = y.bd;
     if (!sink.open(job.output, sp, y.fps_n, y.fps_d, err)) { code = 1; goto done; }
@@ -131,7 +132,16 @@ int RunBackend(const BackendJob &job, std::string *err) {
           DescribeSessionFrame(fr, s, w, h, y.bd, &desc);
           std::vector<uint8_t> tu;
           std::string werr;
-          if (!av1::temporal_unit(desc.f, t == 0, threads, &tu, &werr)) { *err = "bitstream writer: " + werr; return false; }
+          if (fr.tile_size) {      // tiles coded on the GPU: frame header + tile group around them
+            const uint32_t *sz = fr.tile_size + (size_t)s * fr.tiles_per_frame;
+            size_t off = 0;
+            for (size_t i = 0; i < (size_t)s * fr.tiles_per_frame; i++) off += fr.tile_size[i];
+            std::vector<uint8_t> frame;
+            if (!av1::frame_obu_from_tiles(desc.f, fr.tile_payload + off, sz, fr.tiles_per_frame, &frame, &werr)) { *err = "bitstream assembly: " + werr; return false; }
+            tu = av1::temporal_delimiter_obu();
+            if (t == 0) { const std::vector<uint8_t> sh = av1::sequence_header_obu(sp); tu.insert(tu.end(), sh.begin(), sh.end()); }
+            tu.insert(tu.end(), frame.begin(), frame.end());
+          } else if (!av1::temporal_unit(desc.f, t == 0, threads, &tu, &werr)) { *err = "bitstream writer: " + werr; return false; }
           units[(size_t)s].push_back(std::move(tu));
         }
         return true;

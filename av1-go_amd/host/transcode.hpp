@@ -47,6 +47,8 @@ struct BackendJob {
   int device = 0;
   int segments = 4;        // closed GOPs coded in lockstep (the GOP session's batch)
   int threads = 0;         // host threads for entropy coding; 0 = all cores
+  int gpu_entropy = 1;     // 1 = the AV1 tile entropy coder runs on the GPU (the host only assembles frames); 0 = north_star's split:
+                           // symbols are downloaded and coded on the host cores.  Same bytes either way.
 };
 bool ParseBackendJob(const std::vector<std::string> &args, BackendJob *job, std::string *err);
 

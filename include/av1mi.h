@@ -372,6 +372,9 @@ int av1mi_gop_submit(av1mi_gop *g, int frame_type);
 int av1mi_gop_collect(av1mi_gop *g, av1mi_gop_frame *out);
 /* number of batches in flight (0..2) */
 int av1mi_gop_pending(av1mi_gop *g);
+/* gpu_entropy != 0: batches whose tiles exceeded the GPU coder's capacity so far.  Such a batch is handed out by
+ * av1mi_gop_collect with tile_size == NULL and the symbols filled in instead (the caller entropy-codes it on the host). */
+long av1mi_gop_entropy_fallbacks(av1mi_gop *g);
 /* the reference frame(s) produced by the LAST submitted batch (after all in-loop filters): host buffers of the stacked-plane
  * sizes; synchronises the session.  For tests and PSNR. */
 int av1mi_gop_download_reference(av1mi_gop *g, void *y, void *u, void *v);

@@ -174,3 +174,33 @@ def test_gpu_entropy_only_mode_downloads_no_levels(ctx, av1mi):
     finally:
         a.close()
         b.close()
+
+
+@pytest.mark.skipif(not D.available(), reason="no dav1d in this image")
+def test_gpu_coder_capacity_overflow_falls_back_to_the_host(ctx, av1mi):
+    """white noise at base_q_idx 2: a 64x64 tile needs more ops than the GPU coder's per-tile list holds.  The session must not
+    lose the batch: it hands the symbols out instead (tile_size absent), the host writer codes them, dav1d agrees with the GPU."""
+    import av1stream
+    w, h, bd, q = 128, 128, 8, 2
+    rng = np.random.default_rng(0)
+    s = av1mi.GopSession(ctx, w, h, bd, q, 2, 1, gpu_entropy=1)
+    try:
+        stream, refs = b"", []
+        for t in range(2):
+            planes = s.input_planes()
+            planes[0][:] = rng.integers(0, 256, planes[0].shape)
+            planes[1][:] = rng.integers(0, 256, planes[1].shape)
+            planes[2][:] = rng.integers(0, 256, planes[2].shape)
+            s.submit()
+            fr = s.collect()
+            refs.append(s.download_reference())
+            if "tile_size" in fr:
+                stream += av1stream.session_frame_unit_gpu(w, h, bd, fr, 0)
+            else:
+                assert "lev_y" in fr
+                stream += av1stream.session_frame_unit(w, h, bd, fr, 0)
+        assert s.entropy_fallbacks() >= 1
+        got = D.decode(stream)
+        assert len(got) == 2 and all((got[t][i] == refs[t][i]).all() for t in range(2) for i in range(3))
+    finally:
+        s.close()
