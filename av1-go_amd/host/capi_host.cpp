@@ -143,6 +143,14 @@ long long av1mi_host_opstream_temporal_unit(const av1mi_obu_frame *f, int with_s
   if ((long long)b.size() <= cap && out) memcpy(out, b.data(), b.size());
   return (long long)b.size();
 }
+// job record + GPU probe hooks for the CPU tests
+int av1mi_host_job_json(const char *id, const char *source, const char *status, const char *reason, long long orig, long long neu, char *buf, int cap) {
+  Job j; j.ID = id; j.SourcePath = source; j.Status = status; j.Reason = reason; j.OriginalSize = orig; j.NewSize = neu; j.CreatedAt = "2026-01-02T03:04:05Z";
+  const std::string s = JobToJSON(j);
+  strncpy(buf, s.c_str(), cap - 1); buf[cap - 1] = 0;
+  return (int)s.size();
+}
+double av1mi_host_gpu_usage(int device, const char *sysfs_root) { return GetGPUUsage(device, sysfs_root ? sysfs_root : "/sys"); }
 // container hook for the CPU tests: writes `n` temporal units (concatenated in data, sizes[i] bytes each) to path; 0 = OK
 int av1mi_host_mux_units(const char *path, int w, int h, int bd, int fps_n, int fps_d, const uint8_t *data, const long long *sizes,
                          const uint8_t *keys, int n) {

@@ -8,6 +8,7 @@
 #include <cerrno>
 #include <cstdio>
 #include <cstring>
+#include <ctime>
 #include <fstream>
 
 namespace av1mi_host {
@@ -34,19 +35,60 @@ std::string json_escape(const std::string &s) {           // what encoding/json 
   }
   return o;
 }
-void save_job(const Job &j, const std::string &dir) {     // jobs.SaveJob, jobs.go:61-79 (fields this path owns)
-  if (dir.empty() || j.ID.empty()) return;
-  std::ofstream f(dir + "/" + j.ID + ".json");
-  f << "{\n  \"id\": \"" << json_escape(j.ID) << "\",\n  \"source_path\": \"" << json_escape(j.SourcePath) << "\",\n  \"output_path\": \""
-    << json_escape(j.OutputPath) << "\",\n  \"status\": \"" << json_escape(j.Status) << "\",\n  \"reason\": \"" << json_escape(j.Reason)
-    << "\",\n  \"original_bytes\": " << j.OriginalSize
-    << ",\n  \"new_bytes\": " << j.NewSize << ",\n  \"is_webrip_like\": " << (j.IsWebRipLike ? "true" : "false") << "\n}\n";
+void save_job(Job &j, const std::string &dir) {      // terminal states carry finished_at (daemon.go sets it before every final SaveJob)
+  if ((j.Status == "success" || j.Status == "failed" || j.Status == "skipped") && j.FinishedAt.empty()) j.FinishedAt = NowRFC3339();
+  SaveJob(j, dir);
 }
 void write_why(const std::string &source, const std::string &reason) {   // metadata.WriteWhyFile, probe.go:398
   std::string dir, stem, ext; split(source, &dir, &stem, &ext);
   write_text(dir + "/" + stem + ".av1qsvd-why.txt", reason);
 }
 }  // namespace
+
+std::string NowRFC3339() {
+  char buf[40];
+  const time_t t = time(nullptr);
+  struct tm tmv;
+  gmtime_r(&t, &tmv);
+  strftime(buf, sizeof(buf), "%Y-%m-%dT%H:%M:%SZ", &tmv);
+  return buf;
+}
+std::string JobToJSON(const Job &j) {     // encoding/json with the struct tags of jobs.go:25-46 (omitempty where tagged)
+  std::string o = "{\n";
+  bool first = true;
+  auto sep = [&] { if (!first) o += ",\n"; first = false; };
+  auto str = [&](const char *k, const std::string &v, bool omitempty) { if (omitempty && v.empty()) return; sep(); o += std::string("  \"") + k + "\": \"" + json_escape(v) + "\""; };
+  auto num = [&](const char *k, int64_t v, bool omitempty) { if (omitempty && v == 0) return; sep(); o += std::string("  \"") + k + "\": " + std::to_string(v); };
+  str("id", j.ID, false); str("source_path", j.SourcePath, false); str("output_path", j.OutputPath, true);
+  str("created_at", j.CreatedAt.empty() ? "0001-01-01T00:00:00Z" : j.CreatedAt, false);      // time.Time zero value
+  str("started_at", j.StartedAt, true); str("finished_at", j.FinishedAt, true);
+  str("status", j.Status, false); str("reason", j.Reason, true);
+  num("original_bytes", j.OriginalSize, true); num("new_bytes", j.NewSize, true); num("estimated_bytes", j.EstimatedSize, true);
+  sep(); o += std::string("  \"is_webrip_like\": ") + (j.IsWebRipLike ? "true" : "false");
+  str("source_codec", j.SourceCodec, true); str("resolution", j.Resolution, true); num("bit_depth", j.BitDepth, true);
+  str("frame_rate", j.FrameRate, true); str("container", j.Container, true); str("video_codec", j.VideoCodec, true);
+  num("audio_streams", j.AudioStreams, true); num("subtitle_streams", j.SubStreams, true);
+  return o + "\n}";
+}
+void SaveJob(const Job &j, const std::string &dir) {
+  if (dir.empty() || j.ID.empty()) return;
+  mkdir(dir.c_str(), 0755);              // os.MkdirAll, jobs.go:63
+  std::ofstream f(dir + "/" + j.ID + ".json");
+  f << JobToJSON(j);
+}
+double GetGPUUsage(int device, const std::string &sysfs_root) {
+  // cards are numbered in probe order; the device-th card that has the amdgpu busy file is the device-th HIP device on a box
+  // whose only GPUs are the MI355X (render-only nodes carry no cardN entry and are skipped)
+  int seen = 0;
+  for (int card = 0; card < 64; card++) {
+    std::ifstream f(sysfs_root + "/class/drm/card" + std::to_string(card) + "/device/gpu_busy_percent");
+    if (!f) continue;
+    double v = -1;
+    f >> v;
+    if (seen++ == device) return v < 0 ? -1 : v > 100 ? 100 : v;
+  }
+  return -1;
+}
 
 bool CheckSizeGate(int64_t origBytes, int64_t newBytes, double maxRatio) { return (double)newBytes <= (double)origBytes * maxRatio; }
 
@@ -75,6 +117,9 @@ std::string ProcessJob(Job *job, const std::string &backendPath, const ProbeResu
   if (!CheckFileStable(job->SourcePath, cfg.StableWaitSeconds, &stable, &err)) return "failed to check file stability: " + err;   // :59-62
   if (!stable) { job->Status = "skipped"; job->Reason = "file still copying"; write_why(job->SourcePath, job->Reason); return ""; }       // :63-71
   job->Status = "running";                                                                                                             // :74-79
+  job->StartedAt = NowRFC3339();
+  if (job->CreatedAt.empty()) job->CreatedAt = job->StartedAt;
+  job->VideoCodec = "av1";
   save_job(*job, cfg.JobStateDir);
   std::string dir, stem, ext; split(job->SourcePath, &dir, &stem, &ext);
   const std::string outputPath = dir + "/" + stem + ".av1-tmp.mkv";                                                                     // :82-87

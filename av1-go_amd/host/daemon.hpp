@@ -12,11 +12,25 @@ bool CheckSizeGate(int64_t origBytes, int64_t newBytes, double maxRatio);       
 bool AtomicReplaceFile(const std::string &originalPath, const std::string &newPath, std::string *err);   // daemon.go:25-53
 bool CheckFileStable(const std::string &path, int waitSeconds, bool *stable, std::string *err);          // scan.go:13-33
 
-struct Job {                       // jobs.Job, the fields ProcessJob reads or writes
+struct Job {                       // jobs.Job, jobs.go:25-46: all 20 fields, so that the records av1top reads stay complete
   std::string ID, SourcePath, OutputPath, Status = "pending", Reason;
-  int64_t OriginalSize = 0, NewSize = 0;
+  std::string CreatedAt, StartedAt, FinishedAt;      // RFC 3339 (time.Time in the reference); empty = omitted like a nil pointer
+  int64_t OriginalSize = 0, NewSize = 0, EstimatedSize = 0;
   bool IsWebRipLike = false;
+  std::string SourceCodec, Resolution, FrameRate, Container, VideoCodec;
+  int BitDepth = 0, AudioStreams = 0, SubStreams = 0;
 };
+// jobs.SaveJob (jobs.go:61-79): <dir>/<id>.json, two-space indent, field names and omitempty rules of the struct tags
+void SaveJob(const Job &j, const std::string &jobsDir);
+std::string JobToJSON(const Job &j);
+// RFC 3339 UTC timestamp of now
+std::string NowRFC3339();
+
+// AMD replacement of the reference's Intel-only GPU utilisation probe (internal/tui/gpu.go:16 getGPUUsage reads i915's
+// rps_act_freq_mhz / rps_max_freq_mhz): amdgpu exposes the busy percentage directly in sysfs,
+// /sys/class/drm/card<N>/device/gpu_busy_percent.  Returns 0..100, or -1 when no amdgpu card exposes it.
+// `sysfs_root` is "/sys" outside tests.
+double GetGPUUsage(int device = 0, const std::string &sysfs_root = "/sys");
 struct TranscodeConfig {           // daemon.go:185-188; Device is this backend's addition (which GPU runs the job)
   std::string JobStateDir; double MaxSizeRatio = 0.90; int StableWaitSeconds = 10; int Device = 0;
   // The reference renames its output over the source (daemon.go:154): there the output carries the copied audio and

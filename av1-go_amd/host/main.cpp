@@ -10,6 +10,10 @@
 using namespace av1mi_host;
 
 int main(int argc, char **argv) {
+  if (argc >= 2 && !strcmp(argv[1], "--gpu-usage")) {     // the AMD twin of internal/tui/gpu.go getGPUUsage
+    printf("%.1f\n", GetGPUUsage(argc >= 3 ? atoi(argv[2]) : 0));
+    return 0;
+  }
   if (argc >= 3 && !strcmp(argv[1], "--job")) {
     Job job; job.ID = "cli"; job.SourcePath = argv[2];
     TranscodeConfig cfg; cfg.StableWaitSeconds = 0;

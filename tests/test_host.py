@@ -296,3 +296,32 @@ def test_containers_carry_the_temporal_units_unchanged(host, tmp_path, O):
     if D.available():
         dec = D.decode(rebuilt)
         assert all((dec[t][i] == refs[t][i]).all() for t in range(n) for i in range(3))
+
+
+def test_job_record_has_the_reference_fields_and_escapes_strings(host):
+    """jobs.Job JSON (jobs.go:25-46): field names, omitempty, two-space indent; strings escaped (paths with quotes broke it)"""
+    import json
+    buf = C.create_string_buffer(4096)
+    host.av1mi_host_job_json.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_longlong, C.c_longlong, C.c_char_p, C.c_int]
+    host.av1mi_host_job_json(b"abc", b'/m/we "quoted"\\dir/a\tb.mkv', b"failed", b'ffmpeg exit code 1: x\ny', 1000, 0, buf, 4096)
+    text = buf.value.decode()
+    j = json.loads(text)
+    assert j == {"id": "abc", "source_path": '/m/we "quoted"\\dir/a\tb.mkv', "created_at": "2026-01-02T03:04:05Z", "status": "failed",
+                 "reason": "ffmpeg exit code 1: x\ny", "original_bytes": 1000, "is_webrip_like": False}
+    assert text.startswith('{\n  "id": "abc",\n  "source_path": ') and list(j) == ["id", "source_path", "created_at", "status", "reason", "original_bytes",
+                                                                                  "is_webrip_like"]
+
+
+def test_amd_gpu_usage_probe(host, tmp_path):
+    """the AMD twin of internal/tui/gpu.go getGPUUsage: amdgpu's gpu_busy_percent of the device-th card that has one"""
+    host.av1mi_host_gpu_usage.restype = C.c_double
+    host.av1mi_host_gpu_usage.argtypes = [C.c_int, C.c_char_p]
+    assert host.av1mi_host_gpu_usage(0, str(tmp_path).encode()) == -1.0          # no card: "cannot determine"
+    for card, val in ((0, None), (1, "37\n"), (3, "100\n")):                      # card0 = a display adapter without the file
+        d = tmp_path / "class" / "drm" / ("card%d" % card) / "device"
+        d.mkdir(parents=True)
+        if val:
+            (d / "gpu_busy_percent").write_text(val)
+    assert host.av1mi_host_gpu_usage(0, str(tmp_path).encode()) == 37.0
+    assert host.av1mi_host_gpu_usage(1, str(tmp_path).encode()) == 100.0
+    assert host.av1mi_host_gpu_usage(2, str(tmp_path).encode()) == -1.0
