@@ -3,14 +3,17 @@
 // cores sustains ~100 4K frames/s while the block pipeline produces 4 900 — so the same syntax also runs here, and what crosses
 // PCIe is the coded tile payloads (0.7 MB per 4K frame) instead of 25 MB of int16 levels.
 //
-// The syntax is av1_ops.hpp (shared source with the host's CPU twin, byte-identical to the dav1d-verified writer):
+// The syntax is av1_ops.hpp (shared source with the host's CPU twin, byte-identical to the dav1d-verified writer), in three stages:
 //   k_av1_info     thread per block: level-context summary of the block + (inter) the mode that codes its vector
-//   k_av1_tokens   workgroup per tile, thread per block in z-order: the block's ops, counted, scanned, written
-//   k_av1_code     ONE LANE PER TILE: the serial range coder over the tile's op list, the tile's CDFs in LDS
+//   k_av1_tokens   workgroup per tile, thread per block in z-order: the block's syntax elements, counted, placed, written —
+//                  literals into the tile's list, adaptive symbols as entries grouped by CDF slot
+//   k_av1_chains   a slot's CDF evolves with that slot's symbols only: one lane per (tile, slot) walks the slot's entries with the
+//                  CDF in registers and writes, at each element's place in the list, the tuple (icdf[s - 1], icdf[s], n - s) the
+//                  range coder needs.  The serial dependency of a tile drops from all its symbols (4000-8000) to its longest
+//                  chain (700-1300), and the chains of ALL tiles run side by side
+//   k_av1_code     ONE LANE PER TILE: the serial range coder over the finished list.  No CDFs: its state is five registers.
 //   k_av1_scan / k_av1_gather   tile payloads -> one contiguous buffer in tile order (the host adds the frame header and the
 //                  tile-size fields: they depend on the largest tile, host/av1_bitstream.cpp frame_obu_from_tiles)
-// The coder is a latency-bound dependent chain per lane (a wave = up to 32 tiles in lockstep); it is meant to run BESIDE the
-// block pipeline of the next frame (GOP session, side stream), not to be fast alone.
 #include <string.h>
 #include <vector>
 #include "av1_ops_cdfs.hpp"
@@ -23,7 +26,9 @@ struct Av1EntLaunch {
   FrameView fv;                 // pointers of frame 0; frame f adds f * per-frame strides
   int nframes, sbr_n, sbc_n;
   BlockInfo *info;              // nframes * blocks
-  op_t *ops; uint32_t ops_cap;  // per tile (32-bit ops)
+  op_t *ops; uint32_t ops_cap;  // per tile: the list (literal ops, tuples)
+  uint32_t *grouped; uint32_t grouped_cap;   // per tile: the entries of the adaptive symbols, grouped by slot
+  uint16_t *slot_total, *slot_base;          // per tile x S_MAX: entries of the slot, position of its first entry
   uint32_t *nops;               // per tile
   uint8_t *slots; uint32_t slot_cap;   // per tile payload slot
   uint32_t *tile_size;          // per tile: payload bytes (0 = overflow)
@@ -56,105 +61,186 @@ __global__ __launch_bounds__(256) void k_av1_info(Av1EntLaunch L) {
   L.info[nb * f + b] = o;
 }
 
+struct TokLds {
+  uint16_t M[S_MAX * kBlocksPerTile];
+  uint16_t total[S_MAX], base[S_MAX];
+  ScanTables scan;
+  alignas(16) uint8_t mag[kBlocksPerTile * kMagBytes];
+};
+
+// TOKENIZE: count, place, write.  Every read of a coefficient after the first goes to the thread's LDS copy of the block
+// (TokScratch); the counters of the grouping (M) are LDS too.
 __global__ __launch_bounds__(64) void k_av1_tokens(Av1EntLaunch L) {
   const int tiles = L.sbr_n * L.sbc_n, t = blockIdx.x, f = t / tiles, tt = t - f * tiles, sbr = tt / L.sbc_n, sbc = tt - sbr * L.sbc_n;
   const FrameView v = frame_view(L, f);
-  const int zi = threadIdx.x;
-  __shared__ SlotTable s_tab;          // per-thread indexed lookups when the ops are written: from LDS, not from the kernel arguments
+  const int zi = threadIdx.x, nslots = v.key ? S_KEY_END : S_INTER_END;
+  __shared__ TokLds S;
   {
-    const uint32_t *src = reinterpret_cast<const uint32_t *>(&L.tab);
-    uint32_t *dst = reinterpret_cast<uint32_t *>(&s_tab);
-    for (int i = zi; i < (int)(sizeof(SlotTable) / 4); i += 64) dst[i] = src[i];
+    uint32_t *m = reinterpret_cast<uint32_t *>(S.M);
+    for (int i = zi; i < S_MAX * kBlocksPerTile / 2; i += 64) m[i] = 0;
+    if (zi == 0) fill_scan_tables(&S.scan);
   }
   __syncthreads();
-  Sink cnt = { nullptr, 0, &s_tab };
-  tok_block(v, cnt, sbr, sbc, zi);
-  // exclusive scan of the 64 counts (one wave)
+  const TokScratch ts = { S.mag + zi * kMagBytes, &S.scan };
+  Sink cnt = { nullptr, nullptr, S.M, zi, 0 };
+  tok_block(v, cnt, ts, sbr, sbc, zi);
   int x = cnt.n;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
     const int y = __shfl_up(x, d, 64);
     if (zi >= d) x += y;
   }
-  const int total = __shfl(x, 63, 64), off = x - cnt.n;
-  if (zi == 0) L.nops[t] = (uint32_t)total;
+  const int total = __shfl(x, 63, 64), first = x - cnt.n;
   if ((uint32_t)total > L.ops_cap) {
     if (zi == 0) { atomicOr(L.status, 1u); L.nops[t] = 0; }
+    for (int sl = zi; sl < S_MAX; sl += 64) L.slot_total[(size_t)t * S_MAX + sl] = 0;
     return;
   }
-  Sink w = { L.ops + (size_t)t * L.ops_cap + off, 0, &s_tab };
-  tok_block(v, w, sbr, sbc, zi);
+  if (zi == 0) L.nops[t] = (uint32_t)total;
+  __syncthreads();
+  // place: a slot's entries are contiguous, in block order; slots follow each other on 16-byte boundaries
+  for (int sl = zi; sl < nslots; sl += 64) {
+    int sum = 0;
+    for (int b = 0; b < kBlocksPerTile; b++) sum += S.M[sl * kBlocksPerTile + b];
+    S.total[sl] = (uint16_t)sum;
+  }
+  __syncthreads();
+  {
+    int mine = 0;       // thread zi places slots [4 zi, 4 zi + 4)
+    for (int k = 0; k < 4; k++) { const int sl = 4 * zi + k; if (sl < nslots) mine += (S.total[sl] + kListAlign - 1) & ~(kListAlign - 1); }
+    int inc = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int y = __shfl_up(inc, d, 64);
+      if (zi >= d) inc += y;
+    }
+    int run = inc - mine;
+    for (int k = 0; k < 4; k++) { const int sl = 4 * zi + k; if (sl < nslots) { S.base[sl] = (uint16_t)run; run += (S.total[sl] + kListAlign - 1) & ~(kListAlign - 1); } }
+  }
+  __syncthreads();
+  for (int sl = zi; sl < S_MAX; sl += 64) {
+    const bool on = sl < nslots;
+    if (on) group_positions(&S.M[sl * kBlocksPerTile], S.base[sl]);
+    L.slot_total[(size_t)t * S_MAX + sl] = on ? S.total[sl] : (uint16_t)0;
+    L.slot_base[(size_t)t * S_MAX + sl] = on ? S.base[sl] : (uint16_t)0;
+  }
+  __syncthreads();
+  // write: literals into the list, adaptive symbols into their slot's entries
+  Sink w = { L.ops + (size_t)t * L.ops_cap, L.grouped + (size_t)t * L.grouped_cap, S.M, zi, first };
+  tok_block(v, w, ts, sbr, sbc, zi);
 }
 
-// blockDim.x lanes (tiles) per workgroup, chosen so that their CDF copies fit 64 KB of LDS (16 for key frames, 32 for inter
-// frames); each lane's CDF storage is `stride` uint16 apart in dynamic LDS
-__global__ __launch_bounds__(32) void k_av1_code(Av1EntLaunch L, int ntiles_all, int stride) {
-  const int LPW = (int)blockDim.x;
-  extern __shared__ uint16_t s_cdf[];
-  const int lane = threadIdx.x, t = blockIdx.x * LPW + lane;
+// CHAINS: workgroup = one CDF slot of 64 consecutive tiles, one lane per tile.  The slot is the same for the whole wave (no
+// divergence between alphabet sizes) and its chains are about equally long in neighbouring tiles, so the lanes stay busy — a
+// tile's own slots differ in length by three orders of magnitude.  Small alphabets keep the CDF in registers, large ones in LDS.
+__global__ __launch_bounds__(64) void k_av1_chains(Av1EntLaunch L, int ntiles_all, int ngroups) {
+  // workgroups are dealt to the eight XCDs in turn (id % 8), each with its own L2: all slots of a tile group go to ONE XCD, one
+  // after the other, so the 64 lists the group's chains complete word by word stay in that L2 until they are whole
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, nslots = L.fv.key ? S_KEY_END : S_INTER_END;
+  const int g = (j / nslots) * 8 + xcd, sl = j - (j / nslots) * nslots, lane = threadIdx.x, t = g * 64 + lane;
+  if (g >= ngroups) return;
+  __shared__ __attribute__((aligned(16))) uint16_t s_big[64 * 16];
+  const int n = L.tab.nsym[sl], off = L.tab.off[sl];
+  int cnt = 0, base = 0;
+  if (t < ntiles_all) { cnt = L.slot_total[(size_t)t * S_MAX + sl]; base = L.slot_base[(size_t)t * S_MAX + sl]; }
+  if (!__any(cnt > 0)) return;
+  const size_t tt = t < ntiles_all ? (size_t)t : 0;
+  op_t *list = L.ops + tt * L.ops_cap;
+  const uint32_t *grouped = L.grouped + tt * L.grouped_cap + base;
+  if (n <= 4) {
+    const uint32_t *iw = reinterpret_cast<const uint32_t *>(L.cdf_image) + (off >> 1);
+    uint64_t cdf = (uint64_t)iw[0] | ((uint64_t)iw[1] << 32);
+    const uint4 *g4 = reinterpret_cast<const uint4 *>(grouped);
+    uint4 cur = cnt > 0 ? g4[0] : make_uint4(0, 0, 0, 0);
+    for (int e = 0; e < cnt; e += 4) {
+      const uint4 nxt = e + 4 < cnt ? g4[(e >> 2) + 1] : make_uint4(0, 0, 0, 0);
+      list[cur.x >> 4] = small_step(cdf, (int)(cur.x & 15), n);
+      if (e + 1 < cnt) list[cur.y >> 4] = small_step(cdf, (int)(cur.y & 15), n);
+      if (e + 2 < cnt) list[cur.z >> 4] = small_step(cdf, (int)(cur.z & 15), n);
+      if (e + 3 < cnt) list[cur.w >> 4] = small_step(cdf, (int)(cur.w & 15), n);
+      cur = nxt;
+    }
+  } else {
+    uint16_t *cdf = s_big + lane * 16;
+    {
+      const uint4 *iw = reinterpret_cast<const uint4 *>(L.cdf_image + off);
+      uint4 *d = reinterpret_cast<uint4 *>(cdf);
+      d[0] = iw[0];
+      d[1] = n > 8 ? iw[1] : make_uint4(0, 0, 0, 0);
+    }
+    for (int e = 0; e < cnt; e++) {
+      const uint32_t q = grouped[e];
+      const int s = (int)(q & 15);
+      list[q >> 4] = s >= kSplitHorz ? split_tuple(cdf, s) : big_step(cdf, s, n);
+    }
+  }
+}
+
+// 64 lanes (tiles) per workgroup; per lane in LDS a ring of 64 list words and the coder's byte stage (32 x 16 bits).
+//
+// The chain is serial and the lanes of a wave are at different places of different tiles: what counts is the latency of one step.
+//  * one interval update per step for every lane, whatever the word: a tuple, or one bit of a literal;
+//  * NO global memory in the steady state (a wait for memory on gfx9 waits for every outstanding vector-memory operation,
+//    stores included).  Words come from the LDS ring, bytes go to the LDS stage; both meet global memory in rare PHASES the whole
+//    wave takes together: 32 words per lane are requested into registers in one phase and written to the ring in the next (the
+//    loads have long landed), the stages are stored.  A phase is due when a lane has fewer than 16 words staged or a stage is full.
+constexpr int kRingOps = 64, kLaneWords = kRingOps * 2 + Coder::kStage + 8;     // uint16 per lane; + 8: the lanes start on different banks
+
+__global__ __launch_bounds__(64) void k_av1_code(Av1EntLaunch L, int ntiles_all) {
+  __shared__ __attribute__((aligned(16))) uint16_t s_lane[64 * kLaneWords];
+  const int lane = threadIdx.x, t = blockIdx.x * 64 + lane;
   const bool live = t < ntiles_all;
-  uint16_t *cdf = s_cdf + lane * stride;
-  for (int i = 0; i < L.cdf_words; i++) cdf[i] = L.cdf_image[i];     // init_symbol: the frame's default CDFs
+  uint32_t *ring = reinterpret_cast<uint32_t *>(s_lane + lane * kLaneWords);
   Coder c;
-  c.init(L.slots + (size_t)(live ? t : 0) * L.slot_cap, (int)L.slot_cap);
+  c.init(L.slots + (size_t)(live ? t : 0) * L.slot_cap, (int)L.slot_cap, s_lane + lane * kLaneWords + kRingOps * 2);
   const int n = live ? (int)L.nops[t] : 0;
-  // ONE interval update per loop iteration for every lane, whatever the op: an adaptive symbol, or one bit of a literal (a
-  // literal of k bits takes k iterations).  The lanes of a wave code different tiles and meet different ops at every step; with
-  // "symbol" and "literal" as separate paths the wave executed both, literal loop included, at almost every step (measured:
-  // 4 us per op).  Here the paths differ only in where (fl, fh) come from and whether the CDF adapts.
-  // The op list is read four ops (one 16-byte load) at a time, the next chunk requested before the current one is coded.
   const uint4 *ops4 = reinterpret_cast<const uint4 *>(L.ops + (size_t)(live ? t : 0) * L.ops_cap);
-  uint4 cur = n > 0 ? ops4[0] : make_uint4(0, 0, 0, 0), nxt = n > 4 ? ops4[1] : make_uint4(0, 0, 0, 0);
+  // words [w - 64, w) are in the ring; `pend`: words [w, w + 32) are on their way into r0..r7
+  uint4 r0, r1, r2, r3, r4, r5, r6, r7;
+  r0 = r1 = r2 = r3 = r4 = r5 = r6 = r7 = make_uint4(0, 0, 0, 0);
+  int w = 0;
+  bool pend = false;
+  auto request = [&]() {
+    const uint4 *p = ops4 + (w >> 2);
+    if (w < n) r0 = p[0];
+    if (w + 4 < n) r1 = p[1];
+    if (w + 8 < n) r2 = p[2];
+    if (w + 12 < n) r3 = p[3];
+    if (w + 16 < n) r4 = p[4];
+    if (w + 20 < n) r5 = p[5];
+    if (w + 24 < n) r6 = p[6];
+    if (w + 28 < n) r7 = p[7];
+    pend = w < n;
+  };
+  auto take = [&]() {
+    uint4 *q = reinterpret_cast<uint4 *>(ring + (w & 32));
+    q[0] = r0; q[1] = r1; q[2] = r2; q[3] = r3; q[4] = r4; q[5] = r5; q[6] = r6; q[7] = r7;
+    w += 32;
+  };
+  request();
+  if (pend) { take(); request(); }
   int i = 0, lit_left = 0;
-  uint32_t lit_val = 0;
-  while (__any(lit_left > 0 || i < n)) {
-    if (!(lit_left > 0 || i < n)) continue;
-    uint32_t fl = 32768u, fh = 0;
-    int sym = 0, ns = 2;
-    uint16_t *v = nullptr;
-    if (lit_left == 0) {
-      const int k = i & 3;
-      const uint32_t op = k == 0 ? cur.x : k == 1 ? cur.y : k == 2 ? cur.z : cur.w;
-      i++;
-      if ((i & 3) == 0) { cur = nxt; if (i + 4 < n) nxt = ops4[(i >> 2) + 1]; }
-      if (op & 0x80000000u) {
-        const int nbits = (op >> 27) & 15;
-        if (nbits) { lit_left = nbits; lit_val = op & 0x7FFu; }
-        else {   // split_or_horz / split_or_vert: "split" with the probability gathered from the partition CDF as it stands
-          const uint16_t *p = cdf + (op & 0xFFF);
-          const uint32_t p1 = p[0] - p[1], p2 = p[1] - p[2], p3 = p[2] - p[3], p4 = p[3] - p[4], p5 = p[4] - p[5], p6 = p[5] - p[6], p7 = p[6] - p[7],
-                         p8 = p[7] - p[8], p9 = p[8];
-          fl = ((op >> 26) & 1) == 0 ? p2 + p3 + p4 + p6 + p7 + p9 : p1 + p3 + p4 + p5 + p6 + p8;
-          fh = 0; sym = 1; ns = 2;
-        }
-      } else {
-        sym = op & 15; ns = (op >> 4) & 31;
-        v = cdf + ((op >> 9) & 0xFFF);
-        fl = sym ? v[sym - 1] : 32768u;
-        fh = sym == ns - 1 ? 0u : v[sym];
-      }
+  uint32_t op = ring[0], op_next = ring[1];
+  for (;;) {
+    const bool has = lit_left > 0 || i < n;
+    if (!__any(has)) break;
+    if (__any((has && pend && w - i < 16) || c.stage_full())) {      // a phase
+      if (pend && w - i <= 32) { take(); request(); }
+      c.spill();
     }
-    if (lit_left > 0) {
-      lit_left--;
-      sym = (lit_val >> lit_left) & 1;
-      fl = sym ? 16384u : 32768u; fh = sym ? 0u : 16384u; ns = 2;
-    }
-    c.encode(fl, fh, sym, ns);
-    if (v) {   // adaptation (8.2.6): alphabets of up to four symbols (95 % of all) without a loop
-      const int count = v[ns - 1];
-      const int rate = 3 + (count > 15) + (count > 31) + (ns >= 4 ? 2 : 1);
-      if (ns <= 4) {
-#pragma unroll
-        for (int q = 0; q < 3; q++)
-          if (q < ns - 1) { const int x = v[q]; v[q] = (uint16_t)(q < sym ? x + ((32768 - x) >> rate) : x - (x >> rate)); }
-      } else {
-        for (int q = 0; q < ns - 1; q++) { const int x = v[q]; v[q] = (uint16_t)(q < sym ? x + ((32768 - x) >> rate) : x - (x >> rate)); }
+    if (has) {
+      uint32_t tup = op;
+      if (lit_left == 0 && (op >> 31)) lit_left = (int)((op >> 27) & 15);
+      if (lit_left > 0) {         // one equiprobable bit: the tuples of (icdf 16384 | 0, symbol 1 of 2) and (32768 | 16384, symbol 0 of 2)
+        lit_left--;
+        tup = (op >> lit_left) & 1 ? (1u << 19) | (256u << 9) : (2u << 19) | (512u << 9) | 256u;
       }
-      v[ns - 1] = (uint16_t)(count + (count < 32));
+      c.encode_tuple(tup);
+      if (lit_left == 0) { i++; op = op_next; op_next = ring[(i + 1) & (kRingOps - 1)]; }
     }
   }
   if (!live) return;
-  int sz = n ? c.finish() : -1;          // n == 0: the op list overflowed (k_av1_tokens), nothing to code
+  int sz = n ? c.finish() : -1;          // n == 0: the list overflowed (k_av1_tokens), nothing to code
   if (sz < 0) { if (n) atomicOr(L.status, 2u); sz = 0; }
   L.tile_size[t] = (uint32_t)sz;
 }
@@ -180,13 +266,23 @@ __global__ __launch_bounds__(1024) void k_av1_scan(Av1EntLaunch L, int ntiles_al
     if (part[1023] > L.out_cap) atomicOr(L.status, 4u);
   }
 }
+// one workgroup per tile; `out` may be pinned host memory (the GOP session hands the payloads straight to the host this way):
+// bytes up to the first 16-byte boundary of the destination, then aligned 16-byte stores, then the tail
 __global__ __launch_bounds__(64) void k_av1_gather(Av1EntLaunch L) {
   const int t = blockIdx.x;
   const uint32_t n = L.tile_size[t];
   const uint64_t off = L.tile_off[t];
   if (off + n > L.out_cap) return;
   const uint8_t *src = L.slots + (size_t)t * L.slot_cap;
-  for (uint32_t i = threadIdx.x; i < n; i += 64) L.out[off + i] = src[i];
+  uint8_t *dst = L.out + off;
+  const uint32_t head = min(n, (uint32_t)((16 - (reinterpret_cast<uintptr_t>(dst) & 15)) & 15)), body = (n - head) >> 4, tail0 = head + (body << 4);
+  if (threadIdx.x < head) dst[threadIdx.x] = src[threadIdx.x];
+  for (uint32_t i = threadIdx.x; i < body; i += 64) {
+    uint4 v;
+    __builtin_memcpy(&v, src + head + 16 * i, 16);       // the source is not aligned with the destination
+    *reinterpret_cast<uint4 *>(dst + head + 16 * i) = v;
+  }
+  if (tail0 + threadIdx.x < n) dst[tail0 + threadIdx.x] = src[tail0 + threadIdx.x];
 }
 
 hipError_t launch_av1_entropy(const Av1EntLaunch &L, hipStream_t s) {
@@ -195,11 +291,9 @@ hipError_t launch_av1_entropy(const Av1EntLaunch &L, hipStream_t s) {
   const int ntiles_all = L.sbr_n * L.sbc_n * L.nframes;
   hipLaunchKernelGGL(k_av1_info, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, L);
   hipLaunchKernelGGL(k_av1_tokens, dim3((unsigned)ntiles_all), dim3(64), 0, s, L);
-  const int stride = (((L.cdf_words + 1) / 2) | 1) * 2;     // an odd number of dwords: the lanes' copies of a slot fall on different banks
-  int LPW = 32;
-  while (LPW > 1 && (size_t)LPW * stride * sizeof(uint16_t) > 60 * 1024) LPW >>= 1;      // static + dynamic LDS stay below 64 KB per workgroup
-  const size_t lds = (size_t)LPW * stride * sizeof(uint16_t);
-  hipLaunchKernelGGL(k_av1_code, dim3((unsigned)((ntiles_all + LPW - 1) / LPW)), dim3(LPW), lds, s, L, ntiles_all, stride);
+  const int ngroups = (ntiles_all + 63) / 64, nslots = L.fv.key ? S_KEY_END : S_INTER_END;
+  hipLaunchKernelGGL(k_av1_chains, dim3((unsigned)(((ngroups + 7) / 8) * 8 * nslots)), dim3(64), 0, s, L, ntiles_all, ngroups);
+  hipLaunchKernelGGL(k_av1_code, dim3((unsigned)((ntiles_all + 63) / 64)), dim3(64), 0, s, L, ntiles_all);
   hipLaunchKernelGGL(k_av1_scan, dim3(1), dim3(1024), 0, s, L, ntiles_all);
   hipLaunchKernelGGL(k_av1_gather, dim3((unsigned)ntiles_all), dim3(64), 0, s, L);
   return hipGetLastError();
@@ -209,8 +303,8 @@ hipError_t launch_av1_entropy(const Av1EntLaunch &L, hipStream_t s) {
 
 // ------------------------------------------------------------------------------------------------ C ABI
 struct av1mi_av1ent_state {      // per-context scratch of the coder, grown on demand (owned through av1mi_av1_entropy_release)
-  void *info = nullptr, *ops = nullptr, *nops = nullptr, *slots = nullptr, *tile_off = nullptr, *status = nullptr;
-  size_t info_b = 0, ops_b = 0, nops_b = 0, slots_b = 0, off_b = 0;
+  void *info = nullptr, *ops = nullptr, *grouped = nullptr, *slot_tb = nullptr, *nops = nullptr, *slots = nullptr, *tile_off = nullptr, *status = nullptr;
+  size_t info_b = 0, ops_b = 0, grouped_b = 0, slot_tb_b = 0, nops_b = 0, slots_b = 0, off_b = 0;
   uint16_t *d_image[2][4] = {};   // [key][qcat] default CDF images
   int image_words[2] = { 0, 0 };
   av1ops::SlotTable tab[2];
@@ -269,12 +363,14 @@ int av1mi_av1_entropy_encode_on(av1mi_ctx *ctx, const av1mi_av1_entropy_job *j, 
   L.nframes = j->nframes; L.sbr_n = (L.fv.h8 + 7) / 8; L.sbc_n = (L.fv.w8 + 7) / 8;
   const size_t nb = (size_t)L.fv.w8 * L.fv.h8 * j->nframes, nt = (size_t)L.sbr_n * L.sbc_n * j->nframes;
   L.ops_cap = av1mi_av1_entropy_ops_per_tile(); L.slot_cap = av1mi_av1_entropy_slot_bytes();
+  L.grouped_cap = L.ops_cap + av1ops::kListAlign * av1ops::S_MAX;      // every slot's entries start on 16 bytes
   int rc;
   if ((rc = grow(ctx, &st->info, &st->info_b, nb * sizeof(av1ops::BlockInfo))) || (rc = grow(ctx, &st->ops, &st->ops_b, nt * L.ops_cap * sizeof(av1ops::op_t))) ||
-      (rc = grow(ctx, &st->nops, &st->nops_b, nt * 4)) || (rc = grow(ctx, &st->slots, &st->slots_b, nt * L.slot_cap)) ||
+      (rc = grow(ctx, &st->grouped, &st->grouped_b, nt * L.grouped_cap * sizeof(uint32_t))) ||
+      (rc = grow(ctx, &st->slot_tb, &st->slot_tb_b, nt * av1ops::S_MAX * 4)) || (rc = grow(ctx, &st->nops, &st->nops_b, nt * 4)) || (rc = grow(ctx, &st->slots, &st->slots_b, nt * L.slot_cap)) ||
       (rc = grow(ctx, &st->tile_off, &st->off_b, (nt + 1) * 8)))
     return rc;
-  L.info = (av1ops::BlockInfo *)st->info; L.ops = (av1ops::op_t *)st->ops; L.nops = (uint32_t *)st->nops; L.slots = (uint8_t *)st->slots;
+  L.info = (av1ops::BlockInfo *)st->info; L.ops = (av1ops::op_t *)st->ops; L.grouped = (uint32_t *)st->grouped; L.slot_total = (uint16_t *)st->slot_tb; L.slot_base = L.slot_total + nt * av1ops::S_MAX; L.nops = (uint32_t *)st->nops; L.slots = (uint8_t *)st->slots;
   L.tile_off = (uint64_t *)st->tile_off;
   L.tile_size = j->d_tile_size; L.out = j->d_out; L.out_cap = j->out_cap;
   L.status = (uint32_t *)(j->d_total + 1);
@@ -294,7 +390,7 @@ int av1mi_av1_entropy_encode(av1mi_ctx *ctx, const av1mi_av1_entropy_job *j) { r
 namespace av1mi {
 void av1ent_free(av1mi_av1ent_state *st) {
   if (!st) return;
-  for (void *p : { st->info, st->ops, st->nops, st->slots, st->tile_off }) if (p) (void)hipFree(p);
+  for (void *p : { st->info, st->ops, st->grouped, st->slot_tb, st->nops, st->slots, st->tile_off }) if (p) (void)hipFree(p);
   for (auto &k : st->d_image) for (uint16_t *p : k) if (p) (void)hipFree(p);
   delete st;
 }

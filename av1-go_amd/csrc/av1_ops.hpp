@@ -18,15 +18,21 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define AV1_HD __host__ __device__ inline
+#define AV1_UNROLL _Pragma("unroll")
 #else
 #define AV1_HD inline
+#define AV1_UNROLL
 #endif
 
 namespace av1ops {
 
+// uint16 / byte storage that is also read and written as 32- and 64-bit words
+typedef uint32_t __attribute__((may_alias)) u32a;
+typedef uint64_t __attribute__((may_alias)) u64a;
+
 // ------------------------------------------------------------------------------------------------ CDF slots of a tile
 // Every adaptive CDF a tile of this tool set can touch has a slot.  A slot stores the N - 1 inverse-CDF values (32768 - cdf)
-// followed by the adaptation counter, padded to a multiple of four uint16 (N <= 4: one 64-bit word).
+// then zeros, the adaptation counter in the slot's last entry (slot_words: 4, 8 or 16 uint16).
 enum Slot : int {
   S_SKIP = 0,                 // [3]
   S_PART8 = S_SKIP + 3,       // context 0 only (neighbours are 8x8 too)
@@ -95,34 +101,54 @@ AV1_HD int slot_nsym(int s, bool key) {
   }
   return 16;
 }
-AV1_HD int slot_words(int nsym) { return nsym; }      // uint16 entries of a slot: nsym - 1 values + the counter, no padding (LDS is the coder's scarce resource)
+// uint16 entries of a slot: N <= 4: four (ONE 64-bit word [v0 v1 v2 counter]: the coder's step is one LDS read and one LDS
+// write), N <= 8: eight, else sixteen (128-bit words); unused entries are 0, the counter is the LAST entry
+AV1_HD int slot_words(int nsym) { return nsym <= 4 ? 4 : nsym <= 8 ? 8 : 16; }
 
-// ------------------------------------------------------------------------------------------------ ops
-// 32-bit ops, RESOLVED by the tokenizer (the slot's storage offset and alphabet size travel in the op, so the serial coder has no
-// table lookup on its dependent chain):
-// symbol op:  0 | offset of the slot in uint16 (12 bits, << 9) | alphabet size (5 bits, << 4) | symbol (4 bits)
-// literal op: 1 | n (4 bits, 1..11, << 27) | value (11 bits)          n equiprobable bits, most significant first
-// split op:   1 | n = 0 | kind (bit 26: 0 = split_or_horz, 1 = split_or_vert) | offset of the partition slot (12 bits): the bit
-//             "split" coded with the probability gathered from the CURRENT partition CDF (frame edges, spec 9.3); no adaptation
+// ------------------------------------------------------------------------------------------------ ops, entries, tuples
+// A tile's syntax leaves the tokenizer in two forms (32-bit words):
+//   the tile's LIST, one word per syntax element in decoding order:
+//     literal op: 1 | n (4 bits, 1..11, << 27) | value (11 bits)      n equiprobable bits, most significant first
+//     (the words of the adaptive symbols are written later, by the chains, as tuples)
+//   GROUPED ENTRIES, one per adaptive symbol, grouped by CDF slot and, inside a slot, in decoding order:
+//     index of the element in the list (<< 4) | symbol (4 bits; in the partition slots 14 / 15 = the gathered bit
+//     split_or_horz / split_or_vert of a frame edge, spec 9.3, which reads the slot's CDF and does not adapt it)
+// What the range coder needs of an adaptive symbol is a TUPLE (the coder only ever uses icdf >> 6):
+//     0 | n - s (5 bits, << 19) | icdf[s - 1] >> 6 (10 bits, << 9; 512 for s = 0) | icdf[s] >> 6 (9 bits; 0 for s = n - 1)
+// A slot's CDF evolves with the symbols coded in THAT slot only, so a slot's entries are a chain that turns symbols into tuples
+// on its own, in parallel with every other slot of the tile; the serial range coder that follows touches no CDF at all.
 typedef uint32_t op_t;
 struct SlotTable { uint16_t off[S_MAX]; uint8_t nsym[(S_MAX + 3) & ~3]; int words; };     // a whole number of dwords
-AV1_HD op_t op_sym(int off, int nsym, int s) { return (op_t)(((unsigned)off << 9) | ((unsigned)nsym << 4) | (unsigned)s); }
 AV1_HD op_t op_lit(int n, unsigned v) { return (op_t)(0x80000000u | ((unsigned)n << 27) | (v & 0x7FFu)); }
-AV1_HD op_t op_split(int kind, int off) { return (op_t)(0x80000000u | ((unsigned)kind << 26) | (unsigned)off); }
+AV1_HD op_t make_tuple(uint32_t fl, uint32_t fh, int s, int n) { return (op_t)(((unsigned)(n - s) << 19) | ((fl >> 6) << 9) | (fh >> 6)); }
+enum { kBlocksPerTile = 64, kSplitHorz = 14, kSplitVert = 15, kListAlign = 4 };     // a slot's entries start on 16 bytes
 
-// where the ops of one block go: a counting pass (out == nullptr) and a writing pass share the code
+// Where the elements of one block go.  M[slot][block] (uint16, S_MAX x 64): in the counting pass (ops == nullptr) the number of
+// adaptive symbols the block codes in the slot; before the writing pass it is turned into the position of the block's first
+// entry of that slot in the tile's grouped entries (group_positions), so the writing pass scatters without any ordering step.
 struct Sink {
-  op_t *out;
-  int n;
-  const SlotTable *tab;
-  AV1_HD void put(op_t o) { if (out) out[n] = o; n++; }
-  AV1_HD void sym(int slot, int s) { if (out) out[n] = op_sym(tab->off[slot], tab->nsym[slot], s); n++; }
-  AV1_HD void split(int kind, int slot) { if (out) out[n] = op_split(kind, tab->off[slot]); n++; }
+  op_t *ops;
+  uint32_t *grouped;
+  uint16_t *M;
+  int zi, n;
+  AV1_HD void entry(int slot, int s) {
+    uint16_t &m = M[slot * kBlocksPerTile + zi];
+    if (ops) grouped[m] = ((uint32_t)n << 4) | (uint32_t)s;
+    m++; n++;
+  }
+  AV1_HD void sym(int slot, int s) { entry(slot, s); }
+  AV1_HD void split(int kind, int slot) { entry(slot, kind ? kSplitVert : kSplitHorz); }
   AV1_HD void lit(unsigned v, int nbits) {                // most significant bits first, at most 11 per op
-    while (nbits > 11) { nbits -= 11; put(op_lit(11, v >> nbits)); }
-    if (nbits > 0) put(op_lit(nbits, v & ((1u << nbits) - 1u)));
+    while (nbits > 11) { nbits -= 11; if (ops) ops[n] = op_lit(11, v >> nbits); n++; }
+    if (nbits > 0) { if (ops) ops[n] = op_lit(nbits, v & ((1u << nbits) - 1u)); n++; }
   }
 };
+// counts of ONE slot over the tile's 64 blocks -> running positions; returns the slot's number of entries
+AV1_HD int group_positions(uint16_t *m_slot, int base) {
+  int run = base;
+  for (int b = 0; b < kBlocksPerTile; b++) { const int c = m_slot[b]; m_slot[b] = (uint16_t)run; run += c; }
+  return run - base;
+}
 
 // ------------------------------------------------------------------------------------------------ frame view
 // what the tokenizer reads: the block pipeline's outputs of ONE frame (device or host pointers) + per-block summaries
@@ -318,15 +344,45 @@ AV1_HD void tok_partition_prefix(const FrameView &f, Sink &k, int sbr, int sbc, 
 }
 
 // coeffs (5.11.39) of an N x N block (N = 8 luma, 4 chroma)
-template <int N> AV1_HD void tok_coeffs(Sink &k, int plane, const int16_t *lev, int above_cul, int above_dc, int left_cul, int left_dc, bool key, int y_mode) {
-  const int nc = N * N, LG = N == 4 ? 2 : 3, MS = N + 4;
-  // Default_Scan_4x4 / Default_Scan_8x8 for row-major blocks: diagonals, odd ones walked downwards from the top row
-  static constexpr uint8_t kScan4[16] = { 0, 1, 4, 8, 5, 2, 3, 6, 9, 12, 13, 10, 7, 11, 14, 15 };
-  static constexpr uint8_t kScan8[64] = { 0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
-                                          35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63 };
-  const uint8_t *scan = N == 4 ? kScan4 : kScan8;
+// Default_Scan_4x4 / Default_Scan_8x8 for row-major blocks: diagonals, odd ones walked downwards from the top row
+struct ScanTables { uint8_t s4[16], s8[64]; };
+AV1_HD void fill_scan_tables(ScanTables *t) {
+  for (int N = 4; N <= 8; N += 4) {
+    uint8_t *o = N == 4 ? t->s4 : t->s8;
+    int k = 0;
+    for (int d = 0; d < 2 * N - 1; d++)
+      for (int i = 0; i <= d; i++) {
+        const int r = (d & 1) ? i : d - i, c = d - r;
+        if (r < N && c < N) o[k++] = (uint8_t)(r * N + c);
+      }
+  }
+}
+// what a thread needs beside the frame to tokenize coefficients: its own scratch (LDS on the GPU: the magnitudes are read five
+// at a time per coefficient) and the scan tables
+enum { kMagStride = 12, kMagBytes = 148 };      // (8 + 4)^2 = 144, + 4: an odd number of dwords per thread
+struct TokScratch { uint8_t *mag; const ScanTables *scan; };
+
+// coeffs() (5.11.39) of one transform block: `lev` = its N x N levels, row-major (16-byte aligned)
+template <int N> AV1_HD void tok_coeffs(Sink &k, const TokScratch &ts, int plane, const int16_t *lev, int above_cul, int above_dc, int left_cul, int left_dc, bool key,
+                                        int y_mode) {
+  const int nc = N * N, LG = N == 4 ? 2 : 3, MS = kMagStride;
+  const uint8_t *scan = N == 4 ? ts.scan->s4 : ts.scan->s8;
+  // min(|level|, 15) | sign << 7 of the whole block, zero-padded to the right and below: every later read is from this copy
+  // (the exact value of the rare levels above 14 is re-read from `lev`)
+  uint8_t *mag = ts.mag;
+  for (int i = 0; i < kMagBytes / 4; i++) reinterpret_cast<u32a *>(mag)[i] = 0;
+  bool any = false;
+  for (int r = 0; r < nc / 8; r++) {
+    struct alignas(16) L8 { int16_t v[8]; } q = *reinterpret_cast<const L8 *>(lev + 8 * r);
+    for (int j = 0; j < 8; j++) {
+      const int pos = 8 * r + j, v = q.v[j], a = iabs(v);
+      any |= v != 0;
+      mag[(pos >> LG) * MS + (pos & (N - 1))] = (uint8_t)((a > 15 ? 15 : a) | (v < 0 ? 128 : 0));
+    }
+  }
+  auto at = [&](int pos) { return mag[(pos >> LG) * MS + (pos & (N - 1))]; };
   int eob = 0;
-  for (int c = nc - 1; c >= 0; c--) if (lev[scan[c]]) { eob = c + 1; break; }
+  if (any) for (int c = nc - 1; c >= 0; c--) if (at(scan[c])) { eob = c + 1; break; }
   const bool chroma = plane > 0;
   const int skip_slot = chroma ? S_TXB_SKIP_C + ((above_cul | above_dc) != 0) + ((left_cul | left_dc) != 0) : S_TXB_SKIP_Y;
   k.sym(skip_slot, eob == 0);
@@ -343,28 +399,24 @@ template <int N> AV1_HD void tok_coeffs(Sink &k, int plane, const int16_t *lev, 
     k.sym((chroma ? S_EOBX_C : S_EOBX_Y) + eob_pt - 3, (off >> shift) & 1);
     if (shift > 0) k.lit((unsigned)(off & ((1 << shift) - 1)), shift);
   }
-  uint8_t mag[MS * MS];
-  for (int i = 0; i < MS * MS; i++) mag[i] = 0;
-  for (int c = 0; c < eob; c++) {
-    const int pos = scan[c], a = iabs(lev[pos]);
-    mag[(pos >> LG) * MS + (pos & (N - 1))] = (uint8_t)(a > 15 ? 15 : a);
-  }
   const int base_eob = chroma ? S_BASE_EOB_C : S_BASE_EOB_Y, base = chroma ? S_BASE_C : S_BASE_Y, br = chroma ? S_BR_C : S_BR_Y;
   for (int c = eob - 1; c >= 0; c--) {
     const int pos = scan[c], row = pos >> LG, col = pos & (N - 1);
     const uint8_t *m = mag + row * MS + col;
-    const int a = iabs(lev[pos]);
+    const int m0 = m[0] & 15, m1 = m[1] & 15, m2 = m[2] & 15, mb = m[MS] & 15, md = m[MS + 1] & 15, mbb = m[2 * MS] & 15;
+    int a = m0;
+    if (a == 15) a = iabs(lev[pos]);
     if (c == eob - 1) {
       k.sym(base_eob + (c == 0 ? 0 : c <= nc / 8 ? 1 : c <= nc / 4 ? 2 : 3), imin(a, 3) - 1);
     } else {
-      const int mm = imin(m[1], 3) + imin(m[MS], 3) + imin(m[MS + 1], 3) + imin(m[2], 3) + imin(m[2 * MS], 3);
+      const int mm = imin(m1, 3) + imin(mb, 3) + imin(md, 3) + imin(m2, 3) + imin(mbb, 3);
       int bctx = imin((mm + 1) >> 1, 4);
       if (pos == 0) bctx = 0;
       else bctx += row + col < 2 ? 1 : row + col < 4 ? 6 : 21;
       k.sym(base + bctx, imin(a, 3));
     }
     if (a > 2) {
-      int mm = m[1] + m[MS] + m[MS + 1];
+      int mm = m1 + mb + md;
       mm = imin((mm + 1) >> 1, 6);
       const int rctx = pos == 0 ? mm : (row < 2 && col < 2) ? mm + 7 : mm + 14;
       int rem = a - 3;
@@ -377,20 +429,23 @@ template <int N> AV1_HD void tok_coeffs(Sink &k, int plane, const int16_t *lev, 
     }
   }
   for (int c = 0; c < eob; c++) {
-    const int v = lev[scan[c]];
-    if (!v) continue;
-    const int a = iabs(v);
+    const int pos = scan[c], m = at(pos);
+    if (!m) continue;
+    const int neg = m >> 7;
     if (c == 0) {
       const int sg = (above_dc == 2) - (above_dc == 1) + (left_dc == 2) - (left_dc == 1);
-      k.sym((chroma ? S_DC_SIGN_C : S_DC_SIGN_Y) + (sg < 0 ? 1 : sg > 0 ? 2 : 0), v < 0);
+      k.sym((chroma ? S_DC_SIGN_C : S_DC_SIGN_Y) + (sg < 0 ? 1 : sg > 0 ? 2 : 0), neg);
     } else {
-      k.lit((unsigned)(v < 0), 1);
+      k.lit((unsigned)neg, 1);
     }
-    if (a > 14) {
-      const unsigned x = (unsigned)(a - 14);
-      const int len = ilog2(x) + 1;
-      k.lit(0, len - 1);
-      k.lit(x, len);
+    if ((m & 15) == 15) {
+      const int a = iabs(lev[pos]);
+      if (a > 14) {
+        const unsigned x = (unsigned)(a - 14);
+        const int len = ilog2(x) + 1;
+        k.lit(0, len - 1);
+        k.lit(x, len);
+      }
     }
   }
 }
@@ -411,7 +466,7 @@ AV1_HD void tok_mv_comp(Sink &k, int comp, int diff) {            // read_mv_com
 }
 
 // all ops of the block with z-order index `zi` of superblock (sbr, sbc); returns without ops for blocks outside the frame
-AV1_HD void tok_block(const FrameView &f, Sink &k, int sbr, int sbc, int zi) {
+AV1_HD void tok_block(const FrameView &f, Sink &k, const TokScratch &ts, int sbr, int sbc, int zi) {
   int bx, by;
   demorton8((unsigned)zi, &bx, &by);
   const int r8 = sbr * 8 + by, c8 = sbc * 8 + bx;
@@ -472,9 +527,9 @@ AV1_HD void tok_block(const FrameView &f, Sink &k, int sbr, int sbc, int zi) {
     }
   }
   if (skip) return;
-  tok_coeffs<8>(k, 0, f.lev_y + (long)b * 64, ia.cul[0], ia.dc[0], il.cul[0], il.dc[0], f.key != 0, ym);
-  tok_coeffs<4>(k, 1, f.lev_u + (long)b * 16, ia.cul[1], ia.dc[1], il.cul[1], il.dc[1], f.key != 0, ym);
-  tok_coeffs<4>(k, 2, f.lev_v + (long)b * 16, ia.cul[2], ia.dc[2], il.cul[2], il.dc[2], f.key != 0, ym);
+  tok_coeffs<8>(k, ts, 0, f.lev_y + (long)b * 64, ia.cul[0], ia.dc[0], il.cul[0], il.dc[0], f.key != 0, ym);
+  tok_coeffs<4>(k, ts, 1, f.lev_u + (long)b * 16, ia.cul[1], ia.dc[1], il.cul[1], il.dc[1], f.key != 0, ym);
+  tok_coeffs<4>(k, ts, 2, f.lev_v + (long)b * 16, ia.cul[2], ia.dc[2], il.cul[2], il.dc[2], f.key != 0, ym);
 }
 
 // ------------------------------------------------------------------------------------------------ op coder
@@ -484,55 +539,85 @@ AV1_HD void build_slot_table(bool key, SlotTable *t) {
   const int n = key ? S_KEY_END : S_INTER_END;
   int o = 0;
   for (int s = 0; s < S_MAX; s++) {
-    if (s < n) { t->nsym[s] = (uint8_t)slot_nsym(s, key); t->off[s] = (uint16_t)o; o += slot_words(t->nsym[s]); }
-    else { t->nsym[s] = 2; t->off[s] = 0; }
+    if (s < n) {
+      t->nsym[s] = (uint8_t)slot_nsym(s, key);
+      const int w = slot_words(t->nsym[s]), al = w < 8 ? 4 : 8;      // 64-bit words on 8 bytes, 128-bit words on 16
+      o = (o + al - 1) & ~(al - 1);
+      t->off[s] = (uint16_t)o;
+      o += w;
+    } else { t->nsym[s] = 2; t->off[s] = 0; }
   }
-  t->words = o;
+  t->words = (o + 7) & ~7;
 }
 
+// The range coder (spec 8.2 mirrored; the arithmetic of the host writer's RangeEnc, av1_bitstream.cpp), built so that its steady
+// state never waits for global memory (on gfx9 a wait for ANY outstanding vector-memory operation, stores included, is the only
+// wait there is: one store per step puts a memory round trip on every step of the serial chain):
+//  * bytes leave the window LAZILY: `low` keeps 16 + nb bits, sixteen of them are retired when nb reaches 32, so at least 16
+//    finished bits always stay behind in the register and a carry reaches bytes already retired only through sixteen 1 bits in
+//    a row (2^-16 per flush); the carry bit sits above the window (bit 16 + nb) until the next flush looks at it;
+//  * retired bits go to a small STAGE (32 x 16 bits; LDS on the GPU), not to the output: spill() stores the stage to `out`
+//    and is called by the loop that drives the coder — on the GPU in rare wave-uniform phases, all lanes at once.
+#ifdef AV1_CODER_STATS
+static long long coder_stat_carries = 0;
+#endif
 struct Coder {
+  enum { kStage = 32 };
   uint64_t low;
   uint32_t rng;
   int nb;
   uint8_t *out;
-  int pos, cap;
+  uint16_t *stage;         // kStage entries, most significant byte first as a NUMBER (swapped to memory order when spilled)
+  int pos, cap, ns;        // bytes in `out`, its capacity, entries staged
   bool overflow;
-  AV1_HD void init(uint8_t *o, int c) { low = 0; rng = 0x8000; nb = -1; out = o; pos = 0; cap = c; overflow = false; }
-  AV1_HD void carry_back() { for (int i = pos; i-- > 0;) if (++out[i] != 0) break; }
-  AV1_HD void renorm() {
-    const int d = 15 - ilog2(rng);
-    rng <<= d; low <<= d; nb += d;
-    while (nb >= 8) {
-      nb -= 8;
-      if (pos < cap) out[pos] = (uint8_t)(low >> (16 + nb)); else overflow = true;
-      pos++;
-      low &= ((uint64_t)1 << (16 + nb)) - 1;
-    }
+  AV1_HD void init(uint8_t *o, int c, uint16_t *st) { low = 0; rng = 0x8000; nb = -1; out = o; stage = st; pos = 0; cap = c; ns = 0; overflow = false; }
+  AV1_HD void carry_back() {        // + 1 on the bytes already retired: the staged ones first, then the stored ones
+    for (int k = ns; k-- > 0;) { const uint16_t v = (uint16_t)(stage[k] + 1); stage[k] = v; if (v) return; }
+    for (int i = pos; i-- > 0;) if (++out[i] != 0) return;
   }
+  AV1_HD bool stage_full() const { return ns >= kStage - 1; }
+  AV1_HD void spill() {
+    if (pos + 2 * ns > cap) { overflow = true; pos += 2 * ns; ns = 0; return; }
+    for (int k = 0; k < ns; k++) { const uint32_t v = stage[k]; *reinterpret_cast<uint16_t *>(out + pos + 2 * k) = (uint16_t)((v >> 8) | (v << 8)); }   // pos is even
+    pos += 2 * ns; ns = 0;
+  }
+  AV1_HD void flush16() {           // nb >= 32; the driver keeps ns < kStage (stage_full -> spill)
+    nb -= 16;
+    const uint32_t w = (uint32_t)(low >> (16 + nb));          // 16 bits + the carry above them
+    if ((w >> 16) && !overflow) {
+#ifdef AV1_CODER_STATS
+      coder_stat_carries++;          // host self-test builds only (host/coder_selftest.cpp)
+#endif
+      carry_back();
+    }
+    stage[ns++] = (uint16_t)w;
+    low &= ((uint64_t)1 << (16 + nb)) - 1;
+  }
+  // symbol s of an alphabet of n with inverse CDF values fl = icdf[s - 1] (32768 for s = 0), fh = icdf[s] (0 for s = n - 1)
   AV1_HD void encode(uint32_t fl, uint32_t fh, int s, int n) {
     const uint32_t r = rng, v = (((r >> 8) * (fh >> 6)) >> 1) + 4u * (uint32_t)(n - 1 - s);
-    if (fl < 32768u) {
-      const uint32_t u = (((r >> 8) * (fl >> 6)) >> 1) + 4u * (uint32_t)(n - s);
-      low += r - u; rng = u - v;
-    } else {
-      rng = r - v;
-    }
-    if (nb >= 0 && (low >> (16 + nb))) { if (!overflow) carry_back(); low &= ((uint64_t)1 << (16 + nb)) - 1; }
-    renorm();
+    const uint32_t u = fl < 32768u ? (((r >> 8) * (fl >> 6)) >> 1) + 4u * (uint32_t)(n - s) : r;
+    low += r - u;
+    const uint32_t nr = u - v;
+    const int d = 15 - ilog2(nr);
+    rng = nr << d; low <<= d; nb += d;
+    if (nb >= 32) flush16();
   }
-  AV1_HD void bit(int b) {
-    const uint32_t r = rng, v = ((r >> 8) << 7) + 4;
-    if (b) {
-      low += r - v; rng = v;
-      if (nb >= 0 && (low >> (16 + nb))) { if (!overflow) carry_back(); low &= ((uint64_t)1 << (16 + nb)) - 1; }
-    } else {
-      rng = r - v;
-    }
-    renorm();
+  AV1_HD void encode_tuple(op_t t) {      // make_tuple's fields: the same interval update
+    const uint32_t fl6 = (t >> 9) & 1023u, fh6 = t & 511u, dl = (t >> 19) & 31u;
+    const uint32_t r = rng, v = (((r >> 8) * fh6) >> 1) + 4u * (dl - 1u);
+    const uint32_t u = fl6 < 512u ? (((r >> 8) * fl6) >> 1) + 4u * dl : r;
+    low += r - u;
+    const uint32_t nr = u - v;
+    const int d = 15 - ilog2(nr);
+    rng = nr << d; low <<= d; nb += d;
+    if (nb >= 32) flush16();
   }
-  AV1_HD int finish() {
+  AV1_HD void bit(int b) { encode(b ? 16384u : 32768u, b ? 0u : 16384u, b, 2); }      // an equiprobable bit (literals)
+  AV1_HD int finish() {             // exit process (8.2.4)
     uint64_t e = ((low + 0x3FFF) & ~(uint64_t)0x3FFF) | 0x4000;
     if (nb >= 0 && (e >> (16 + nb))) { if (!overflow) carry_back(); e &= ((uint64_t)1 << (16 + nb)) - 1; }
+    spill();
     int top = 15 + nb;
     while (top >= 14) {
       uint8_t byte = 0;
@@ -544,32 +629,73 @@ struct Coder {
   }
 };
 
-// one op on a tile's CDF storage
-template <class CdfPtr> AV1_HD void code_op(Coder &c, CdfPtr cdf, op_t op) {
-  if (op & 0x80000000u) {
-    const int n = (op >> 27) & 15;
-    if (n) {
-      for (int i = n - 1; i >= 0; i--) c.bit((op >> i) & 1);
-    } else {
-      // split_or_horz / split_or_vert: "split" with the probability gathered from the partition CDF as it stands now
-      const int kind = (op >> 26) & 1;
-      const uint16_t *p = &cdf[op & 0xFFF];
-      auto prob = [&](int q) { return (uint32_t)((q ? p[q - 1] : 32768) - (q == 9 ? 0 : p[q])); };
-      const uint32_t psum = kind == 0 ? prob(2) + prob(3) + prob(4) + prob(6) + prob(7) + prob(9) : prob(1) + prob(3) + prob(4) + prob(5) + prob(6) + prob(8);
-      c.encode(psum, 0, 1, 2);
-    }
+// 8.2.6 on inverse values: x + ((32768 - x) >> rate) for the entries below the symbol, x - (x >> rate) for the others; written
+// without a branch (m = all ones below the symbol: 32768 - x = (x ^ m) + 32769, and the step changes sign with m)
+AV1_HD uint32_t adapt(uint32_t x, bool below, int rate) {
+  const uint32_t m = 0u - (uint32_t)below, d = ((x ^ m) + (m & 32769u)) >> rate;
+  return x - ((d ^ m) - m);
+}
+
+// one link of a chain: the tuple of symbol s, and the slot's CDF adapted (8.2.6).  Alphabets of at most four: the slot is one
+// 64-bit word [v0 v1 v2 counter] (a chain keeps it in registers)
+AV1_HD op_t small_step(uint64_t &w, int s, int n) {
+  const uint32_t x0 = (uint32_t)w & 0xFFFFu, x1 = (uint32_t)w >> 16, x2 = (uint32_t)(w >> 32) & 0xFFFFu, cnt = (uint32_t)(w >> 48);
+  const uint32_t fl = s == 0 ? 32768u : s == 1 ? x0 : s == 2 ? x1 : x2;
+  const uint32_t fh = s == n - 1 ? 0u : s == 0 ? x0 : s == 1 ? x1 : x2;
+  const int rate = 3 + (cnt > 15) + (cnt > 31) + (n >= 4 ? 2 : 1);
+  // unused entries are 0 and stay 0 (they are never "below" the symbol)
+  const uint32_t y0 = adapt(x0, 0 < s, rate), y1 = adapt(x1, 1 < s, rate), y2 = adapt(x2, 2 < s, rate), ncnt = cnt + (cnt < 32);
+  w = (uint64_t)(y0 | (y1 << 16)) | ((uint64_t)(y2 | (ncnt << 16)) << 32);
+  return make_tuple(fl, fh, s, n);
+}
+
+// alphabets of 5..16: a slot of 8 (n <= 8) or 16 entries in memory (LDS on the GPU), read and written as dwords
+AV1_HD op_t big_step(uint16_t *v, int s, int n) {
+  const int nd = n > 8 ? 8 : 4;
+  u32a *d = reinterpret_cast<u32a *>(v);
+  uint32_t w[8];
+  AV1_UNROLL
+  for (int k = 0; k < 8; k++) w[k] = k < nd ? d[k] : 0u;
+  const uint32_t fl = s ? v[s - 1] : 32768u, fh = s == n - 1 ? 0u : v[s];
+  const uint32_t cnt = (nd == 8 ? w[7] : w[3]) >> 16;
+  const int rate = 3 + (cnt > 15) + (cnt > 31) + 2;
+  AV1_UNROLL
+  for (int k = 0; k < 8; k++) {
+    if (k >= nd) continue;
+    uint32_t lo = adapt(w[k] & 0xFFFFu, 2 * k < s, rate), hi = adapt(w[k] >> 16, 2 * k + 1 < s, rate);
+    if (k == nd - 1) hi = cnt + (cnt < 32);
+    d[k] = lo | (hi << 16);
+  }
+  return make_tuple(fl, fh, s, n);
+}
+
+// split_or_horz / split_or_vert: "split" with the probability gathered from the partition CDF as it stands; no adaptation
+AV1_HD op_t split_tuple(const uint16_t *p, int kind) {
+  const uint32_t p1 = p[0] - p[1], p2 = p[1] - p[2], p3 = p[2] - p[3], p4 = p[3] - p[4], p5 = p[4] - p[5], p6 = p[5] - p[6], p7 = p[6] - p[7],
+                 p8 = p[7] - p[8], p9 = p[8];
+  return make_tuple(kind == kSplitHorz ? p2 + p3 + p4 + p6 + p7 + p9 : p1 + p3 + p4 + p5 + p6 + p8, 0, 1, 2);
+}
+
+// a whole chain, the plain way (the CPU twin; the GPU kernel runs the same steps with its own prefetching loops): `init` = the
+// slot's default CDF (slot_words(n) entries), `g` = the slot's `cnt` grouped entries, tuples go to list[index]
+AV1_HD void run_chain(const uint16_t *init, int n, const uint32_t *g, int cnt, op_t *list) {
+  if (n <= 4) {
+    uint64_t w = (uint64_t)init[0] | ((uint64_t)init[1] << 16) | ((uint64_t)init[2] << 32) | ((uint64_t)init[3] << 48);
+    for (int k = 0; k < cnt; k++) list[g[k] >> 4] = small_step(w, (int)(g[k] & 15), n);
     return;
   }
-  const int s = op & 15, n = (op >> 4) & 31;
-  auto *v = &cdf[(op >> 9) & 0xFFF];
-  c.encode(s ? v[s - 1] : 32768u, s == n - 1 ? 0u : v[s], s, n);
-  const int count = v[n - 1];
-  const int rate = 3 + (count > 15) + (count > 31) + (n >= 4 ? 2 : 1);
-  for (int i = 0; i < n - 1; i++) {
-    const int x = v[i];
-    v[i] = (uint16_t)(i < s ? x + ((32768 - x) >> rate) : x - (x >> rate));
+  alignas(16) uint16_t v[16];
+  for (int i = 0; i < 16; i++) v[i] = i < slot_words(n) ? init[i] : 0;
+  for (int k = 0; k < cnt; k++) {
+    const int s = (int)(g[k] & 15);
+    list[g[k] >> 4] = s >= kSplitHorz ? split_tuple(v, s) : big_step(v, s, n);
   }
-  v[n - 1] = (uint16_t)(count + (count < 32));
+}
+
+// one word of a tile's finished list through the range coder
+AV1_HD void code_word(Coder &c, op_t e) {
+  if (e >> 31) { for (int i = (int)((e >> 27) & 15) - 1; i >= 0; i--) { c.bit((e >> i) & 1); if (c.stage_full()) c.spill(); } }
+  else { c.encode_tuple(e); if (c.stage_full()) c.spill(); }
 }
 
 }  // namespace av1ops

@@ -51,8 +51,8 @@ struct Slot {
   hipEvent_t uploaded = nullptr, kernel_done = nullptr, downloaded = nullptr;
   bool upload_pending = false, kernel_pending = false;
   int frame_type = 0;
-  // GPU entropy coding (gpu_entropy != 0): coded tile payloads + sizes, device + pinned host mirror
-  void *d_ent_out = nullptr, *h_ent_out = nullptr, *d_tile_size = nullptr, *h_tile_size = nullptr, *d_total = nullptr, *h_total = nullptr;
+  // GPU entropy coding (gpu_entropy != 0): coded tile payloads (pinned host memory, written by the GPU) + sizes (device + pinned mirror)
+  void *h_ent_out = nullptr, *d_tile_size = nullptr, *h_tile_size = nullptr, *d_total = nullptr, *h_total = nullptr;
   hipEvent_t ent_done = nullptr;      // coder + download of sizes / total finished (side stream)
   bool ent_pending = false;
 };
@@ -63,7 +63,7 @@ struct av1mi_gop {
   av1mi_ctx *ctx = nullptr;
   av1mi_gop_config cfg{};
   size_t ny = 0, nc = 0, nb = 0, bps = 1;      // per BATCH (segments stacked): luma samples, chroma samples, blocks
-  hipStream_t up = nullptr, down = nullptr;
+  hipStream_t up = nullptr, down = nullptr;     // with the context's main and side streams: four, one hardware queue each
   Slot slot[2];
   void *d_rec[3] = {}, *d_dbl[3] = {}, *d_cdef[3] = {}, *d_ref[3] = {};
   void *d_mi[2][2] = {};                       // [key / inter][luma / chroma] deblocking mode-info maps (one frame, shared by the batch)
@@ -124,7 +124,7 @@ int setup(av1mi_gop *g) {
     if (c.gpu_entropy) {
       g->tiles = ((w + 63) / 64) * ((h + 63) / 64);
       g->ent_cap = (size_t)w * h * S;            // one byte per luma sample: several times what a frame codes to at any sane quantiser
-      G_TRY(dev_alloc(g, &s.d_ent_out, g->ent_cap)); G_TRY(host_alloc(g, &s.h_ent_out, g->ent_cap));
+      G_TRY(host_alloc(g, &s.h_ent_out, g->ent_cap));        // pinned and device-visible: the gather kernel writes it over PCIe
       G_TRY(dev_alloc(g, &s.d_tile_size, (size_t)g->tiles * S * 4)); G_TRY(host_alloc(g, &s.h_tile_size, (size_t)g->tiles * S * 4));
       G_TRY(dev_alloc(g, &s.d_total, 16)); G_TRY(host_alloc(g, &s.h_total, 16));
       G_HIP(hipEventCreateWithFlags(&s.ent_done, hipEventDisableTiming));
@@ -284,7 +284,7 @@ int av1mi_gop_submit(av1mi_gop *g, int frame_type) {
     ej.d_mvs = (const int16_t *)s.d_mv; ej.d_skip = (const uint8_t *)s.d_skip;
     ej.lr_on[0] = P.lr_unit_y[0] == 1; ej.lr_on[1] = ej.lr_on[2] = P.lr_unit_uv[0] == 1;
     memcpy(ej.lr_unit_y, P.lr_unit_y, 8); memcpy(ej.lr_unit_uv, P.lr_unit_uv, 8);
-    ej.d_out = (uint8_t *)s.d_ent_out; ej.out_cap = g->ent_cap; ej.d_tile_size = (uint32_t *)s.d_tile_size; ej.d_total = (uint64_t *)s.d_total;
+    ej.d_out = (uint8_t *)s.h_ent_out; ej.out_cap = g->ent_cap; ej.d_tile_size = (uint32_t *)s.d_tile_size; ej.d_total = (uint64_t *)s.d_total;
     G_TRY(av1mi_av1_entropy_encode_on(g->ctx, &ej, side));
     G_HIP(hipMemcpyAsync(s.h_tile_size, s.d_tile_size, (size_t)g->tiles * S * 4, hipMemcpyDeviceToHost, side));
     G_HIP(hipMemcpyAsync(s.h_total, s.d_total, 16, hipMemcpyDeviceToHost, side));
@@ -348,19 +348,19 @@ int av1mi_gop_collect(av1mi_gop *g, av1mi_gop_frame *out) {
   if (g->cfg.gpu_entropy) {
     G_HIP(hipEventSynchronize(s.ent_done));
     const uint64_t total = ((const uint64_t *)s.h_total)[0], status = ((const uint64_t *)s.h_total)[1];
-    hipStream_t side = av1mi::ctx_side_stream(g->ctx);
+    // the payloads are already here: k_av1_gather wrote them into the slot's pinned buffer (a copy enqueued NOW would queue
+    // behind the next batch's work, which is already submitted)
     if (status || total > g->ent_cap) {
       // A tile exceeded the coder's op-list / payload capacity (very fine quantisers on dense content).  The batch is not lost:
       // its symbols are still in the slot's device buffers (the next kernel that overwrites them is two submits away), so they
       // are downloaded now and handed out like in host mode: tile_size stays NULL, the caller entropy-codes this batch itself.
       if (g->cfg.gpu_entropy == 1) {
-        for (int p = 0; p < 3; p++) G_HIP(hipMemcpyAsync(s.h_lev[p], s.d_lev[p], (p ? g->nc : g->ny) * 2, hipMemcpyDeviceToHost, side));
-        G_HIP(hipStreamSynchronize(side));
+        for (int p = 0; p < 3; p++) G_HIP(hipMemcpyAsync(s.h_lev[p], s.d_lev[p], (p ? g->nc : g->ny) * 2, hipMemcpyDeviceToHost, g->down));
+        G_HIP(hipStreamSynchronize(g->down));
         out->lev_y = (const int16_t *)s.h_lev[0]; out->lev_u = (const int16_t *)s.h_lev[1]; out->lev_v = (const int16_t *)s.h_lev[2];
       }
       g->fallbacks++;
     } else {
-      if (total) { G_HIP(hipMemcpyAsync(s.h_ent_out, s.d_ent_out, total, hipMemcpyDeviceToHost, side)); G_HIP(hipStreamSynchronize(side)); }
       out->tiles_per_frame = g->tiles; out->tile_size = (const uint32_t *)s.h_tile_size; out->tile_payload = (const uint8_t *)s.h_ent_out; out->payload_bytes = total;
     }
   }

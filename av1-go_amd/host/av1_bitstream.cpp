@@ -1039,5 +1039,12 @@ bool temporal_unit(const av1mi_obu_frame &f, bool with_sequence_header, int thre
   return true;
 }
 
+std::vector<uint8_t> range_code_raw(const uint32_t *fl, const uint32_t *fh, const uint8_t *sym, const uint8_t *nsym, size_t count) {
+  RangeEnc ec;
+  for (size_t i = 0; i < count; i++) ec.encode(fl[i], fh[i], sym[i], nsym[i]);
+  ec.finish();
+  return ec.out;
+}
+
 }  // namespace av1
 }  // namespace av1mi_host

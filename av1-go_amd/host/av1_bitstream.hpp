@@ -44,6 +44,8 @@ bool frame_obu(const av1mi_obu_frame &f, int threads, std::vector<uint8_t> *out,
 bool frame_obu_from_tiles(const av1mi_obu_frame &f, const uint8_t *payloads, const uint32_t *sizes, int ntiles, std::vector<uint8_t> *out,
                           std::string *err);
 // the op-stream formulation of the tile syntax (csrc/av1_ops.hpp) run on the host: the GPU coder's CPU twin (av1_opstream.cpp)
+// the writer's range coder over a raw list of interval updates (tests: the op-stream coder's lazy byte output against this one)
+std::vector<uint8_t> range_code_raw(const uint32_t *fl, const uint32_t *fh, const uint8_t *sym, const uint8_t *nsym, size_t count);
 bool opstream_supported(const av1mi_obu_frame &f, std::string *why);
 bool opstream_tiles(const av1mi_obu_frame &f, std::vector<std::vector<uint8_t>> *tiles, std::string *err);
 // one temporal unit: delimiter [+ sequence header] + frame

@@ -1,7 +1,8 @@
-// av1_opstream.cpp — the CPU twin of the GPU tile entropy coder: the op-stream formulation of csrc/av1_ops.hpp (tokenize per
-// block with all contexts from neighbour data, then one serial coder pass per tile) run on the host, so that its logic is
-// checked byte for byte against the block-sequential writer of av1_bitstream.cpp on every machine, GPU or not
-// (tests/test_av1_opstream.py).  Also the reference the GPU kernels' output is compared with.
+// av1_opstream.cpp — the CPU twin of the GPU tile entropy coder: the three-stage formulation of csrc/av1_ops.hpp (tokenize per
+// block with all contexts from neighbour data; one adaptation chain per CDF slot; one serial range-coder pass per tile) run on
+// the host, so that its logic is checked byte for byte against the block-sequential writer of av1_bitstream.cpp on every
+// machine, GPU or not (tests/test_av1_opstream.py).  Also the reference the GPU kernels' output is compared with.
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -57,21 +58,49 @@ bool opstream_tiles(const av1mi_obu_frame &f, std::vector<std::vector<uint8_t>> 
   const std::vector<uint16_t> image = default_slot_image(v.key != 0, qcat, &tab);
   const int sbr_n = (v.h8 + 7) / 8, sbc_n = (v.w8 + 7) / 8;
   tiles->assign((size_t)sbr_n * sbc_n, {});
-  std::vector<op_t> ops;
-  std::vector<uint16_t> cdf;
+  const int nslots = v.key ? S_KEY_END : S_INTER_END;
+  std::vector<op_t> list;
+  std::vector<uint32_t> grouped;
+  std::vector<uint16_t> M((size_t)S_MAX * kBlocksPerTile);
+  ScanTables scan;
+  fill_scan_tables(&scan);
+  alignas(16) uint8_t mag[kMagBytes];
+  const TokScratch ts = { mag, &scan };
   for (int sbr = 0; sbr < sbr_n; sbr++)
     for (int sbc = 0; sbc < sbc_n; sbc++) {
-      Sink count = { nullptr, 0, &tab };
-      for (int zi = 0; zi < 64; zi++) tok_block(v, count, sbr, sbc, zi);
-      ops.resize((size_t)count.n);
-      Sink w = { ops.data(), 0, &tab };
-      for (int zi = 0; zi < 64; zi++) tok_block(v, w, sbr, sbc, zi);
-      cdf = image;
+      // stage 1, tokenize (the GPU: one thread per block): count, place, write
+      std::fill(M.begin(), M.end(), 0);
+      int first[kBlocksPerTile + 1];
+      first[0] = 0;
+      for (int zi = 0; zi < kBlocksPerTile; zi++) {
+        Sink count = { nullptr, nullptr, M.data(), zi, 0 };
+        tok_block(v, count, ts, sbr, sbc, zi);
+        first[zi + 1] = first[zi] + count.n;
+      }
+      const int nops = first[kBlocksPerTile];
+      int base[S_MAX], total[S_MAX], run = 0;
+      for (int sl = 0; sl < nslots; sl++) {
+        base[sl] = run;
+        total[sl] = group_positions(&M[(size_t)sl * kBlocksPerTile], run);
+        run = (run + total[sl] + kListAlign - 1) & ~(kListAlign - 1);
+      }
+      if (run > 65535) { if (err) *err = "tile too large for 16-bit entry positions"; return false; }
+      list.assign((size_t)nops, 0);
+      grouped.assign((size_t)run, 0);
+      for (int zi = 0; zi < kBlocksPerTile; zi++) {
+        Sink w = { list.data(), grouped.data(), M.data(), zi, first[zi] };
+        tok_block(v, w, ts, sbr, sbc, zi);
+      }
+      // stage 2, one chain per slot (the GPU: the tile's threads take the slots, longest first)
+      for (int sl = 0; sl < nslots; sl++)
+        if (total[sl]) run_chain(&image[tab.off[sl]], tab.nsym[sl], &grouped[(size_t)base[sl]], total[sl], list.data());
+      // stage 3, the serial range coder over the finished list (the GPU: one lane per tile)
       std::vector<uint8_t> &out = (*tiles)[(size_t)sbr * sbc_n + sbc];
-      out.resize((size_t)count.n * 2 + 64);       // a step adds at most 15 bits
+      out.resize((size_t)nops * 2 + 64);       // a step adds at most 15 bits
       Coder c;
-      c.init(out.data(), (int)out.size());
-      for (int i = 0; i < w.n; i++) code_op(c, cdf.data(), ops[(size_t)i]);
+      uint16_t stage[Coder::kStage];
+      c.init(out.data(), (int)out.size(), stage);
+      for (int i = 0; i < nops; i++) code_word(c, list[(size_t)i]);
       const int n = c.finish();
       if (n < 0) { if (err) *err = "tile payload overflow"; return false; }
       out.resize((size_t)n);

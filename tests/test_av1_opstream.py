@@ -78,3 +78,21 @@ def test_outside_the_tool_set_is_refused(O):
         av1stream.temporal_unit(w, h, 8, 100, opstream=True, angle_y=np.ones(nb, np.int8), **z)
     with pytest.raises(ValueError):
         av1stream.temporal_unit(w, h, 8, 100, opstream=True, reduced_tx_set=1, **z)
+
+
+def test_lazy_byte_output_equals_the_eager_coder_including_late_carries():
+    """The op-stream coder keeps sixteen finished bits back and stores two bytes at a time; a carry into bytes already stored
+    then needs sixteen 1 bits in a row.  Millions of random interval updates make that happen a few times: the bytes must
+    equal the host writer's coder (carry checked after every symbol) and the rare path must have run."""
+    import ctypes
+    import av1stream
+    L = av1stream.lib()
+    f = L.av1mi_host_coder_selftest
+    f.restype = ctypes.c_longlong
+    f.argtypes = [ctypes.c_uint64, ctypes.c_longlong, ctypes.POINTER(ctypes.c_longlong)]
+    total = 0
+    for seed in range(4):
+        c = ctypes.c_longlong(0)
+        assert f(seed, 2000000, ctypes.byref(c)) == 0, "seed %d" % seed
+        total += c.value
+    assert total >= 1

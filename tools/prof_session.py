@@ -18,22 +18,38 @@ ap.add_argument("--segs", type=int, default=8)
 ap.add_argument("--frames", type=int, default=10)
 ap.add_argument("--size", default="3840x2160")
 ap.add_argument("--bd", type=int, default=10)
+ap.add_argument("--verbose", action="store_true", help="per-iteration host timing of fill / submit / collect")
+ap.add_argument("--threads", type=int, default=16, help="host threads that fill the pinned input (like bench.py's end-to-end leg)")
 args = ap.parse_args()
 w, h = (int(x) for x in args.size.split("x"))
 Y, U, V = synth.frames(w, h, args.frames, args.bd, 3)
 ctx = av1mi.Context(0)
 s = av1mi.GopSession(ctx, w, h, args.bd, 128, 30, args.segs, gpu_entropy=args.gpu_entropy)
+from concurrent.futures import ThreadPoolExecutor
+pool = ThreadPoolExecutor(args.threads)
 t0 = time.perf_counter()
 for t in range(args.frames):
+    tf = time.perf_counter()
     planes = s.input_planes()
+    jobs = []
     for sg in range(args.segs):
-        planes[0][sg * h:(sg + 1) * h] = Y[t]
-        planes[1][sg * h // 2:(sg + 1) * h // 2] = U[t]
-        planes[2][sg * h // 2:(sg + 1) * h // 2] = V[t]
+        jobs.append(pool.submit(np.copyto, planes[0][sg * h:(sg + 1) * h], Y[t]))
+        jobs.append(pool.submit(np.copyto, planes[1][sg * h // 2:(sg + 1) * h // 2], U[t]))
+        jobs.append(pool.submit(np.copyto, planes[2][sg * h // 2:(sg + 1) * h // 2], V[t]))
+    for j in jobs:
+        j.result()
+    ta = time.perf_counter()
     s.submit()
+    tb = time.perf_counter()
     if t >= 1:
-        s.collect()
-s.collect()
+        fr = s.collect()
+    tc = time.perf_counter()
+    if args.verbose:
+        print("t %d fill %.2f submit %.2f collect %.2f ms" % (t, (ta - tf) * 1e3, (tb - ta) * 1e3, (tc - tb) * 1e3))
+fr = s.collect()
+if "tile_size" in fr:
+    ts = fr["tile_size"].astype(np.int64)
+    print("tile payload bytes (last batch): n %d mean %.0f p50 %.0f p90 %.0f p99 %.0f max %d" % (len(ts), ts.mean(), np.percentile(ts, 50), np.percentile(ts, 90), np.percentile(ts, 99), ts.max()))
 ctx.sync()
 dt = time.perf_counter() - t0
 print("%d frames in %.3f s = %.1f frames/s" % (args.frames * args.segs, dt, args.frames * args.segs / dt))
