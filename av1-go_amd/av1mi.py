@@ -139,6 +139,9 @@ class GopSession:
     def pending(self):
         return self.ctx.lib.av1mi_gop_pending(self.g)
 
+    def max_in_flight(self):
+        return self.ctx.lib.av1mi_gop_max_in_flight()
+
     def entropy_fallbacks(self):
         self.ctx.lib.av1mi_gop_entropy_fallbacks.restype = C.c_long
         return self.ctx.lib.av1mi_gop_entropy_fallbacks(self.g)
@@ -149,7 +152,7 @@ class GopSession:
         return f
 
     def collect(self):
-        """dict of numpy views (valid for one more submit) + params"""
+        """dict of numpy views (valid until the next submit) + params"""
         f = self.collect_raw()
         S, nb = f.segments, f.blocks_per_frame
         out = dict(params=f.params, frame_type=f.params.frame_type)

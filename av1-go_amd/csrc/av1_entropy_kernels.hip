@@ -54,8 +54,7 @@ __global__ __launch_bounds__(256) void k_av1_info(Av1EntLaunch L) {
   if (i >= nb * L.nframes) return;
   const int f = (int)(i / nb), b = (int)(i - (long)f * nb);
   const FrameView v = frame_view(L, f);
-  BlockInfo o;
-  o.mode = 0; o.flags = 0;
+  BlockInfo o = {};
   block_summary(v, b, &o);
   if (!v.key) inter_mode_decision(v, b / v.w8, b % v.w8, &o);
   L.info[nb * f + b] = o;
@@ -82,52 +81,56 @@ __global__ __launch_bounds__(64) void k_av1_tokens(Av1EntLaunch L) {
   }
   __syncthreads();
   const TokScratch ts = { S.mag + zi * kMagBytes, &S.scan };
-  Sink cnt = { nullptr, nullptr, S.M, zi, 0 };
-  tok_block(v, cnt, ts, sbr, sbc, zi);
-  int x = cnt.n;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const int y = __shfl_up(x, d, 64);
-    if (zi >= d) x += y;
-  }
-  const int total = __shfl(x, 63, 64), first = x - cnt.n;
-  if ((uint32_t)total > L.ops_cap) {
-    if (zi == 0) { atomicOr(L.status, 1u); L.nops[t] = 0; }
-    for (int sl = zi; sl < S_MAX; sl += 64) L.slot_total[(size_t)t * S_MAX + sl] = 0;
-    return;
-  }
-  if (zi == 0) L.nops[t] = (uint32_t)total;
-  __syncthreads();
-  // place: a slot's entries are contiguous, in block order; slots follow each other on 16-byte boundaries
-  for (int sl = zi; sl < nslots; sl += 64) {
-    int sum = 0;
-    for (int b = 0; b < kBlocksPerTile; b++) sum += S.M[sl * kBlocksPerTile + b];
-    S.total[sl] = (uint16_t)sum;
-  }
-  __syncthreads();
-  {
-    int mine = 0;       // thread zi places slots [4 zi, 4 zi + 4)
-    for (int k = 0; k < 4; k++) { const int sl = 4 * zi + k; if (sl < nslots) mine += (S.total[sl] + kListAlign - 1) & ~(kListAlign - 1); }
-    int inc = mine;
+  // two passes over the same code (kept as ONE copy: the tokenizer is most of this kernel's instructions): count, then write
+  Sink k = { nullptr, nullptr, S.M, zi, 0 };
+#pragma unroll 1
+  for (int pass = 0; pass < 2; pass++) {
+    tok_block(v, k, ts, sbr, sbc, zi);
+    if (pass) break;
+    int x = k.n;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
-      const int y = __shfl_up(inc, d, 64);
-      if (zi >= d) inc += y;
+      const int y = __shfl_up(x, d, 64);
+      if (zi >= d) x += y;
     }
-    int run = inc - mine;
-    for (int k = 0; k < 4; k++) { const int sl = 4 * zi + k; if (sl < nslots) { S.base[sl] = (uint16_t)run; run += (S.total[sl] + kListAlign - 1) & ~(kListAlign - 1); } }
+    const int total = __shfl(x, 63, 64), first = x - k.n;
+    if ((uint32_t)total > L.ops_cap) {
+      if (zi == 0) { atomicOr(L.status, 1u); L.nops[t] = 0; }
+      for (int sl = zi; sl < S_MAX; sl += 64) L.slot_total[(size_t)t * S_MAX + sl] = 0;
+      return;
+    }
+    if (zi == 0) L.nops[t] = (uint32_t)total;
+    __syncthreads();
+    // place: a slot's entries are contiguous, in block order; slots follow each other on 16-byte boundaries
+    for (int sl = zi; sl < nslots; sl += 64) {
+      int sum = 0;
+      for (int b = 0; b < kBlocksPerTile; b++) sum += S.M[sl * kBlocksPerTile + b];
+      S.total[sl] = (uint16_t)sum;
+    }
+    __syncthreads();
+    {
+      int mine = 0;       // thread zi places slots [4 zi, 4 zi + 4)
+      for (int q = 0; q < 4; q++) { const int sl = 4 * zi + q; if (sl < nslots) mine += (S.total[sl] + kListAlign - 1) & ~(kListAlign - 1); }
+      int inc = mine;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int y = __shfl_up(inc, d, 64);
+        if (zi >= d) inc += y;
+      }
+      int run = inc - mine;
+      for (int q = 0; q < 4; q++) { const int sl = 4 * zi + q; if (sl < nslots) { S.base[sl] = (uint16_t)run; run += (S.total[sl] + kListAlign - 1) & ~(kListAlign - 1); } }
+    }
+    __syncthreads();
+    for (int sl = zi; sl < S_MAX; sl += 64) {
+      const bool on = sl < nslots;
+      if (on) group_positions(&S.M[sl * kBlocksPerTile], S.base[sl]);
+      L.slot_total[(size_t)t * S_MAX + sl] = on ? S.total[sl] : (uint16_t)0;
+      L.slot_base[(size_t)t * S_MAX + sl] = on ? S.base[sl] : (uint16_t)0;
+    }
+    __syncthreads();
+    // the writing pass: literals into the list, adaptive symbols into their slot's entries
+    k.ops = L.ops + (size_t)t * L.ops_cap; k.grouped = L.grouped + (size_t)t * L.grouped_cap; k.n = first;
   }
-  __syncthreads();
-  for (int sl = zi; sl < S_MAX; sl += 64) {
-    const bool on = sl < nslots;
-    if (on) group_positions(&S.M[sl * kBlocksPerTile], S.base[sl]);
-    L.slot_total[(size_t)t * S_MAX + sl] = on ? S.total[sl] : (uint16_t)0;
-    L.slot_base[(size_t)t * S_MAX + sl] = on ? S.base[sl] : (uint16_t)0;
-  }
-  __syncthreads();
-  // write: literals into the list, adaptive symbols into their slot's entries
-  Sink w = { L.ops + (size_t)t * L.ops_cap, L.grouped + (size_t)t * L.grouped_cap, S.M, zi, first };
-  tok_block(v, w, ts, sbr, sbc, zi);
 }
 
 // CHAINS: workgroup = one CDF slot of 64 consecutive tiles, one lane per tile.  The slot is the same for the whole wave (no

@@ -19,9 +19,11 @@
 #include <hip/hip_runtime.h>
 #define AV1_HD __host__ __device__ inline
 #define AV1_UNROLL _Pragma("unroll")
+#define AV1_NOUNROLL _Pragma("unroll 1")
 #else
 #define AV1_HD inline
 #define AV1_UNROLL
+#define AV1_NOUNROLL
 #endif
 
 namespace av1ops {
@@ -152,9 +154,11 @@ AV1_HD int group_positions(uint16_t *m_slot, int base) {
 
 // ------------------------------------------------------------------------------------------------ frame view
 // what the tokenizer reads: the block pipeline's outputs of ONE frame (device or host pointers) + per-block summaries
-struct BlockInfo { uint8_t cul[3], dc[3], mode, flags; };    // cul = min(63, sum |level|), dc = 0 none / 1 negative / 2 positive per plane;
-                                                             // inter frames: mode = 0 NEAREST 1 NEAR 2 GLOBAL 3 NEW | ref index << 2,
-                                                             // flags bit 0 = coded with NEWMV
+// cul = min(63, sum |level|), dc = 0 none / 1 negative / 2 positive per plane.  Inter frames, from the block's MV prediction list
+// (inter_mode_decision; the list is built ONCE per block): mode = 0 NEAREST 1 NEAR 2 GLOBAL 3 NEW | ref index << 2, flags bit 0 =
+// coded with NEWMV, num = entries of the list, drl bit i = entry i has a nearest-class weight (>= 640), (px, py) = the entry a
+// NEWMV difference is coded against
+struct BlockInfo { uint8_t cul[3], dc[3], mode, flags; uint8_t num, drl; int16_t px, py; uint8_t pad[2]; };
 struct FrameView {
   int w8, h8;                   // frame size in 8x8 blocks
   int key;                      // 1 key frame, 0 inter frame
@@ -282,6 +286,12 @@ AV1_HD void inter_mode_decision(const FrameView &f, int r8, int c8, BlockInfo *o
   }
   o->mode = (uint8_t)(mode | (ref_idx << 2));
   o->flags = (uint8_t)(mode == 3);
+  o->num = (uint8_t)S.num;
+  int drl = 0;
+  for (int i = 0; i < 4; i++) if (i < imax(S.num, 2) && S.st[i].weight >= 640) drl |= 1 << i;
+  o->drl = (uint8_t)drl;
+  const int pred = S.num <= 1 ? 0 : ref_idx;
+  o->px = S.st[pred].x; o->py = S.st[pred].y;
 }
 
 // ------------------------------------------------------------------------------------------------ tokenizer
@@ -494,33 +504,39 @@ AV1_HD void tok_block(const FrameView &f, Sink &k, const TokScratch &ts, int sbr
     k.sym(S_SINGLE_REF + rctx * 3 + 0, 0);
     k.sym(S_SINGLE_REF + rctx * 3 + 1, 0);
     k.sym(S_SINGLE_REF + rctx * 3 + 2, 0);
-    MvStack S;
-    mv_stack(f, r8, c8, true, &S);
-    const int mode = f.info[b].mode & 3, ref_idx = f.info[b].mode >> 2;
+    // the prediction list was built by inter_mode_decision (info).  Its contexts: every candidate position above (left) of the
+    // block lies inside the tile exactly when the row above (column to the left) does, so "close" and "total" matches are the same
+    // count; the NEWMV neighbours are counted among above, left and above-right (7.10.2.7 with every block 8x8)
+    const BlockInfo me = f.info[b];
+    const int mode = me.mode & 3, ref_idx = me.mode >> 2, num = me.num;
     const int mx = f.mv[2 * b], my = f.mv[2 * b + 1];
-    k.sym(S_NEW_MV + S.new_ctx, mode != 3);
+    const int close = (au ? 1 : 0) + (al ? 1 : 0);
+    int num_new = (au ? ia.flags & 1 : 0) + (al ? il.flags & 1 : 0);
+    if (au && bx < 7 && c8 + 1 < f.w8 && morton8((unsigned)bx + 1, (unsigned)by - 1) < morton8((unsigned)bx, (unsigned)by)) num_new += f.info[b - f.w8 + 1].flags & 1;
+    const int new_ctx = close == 0 ? 0 : close == 1 ? 3 - imin(num_new, 1) : 5 - imin(num_new, 1);
+    const int ref_ctx = close == 0 ? 0 : close == 1 ? 3 : 5;
+    k.sym(S_NEW_MV + new_ctx, mode != 3);
     if (mode != 3) {
       k.sym(S_ZERO_MV, mode != 2);
-      if (mode != 2) k.sym(S_REF_MV + S.ref_ctx, mode == 1);
+      if (mode != 2) k.sym(S_REF_MV + ref_ctx, mode == 1);
     }
     auto drl_ctx = [&](int i) {
-      const bool a = S.st[i].weight >= 640, c = S.st[i + 1].weight >= 640;
+      const bool a = (me.drl >> i) & 1, c = (me.drl >> (i + 1)) & 1;
       return a && c ? 0 : a ? 1 : !c ? 2 : 0;
     };
     if (mode == 3) {
       for (int i = 0; i < 2; i++)
-        if (S.num > i + 1) {
+        if (num > i + 1) {
           k.sym(S_DRL + drl_ctx(i), ref_idx != i);
           if (ref_idx == i) break;
         }
-      const int pred = S.num <= 1 ? 0 : ref_idx;
-      const int dx = mx - S.st[pred].x, dy = my - S.st[pred].y;
+      const int dx = mx - me.px, dy = my - me.py;
       k.sym(S_MV_JOINT, (dx ? 1 : 0) + (dy ? 2 : 0));
       if (dy) tok_mv_comp(k, 0, dy);
       if (dx) tok_mv_comp(k, 1, dx);
     } else if (mode == 1) {
       for (int i = 1; i < 3; i++)
-        if (S.num > i + 1) {
+        if (num > i + 1) {
           k.sym(S_DRL + drl_ctx(i), ref_idx != i);
           if (ref_idx == i) break;
         }
@@ -528,8 +544,9 @@ AV1_HD void tok_block(const FrameView &f, Sink &k, const TokScratch &ts, int sbr
   }
   if (skip) return;
   tok_coeffs<8>(k, ts, 0, f.lev_y + (long)b * 64, ia.cul[0], ia.dc[0], il.cul[0], il.dc[0], f.key != 0, ym);
-  tok_coeffs<4>(k, ts, 1, f.lev_u + (long)b * 16, ia.cul[1], ia.dc[1], il.cul[1], il.dc[1], f.key != 0, ym);
-  tok_coeffs<4>(k, ts, 2, f.lev_v + (long)b * 16, ia.cul[2], ia.dc[2], il.cul[2], il.dc[2], f.key != 0, ym);
+  AV1_NOUNROLL
+  for (int p = 1; p < 3; p++)
+    tok_coeffs<4>(k, ts, p, (p == 1 ? f.lev_u : f.lev_v) + (long)b * 16, ia.cul[p], ia.dc[p], il.cul[p], il.dc[p], f.key != 0, ym);
 }
 
 // ------------------------------------------------------------------------------------------------ op coder

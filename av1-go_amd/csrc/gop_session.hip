@@ -7,8 +7,10 @@
 //   up:   wait slot.kernel_done (the kernel that last read this slot's source)  -> H2D of the three source planes -> uploaded
 //   main: wait uploaded -> k_intra_pipe | k_me_int + k_inter_pipe -> symbols_ready -> deblock x3, CDEF, LR x3 -> reference
 //   down: wait symbols_ready -> D2H of the symbols into pinned memory -> downloaded
-// Source and symbol buffers are double-buffered (slot = batch & 1), so batch t + 1 uploads while batch t computes and batch
-// t's symbols download while its filters run; the host codes batch t while the GPU works on t + 1.
+//   side: (GPU entropy coding) wait symbols_ready -> k_av1_* -> payloads gathered into the slot's pinned buffer -> ent_done
+// Source and symbol buffers exist kSlots = 3 times (slot = batch % 3): batch t + 2 uploads while batch t + 1 is in the block
+// pipeline and the coder works on batch t, whose predecessor the host is still reading.  Four streams, one hardware queue each
+// (a fifth would share a queue with one of these and serialise behind it).
 #include <stdio.h>
 #include <string.h>
 #include <new>
@@ -41,6 +43,8 @@ void frame_params(int q, int bd, int frame_type, av1mi_frame_params *p) {
   memcpy(p->lr_unit_y, wy, 8); memcpy(p->lr_unit_uv, wc, 8);
 }
 
+enum { kSlots = 3 };      // batches in flight: one uploading / in the block pipeline, one in the coder, one being read by the host
+
 struct Slot {
   void *h_src[3] = { nullptr, nullptr, nullptr };       // pinned
   void *d_src[3] = { nullptr, nullptr, nullptr };
@@ -64,7 +68,7 @@ struct av1mi_gop {
   av1mi_gop_config cfg{};
   size_t ny = 0, nc = 0, nb = 0, bps = 1;      // per BATCH (segments stacked): luma samples, chroma samples, blocks
   hipStream_t up = nullptr, down = nullptr;     // with the context's main and side streams: four, one hardware queue each
-  Slot slot[2];
+  Slot slot[kSlots];
   void *d_rec[3] = {}, *d_dbl[3] = {}, *d_cdef[3] = {}, *d_ref[3] = {};
   void *d_mi[2][2] = {};                       // [key / inter][luma / chroma] deblocking mode-info maps (one frame, shared by the batch)
   void *d_cdef_sb[2] = {}, *d_lr[2] = {}, *d_zero_skip = nullptr;
@@ -213,14 +217,15 @@ void av1mi_gop_close(av1mi_gop *g) {
   delete g;
 }
 
+int av1mi_gop_max_in_flight(void) { return kSlots; }
 int av1mi_gop_pending(av1mi_gop *g) { return g ? (int)(g->submitted - g->collected) : 0; }
 long av1mi_gop_entropy_fallbacks(av1mi_gop *g) { return g ? g->fallbacks : 0; }
 
 int av1mi_gop_acquire_input(av1mi_gop *g, void **y, void **u, void **v) {
   if (!g || !y || !u || !v) return AV1MI_E_INVAL;
-  if (g->submitted - g->collected >= 2) return av1mi::ctx_fail(g->ctx, AV1MI_E_INVAL, "two batches in flight: collect before acquiring the next input");
+  if (g->submitted - g->collected >= kSlots) return av1mi::ctx_fail(g->ctx, AV1MI_E_INVAL, "%d batches in flight: collect before acquiring the next input", (int)kSlots);
   G_HIP(hipSetDevice(av1mi::ctx_device(g->ctx)));
-  Slot &s = g->slot[g->submitted & 1];
+  Slot &s = g->slot[g->submitted % kSlots];
   if (s.upload_pending) { G_HIP(hipEventSynchronize(s.uploaded)); s.upload_pending = false; }   // the copy engine still reads these buffers
   *y = s.h_src[0]; *u = s.h_src[1]; *v = s.h_src[2];
   g->acquired = true;
@@ -230,14 +235,14 @@ int av1mi_gop_acquire_input(av1mi_gop *g, void **y, void **u, void **v) {
 int av1mi_gop_submit(av1mi_gop *g, int frame_type) {
   if (!g) return AV1MI_E_INVAL;
   if (!g->acquired) return av1mi::ctx_fail(g->ctx, AV1MI_E_INVAL, "submit without av1mi_gop_acquire_input");
-  if (g->submitted - g->collected >= 2) return av1mi::ctx_fail(g->ctx, AV1MI_E_INVAL, "two batches in flight: collect first");
+  if (g->submitted - g->collected >= kSlots) return av1mi::ctx_fail(g->ctx, AV1MI_E_INVAL, "%d batches in flight: collect first", (int)kSlots);
   if (frame_type < -1 || frame_type > 1) return av1mi::ctx_fail(g->ctx, AV1MI_E_INVAL, "frame_type %d", frame_type);
   if (frame_type < 0) frame_type = g->gop_pos == 0 ? 0 : 1;
   if (frame_type == 1 && g->submitted == 0) return av1mi::ctx_fail(g->ctx, AV1MI_E_INVAL, "the first frame of a session must be a key frame");
   G_HIP(hipSetDevice(av1mi::ctx_device(g->ctx)));
   const av1mi_gop_config &c = g->cfg;
   const int w = c.width, h = c.height, S = c.segments, bd = c.bit_depth;
-  Slot &s = g->slot[g->submitted & 1];
+  Slot &s = g->slot[g->submitted % kSlots];
   hipStream_t main = av1mi::ctx_stream(g->ctx);
   // upload: not before the kernel that last read this slot's source has finished
   if (s.kernel_pending) G_HIP(hipStreamWaitEvent(g->up, s.kernel_done, 0));
@@ -245,7 +250,7 @@ int av1mi_gop_submit(av1mi_gop *g, int frame_type) {
   G_HIP(hipEventRecord(s.uploaded, g->up));
   s.upload_pending = true;
   G_HIP(hipStreamWaitEvent(main, s.uploaded, 0));
-  if (s.ent_pending) G_HIP(hipStreamWaitEvent(main, s.ent_done, 0));      // the GPU coder of two batches ago still reads this slot's symbols
+  if (s.ent_pending) G_HIP(hipStreamWaitEvent(main, s.ent_done, 0));      // the GPU coder of the slot's previous batch still reads its symbols
   // the block pipeline (the symbols of this slot were downloaded before the slot was collected, so they may be overwritten)
   if (frame_type == 0) {
     av1mi_intra_job j;
@@ -323,7 +328,7 @@ int av1mi_gop_submit(av1mi_gop *g, int frame_type) {
     G_TRY(av1mi_lr_frames(g->ctx, g->d_cdef[p], g->d_dbl[p], g->d_ref[p], pw, pw, ph, bd, p > 0, P.lr_unit_size, (const int8_t *)g->d_lr[p > 0], 0, S));
   }
   if (frame_type == 1) {
-    // the skip flags are read by CDEF after symbols_ready: the slot's next inter kernel is two batches away and ordered behind
+    // the skip flags are read by CDEF after symbols_ready: the slot's next inter kernel is kSlots batches away and ordered behind
     // this CDEF on the main stream, nothing else writes them
   }
   g->submitted++;
@@ -336,7 +341,7 @@ int av1mi_gop_collect(av1mi_gop *g, av1mi_gop_frame *out) {
   if (!g || !out) return AV1MI_E_INVAL;
   if (g->submitted == g->collected) return av1mi::ctx_fail(g->ctx, AV1MI_E_INVAL, "nothing in flight");
   G_HIP(hipSetDevice(av1mi::ctx_device(g->ctx)));
-  Slot &s = g->slot[g->collected & 1];
+  Slot &s = g->slot[g->collected % kSlots];
   G_HIP(hipEventSynchronize(s.downloaded));
   memset(out, 0, sizeof(*out));
   out->params = g->params[s.frame_type];
@@ -352,7 +357,7 @@ int av1mi_gop_collect(av1mi_gop *g, av1mi_gop_frame *out) {
     // behind the next batch's work, which is already submitted)
     if (status || total > g->ent_cap) {
       // A tile exceeded the coder's op-list / payload capacity (very fine quantisers on dense content).  The batch is not lost:
-      // its symbols are still in the slot's device buffers (the next kernel that overwrites them is two submits away), so they
+      // its symbols are still in the slot's device buffers (the next kernel that overwrites them is kSlots submits away), so they
       // are downloaded now and handed out like in host mode: tile_size stays NULL, the caller entropy-codes this batch itself.
       if (g->cfg.gpu_entropy == 1) {
         for (int p = 0; p < 3; p++) G_HIP(hipMemcpyAsync(s.h_lev[p], s.d_lev[p], (p ? g->nc : g->ny) * 2, hipMemcpyDeviceToHost, g->down));

@@ -9,7 +9,7 @@
 // audio / subtitle copy (transcode.go:134-137) needs a demuxer and is not done.
 //
 // `segments` closed GOPs of the file are coded in lockstep (the session's batch dimension); while the host codes the
-// symbols of frame t the GPU already works on frame t + 1 (two batches in flight).
+// symbols of frame t the GPU already works on frames t + 1 and t + 2 (three batches in flight).
 #include "backend.hpp"
 #include <sys/stat.h>
 #include <cstdio>
@@ -118,6 +118,7 @@ int RunBackend(const BackendJob &job, std::string *err) {
     if (!sink.open(job.output, sp, y.fps_n, y.fps_d, err)) { code = 1; goto done; }
     std::vector<std::vector<std::vector<uint8_t>>> units((size_t)S);   // [segment][frame] temporal units of the batch in flight
     SessionFrameDesc desc;
+    const int lag = av1mi_gop_max_in_flight() - 1;      // batches the GPU holds while the host works on the oldest
     for (long g0 = 0; g0 < ngops; g0 += S) {
       for (auto &u : units) u.clear();
       // frames of this batch of GOPs that exist: segment s, position t -> file frame (g0 + s) * G + t
@@ -156,9 +157,10 @@ int RunBackend(const BackendJob &job, std::string *err) {
           }
         }
         CHK(av1mi_gop_submit(gop, t == 0 ? 0 : 1));
-        if (t >= 1 && !code_oldest(t - 1)) { code = 2; goto done; }    // the GPU works on frame t meanwhile
+        if (t >= lag && !code_oldest(t - lag)) { code = 2; goto done; }    // the GPU works on the frames after it meanwhile
       }
-      if (!code_oldest(T - 1)) { code = 2; goto done; }
+      for (int t = std::max(0, T - lag); t < T; t++)
+        if (!code_oldest(t)) { code = 2; goto done; }
       for (int s = 0; s < S; s++)
         for (size_t t = 0; t < units[(size_t)s].size(); t++)
           if (!sink.write(units[(size_t)s][t], t == 0, err)) { code = 1; goto done; }

@@ -272,8 +272,8 @@ def libaom_leg(planes, bd, qindex, our_bytes, our_rec_y, threads):
 def e2e_leg(ctx, W, H, bd, qindex, first_frame, segs=4, gop=30, steps=2, warmup_frames=2, gpu_entropy=0, compare_libaom=True):
     """END TO END: what the transcode job does per frame (reference: file in -> file out, internal/ffmpeg/transcode.go:194-203):
     source planes from host memory into the session's pinned buffers, H2D upload, block pipeline + in-loop filters on the GPU,
-    D2H of the symbols, AV1 entropy coding + OBU packing on all host cores (north_star keeps that stage on the host).  Two
-    batches in flight: the host codes frame t while the GPU works on frame t + 1.  Timed with the wall clock; the product is
+    D2H of the symbols, AV1 entropy coding + OBU packing on all host cores (north_star keeps that stage on the host).  Three
+    batches in flight: the host codes frame t while the GPU works on frames t + 1 and t + 2.  Timed with the wall clock; the product is
     a decodable AV1 stream (its first frames are decoded with dav1d, when present, and compared with the GPU's reference)."""
     from concurrent.futures import ThreadPoolExecutor
     import av1mi
@@ -316,13 +316,16 @@ def e2e_leg(ctx, W, H, bd, qindex, first_frame, segs=4, gop=30, steps=2, warmup_
         coded["t_wait"] += t1 - t0
         coded["t_code"] += time.perf_counter() - t1
 
+    lag = sess.max_in_flight() - 1       # batches the GPU holds while the host works on the oldest
+
     def run_gop(nframes, keep=None):
         for t in range(nframes):
             fill(t)
             sess.submit(0 if t == 0 else 1)
-            if t >= 1:
+            if t >= lag:
                 code(keep)
-        code(keep)
+        while sess.pending():
+            code(keep)
 
     run_gop(warmup_frames)
     for k in coded:

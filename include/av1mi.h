@@ -312,8 +312,9 @@ uint32_t av1mi_av1_entropy_slot_bytes(void);
  * (the context's stream) and the download of the frame's SYMBOLS (modes or vectors + skip flags + int16 levels; own copy
  * stream) into pinned host memory; av1mi_gop_collect() waits for the oldest submitted batch and hands those symbols out
  * together with the frame-header parameters the policy chose — exactly what the host bitstream writer
- * (av1-go_amd/host/av1_bitstream.hpp, entropy coding stays on the host cores) needs.  Two batches can be in flight:
- * submit(t + 1) before collect(t) overlaps PCIe traffic, kernels and the host's entropy coding. */
+ * (av1-go_amd/host/av1_bitstream.hpp, entropy coding stays on the host cores) needs.  av1mi_gop_max_in_flight() = 3 batches
+ * can be in flight: submit(t + 2) before collect(t) overlaps the upload of one batch, the kernels of the next, the GPU coder
+ * of the third and the host's work on what was collected. */
 typedef struct av1mi_gop_config {
   int width, height;     /* luma samples, multiples of 8 */
   int bit_depth;         /* 8 or 10 */
@@ -343,7 +344,7 @@ typedef struct av1mi_frame_params {
 int av1mi_policy_frame_params(int base_q_idx, int bit_depth, int frame_type, av1mi_frame_params *out);
 
 typedef struct av1mi_gop_frame {    /* one collected frame batch; host pointers into the session's pinned buffers, valid until
-                                       the next av1mi_gop_submit that reuses the slot (i.e. for one more submit) */
+                                       the next av1mi_gop_submit */
   av1mi_frame_params params;
   int segments;                     /* batch size */
   size_t blocks_per_frame;          /* (width / 8) * (height / 8); per-block arrays hold segments * blocks_per_frame entries */
@@ -366,11 +367,12 @@ void av1mi_gop_close(av1mi_gop *g);
  * Blocks until the upload that last used these buffers has finished. */
 int av1mi_gop_acquire_input(av1mi_gop *g, void **y, void **u, void **v);
 /* queue the batch in the acquired buffers.  frame_type: 0 key, 1 inter, -1 = by position in the GOP (gop_length).
- * AV1MI_E_INVAL when two batches are already in flight (collect first). */
+ * AV1MI_E_INVAL when av1mi_gop_max_in_flight() batches are already in flight (collect first). */
 int av1mi_gop_submit(av1mi_gop *g, int frame_type);
 /* wait for the oldest batch in flight and describe its symbols; AV1MI_E_INVAL when nothing is in flight */
 int av1mi_gop_collect(av1mi_gop *g, av1mi_gop_frame *out);
-/* number of batches in flight (0..2) */
+/* number of batches in flight (0..av1mi_gop_max_in_flight()) */
+int av1mi_gop_max_in_flight(void);
 int av1mi_gop_pending(av1mi_gop *g);
 /* gpu_entropy != 0: batches whose tiles exceeded the GPU coder's capacity so far.  Such a batch is handed out by
  * av1mi_gop_collect with tile_size == NULL and the symbols filled in instead (the caller entropy-codes it on the host). */

@@ -108,6 +108,14 @@ def test_session_api_misuse_is_reported(ctx, av1mi):
         s.input_planes()
         with pytest.raises(av1mi.Av1miError):
             s.submit(1)                     # a session starts with a key frame
+        for _ in range(s.max_in_flight()):  # the pipeline holds max_in_flight batches, not one more
+            s.input_planes()
+            s.submit()
+        assert s.pending() == s.max_in_flight() == 3
+        with pytest.raises(av1mi.Av1miError):
+            s.input_planes()
+        while s.pending():
+            s.collect()
     finally:
         s.close()
     with pytest.raises(av1mi.Av1miError):

@@ -41,12 +41,13 @@ for t in range(args.frames):
     ta = time.perf_counter()
     s.submit()
     tb = time.perf_counter()
-    if t >= 1:
+    if t >= s.max_in_flight() - 1:
         fr = s.collect()
     tc = time.perf_counter()
     if args.verbose:
         print("t %d fill %.2f submit %.2f collect %.2f ms" % (t, (ta - tf) * 1e3, (tb - ta) * 1e3, (tc - tb) * 1e3))
-fr = s.collect()
+while s.pending():
+    fr = s.collect()
 if "tile_size" in fr:
     ts = fr["tile_size"].astype(np.int64)
     print("tile payload bytes (last batch): n %d mean %.0f p50 %.0f p90 %.0f p99 %.0f max %d" % (len(ts), ts.mean(), np.percentile(ts, 50), np.percentile(ts, 90), np.percentile(ts, 99), ts.max()))
