@@ -162,9 +162,10 @@ class GopSession:
         if f.tile_size:
             out.update(tiles_per_frame=f.tiles_per_frame, tile_size=_view(f.tile_size, (S * f.tiles_per_frame,), np.uint32),
                        tile_payload=_view(f.tile_payload, (max(int(f.payload_bytes), 1),), np.uint8)[:int(f.payload_bytes)])
-        if f.params.frame_type == 0:
+        # (absent when the tiles were coded on the GPU, gpu_entropy = 1: the host then gets the payloads only)
+        if f.y_mode:
             out["y_mode"], out["uv_mode"] = _view(f.y_mode, (S, nb), np.uint8), _view(f.uv_mode, (S, nb), np.uint8)
-        else:
+        if f.mv:
             out["mv"], out["skip"] = _view(f.mv, (S, nb, 2), np.int16), _view(f.skip, (S, nb), np.uint8)
         return out
 

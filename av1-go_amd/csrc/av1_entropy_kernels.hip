@@ -29,6 +29,7 @@ struct Av1EntLaunch {
   op_t *ops; uint32_t ops_cap;  // per tile: the list (literal ops, tuples)
   uint32_t *grouped; uint32_t grouped_cap;   // per tile: the entries of the adaptive symbols, grouped by slot
   uint16_t *slot_total, *slot_base;          // per tile x S_MAX: entries of the slot, position of its first entry
+  uint16_t *rec;                             // per tile x 64 blocks x kBlockRecords: the tokenizer's records
   uint32_t *nops;               // per tile
   uint8_t *slots; uint32_t slot_cap;   // per tile payload slot
   uint32_t *tile_size;          // per tile: payload bytes (0 = overflow)
@@ -61,84 +62,108 @@ __global__ __launch_bounds__(256) void k_av1_info(Av1EntLaunch L) {
 }
 
 struct TokLds {
-  uint16_t M[S_MAX * kBlocksPerTile];
+  union {
+    struct { uint8_t cnt[S_MAX * kBlocksPerTile]; alignas(16) uint8_t mag[kBlocksPerTile * kMagBytes]; } p1;    // while tokenizing
+    uint16_t pos[S_MAX * kBlocksPerTile];                                                                      // while replaying
+  };
   uint16_t total[S_MAX], base[S_MAX];
   ScanTables scan;
-  alignas(16) uint8_t mag[kBlocksPerTile * kMagBytes];
 };
 
-// TOKENIZE: count, place, write.  Every read of a coefficient after the first goes to the thread's LDS copy of the block
-// (TokScratch); the counters of the grouping (M) are LDS too.
-__global__ __launch_bounds__(64) void k_av1_tokens(Av1EntLaunch L) {
+// TOKENIZE once (records + counts; every read of a coefficient after the first goes to the thread's LDS copy of the block),
+// PLACE (the counts of the tile's 64 blocks -> where each block's entries of each slot go), REPLAY (records -> list words and
+// grouped entries).  The counts are bytes and share their LDS with the 16-bit positions that replace them: a thread keeps the
+// counts of its slots in registers across the switch.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) void k_av1_tokens(Av1EntLaunch L) {
   const int tiles = L.sbr_n * L.sbc_n, t = blockIdx.x, f = t / tiles, tt = t - f * tiles, sbr = tt / L.sbc_n, sbc = tt - sbr * L.sbc_n;
   const FrameView v = frame_view(L, f);
   const int zi = threadIdx.x, nslots = v.key ? S_KEY_END : S_INTER_END;
   __shared__ TokLds S;
   {
-    uint32_t *m = reinterpret_cast<uint32_t *>(S.M);
-    for (int i = zi; i < S_MAX * kBlocksPerTile / 2; i += 64) m[i] = 0;
+    uint32_t *m = reinterpret_cast<uint32_t *>(S.p1.cnt);
+    for (int i = zi; i < S_MAX * kBlocksPerTile / 4; i += 64) m[i] = 0;
     if (zi == 0) fill_scan_tables(&S.scan);
   }
   __syncthreads();
-  const TokScratch ts = { S.mag + zi * kMagBytes, &S.scan };
-  // two passes over the same code (kept as ONE copy: the tokenizer is most of this kernel's instructions): count, then write
-  Sink k = { nullptr, nullptr, S.M, zi, 0 };
-#pragma unroll 1
-  for (int pass = 0; pass < 2; pass++) {
-    tok_block(v, k, ts, sbr, sbc, zi);
-    if (pass) break;
-    int x = k.n;
+  uint16_t *rec = L.rec + ((size_t)t * kBlocksPerTile + zi) * kBlockRecords;
+  const TokScratch ts = { S.p1.mag + zi * kMagBytes, &S.scan };
+  Sink k = { rec, S.p1.cnt, zi, 0, 0, false };
+  tok_block(v, k, ts, sbr, sbc, zi);
+  int x = k.n;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int y = __shfl_up(x, d, 64);
+    if (zi >= d) x += y;
+  }
+  const int total = __shfl(x, 63, 64), first = x - k.n;
+  if ((uint32_t)total > L.ops_cap || __any(k.overflow)) {
+    if (zi == 0) { atomicOr(L.status, 1u); L.nops[t] = 0; }
+    for (int sl = zi; sl < S_MAX; sl += 64) L.slot_total[(size_t)t * S_MAX + sl] = 0;
+    return;
+  }
+  if (zi == 0) L.nops[t] = (uint32_t)total;
+  __syncthreads();
+  // place: thread zi owns slots zi, zi + 64, ...: their counts into registers, their totals to everybody
+  constexpr int kOwn = (S_MAX + 63) / 64;
+  uint32_t c[kOwn][kBlocksPerTile / 4];
+#pragma unroll
+  for (int q = 0; q < kOwn; q++) {
+    const int sl = zi + 64 * q;
+    int sum = 0;
+#pragma unroll
+    for (int w = 0; w < kBlocksPerTile / 4; w++) {
+      const uint32_t u = sl < nslots ? reinterpret_cast<const uint32_t *>(S.p1.cnt)[sl * (kBlocksPerTile / 4) + w] : 0u;
+      c[q][w] = u;
+      sum += (int)((u & 0xFF) + ((u >> 8) & 0xFF) + ((u >> 16) & 0xFF) + (u >> 24));
+    }
+    if (sl < S_MAX) S.total[sl] = (uint16_t)sum;
+  }
+  __syncthreads();         // every count is in a register now: the positions may overwrite them
+  {
+    int mine = 0;       // thread zi places slots [4 zi, 4 zi + 4): slots follow each other on 16-byte boundaries
+    for (int q = 0; q < 4; q++) { const int sl = 4 * zi + q; if (sl < nslots) mine += (S.total[sl] + kListAlign - 1) & ~(kListAlign - 1); }
+    int inc = mine;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
-      const int y = __shfl_up(x, d, 64);
-      if (zi >= d) x += y;
+      const int y = __shfl_up(inc, d, 64);
+      if (zi >= d) inc += y;
     }
-    const int total = __shfl(x, 63, 64), first = x - k.n;
-    if ((uint32_t)total > L.ops_cap) {
-      if (zi == 0) { atomicOr(L.status, 1u); L.nops[t] = 0; }
-      for (int sl = zi; sl < S_MAX; sl += 64) L.slot_total[(size_t)t * S_MAX + sl] = 0;
-      return;
-    }
-    if (zi == 0) L.nops[t] = (uint32_t)total;
-    __syncthreads();
-    // place: a slot's entries are contiguous, in block order; slots follow each other on 16-byte boundaries
-    for (int sl = zi; sl < nslots; sl += 64) {
-      int sum = 0;
-      for (int b = 0; b < kBlocksPerTile; b++) sum += S.M[sl * kBlocksPerTile + b];
-      S.total[sl] = (uint16_t)sum;
-    }
-    __syncthreads();
-    {
-      int mine = 0;       // thread zi places slots [4 zi, 4 zi + 4)
-      for (int q = 0; q < 4; q++) { const int sl = 4 * zi + q; if (sl < nslots) mine += (S.total[sl] + kListAlign - 1) & ~(kListAlign - 1); }
-      int inc = mine;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const int y = __shfl_up(inc, d, 64);
-        if (zi >= d) inc += y;
-      }
-      int run = inc - mine;
-      for (int q = 0; q < 4; q++) { const int sl = 4 * zi + q; if (sl < nslots) { S.base[sl] = (uint16_t)run; run += (S.total[sl] + kListAlign - 1) & ~(kListAlign - 1); } }
-    }
-    __syncthreads();
-    for (int sl = zi; sl < S_MAX; sl += 64) {
-      const bool on = sl < nslots;
-      if (on) group_positions(&S.M[sl * kBlocksPerTile], S.base[sl]);
-      L.slot_total[(size_t)t * S_MAX + sl] = on ? S.total[sl] : (uint16_t)0;
-      L.slot_base[(size_t)t * S_MAX + sl] = on ? S.base[sl] : (uint16_t)0;
-    }
-    __syncthreads();
-    // the writing pass: literals into the list, adaptive symbols into their slot's entries
-    k.ops = L.ops + (size_t)t * L.ops_cap; k.grouped = L.grouped + (size_t)t * L.grouped_cap; k.n = first;
+    int run = inc - mine;
+    for (int q = 0; q < 4; q++) { const int sl = 4 * zi + q; if (sl < nslots) { S.base[sl] = (uint16_t)run; run += (S.total[sl] + kListAlign - 1) & ~(kListAlign - 1); } }
   }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < kOwn; q++) {
+    const int sl = zi + 64 * q;
+    if (sl >= S_MAX) continue;
+    const bool on = sl < nslots;
+    int run = on ? S.base[sl] : 0;
+    L.slot_total[(size_t)t * S_MAX + sl] = on ? S.total[sl] : (uint16_t)0;
+    L.slot_base[(size_t)t * S_MAX + sl] = (uint16_t)run;
+    if (!on) continue;
+#pragma unroll
+    for (int w = 0; w < kBlocksPerTile / 4; w++) {
+      const uint32_t u = c[q][w];
+      const int p0 = run, p1 = p0 + (int)(u & 0xFF), p2 = p1 + (int)((u >> 8) & 0xFF), p3 = p2 + (int)((u >> 16) & 0xFF);
+      run = p3 + (int)(u >> 24);
+      uint32_t *d = reinterpret_cast<uint32_t *>(S.pos + sl * kBlocksPerTile + 4 * w);
+      d[0] = (uint32_t)p0 | ((uint32_t)p1 << 16); d[1] = (uint32_t)p2 | ((uint32_t)p3 << 16);
+    }
+  }
+  __syncthreads();
+  __threadfence_block();
+  // replay: the thread's own records (it wrote them itself), literals into the list, adaptive symbols into their slot's entries
+  replay_block(rec, k.nrec, S.pos, zi, first, L.ops + (size_t)t * L.ops_cap, L.grouped + (size_t)t * L.grouped_cap);
 }
 
 // CHAINS: workgroup = one CDF slot of 64 consecutive tiles, one lane per tile.  The slot is the same for the whole wave (no
 // divergence between alphabet sizes) and its chains are about equally long in neighbouring tiles, so the lanes stay busy — a
 // tile's own slots differ in length by three orders of magnitude.  Small alphabets keep the CDF in registers, large ones in LDS.
+// (Measured: a workgroup that walks several slots one after the other is slower — fewer, longer waves; about half of this
+// kernel's time is the 4-byte scatter of the tuples into the lists.)
 __global__ __launch_bounds__(64) void k_av1_chains(Av1EntLaunch L, int ntiles_all, int ngroups) {
   // workgroups are dealt to the eight XCDs in turn (id % 8), each with its own L2: all slots of a tile group go to ONE XCD, one
-  // after the other, so the 64 lists the group's chains complete word by word stay in that L2 until they are whole
+  // after the other, so the 64 lists the group's chains complete word by word stay in that L2 as long as possible
   const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, nslots = L.fv.key ? S_KEY_END : S_INTER_END;
   const int g = (j / nslots) * 8 + xcd, sl = j - (j / nslots) * nslots, lane = threadIdx.x, t = g * 64 + lane;
   if (g >= ngroups) return;
@@ -153,15 +178,23 @@ __global__ __launch_bounds__(64) void k_av1_chains(Av1EntLaunch L, int ntiles_al
   if (n <= 4) {
     const uint32_t *iw = reinterpret_cast<const uint32_t *>(L.cdf_image) + (off >> 1);
     uint64_t cdf = (uint64_t)iw[0] | ((uint64_t)iw[1] << 32);
+    // sixteen entries (four 16-byte loads) per round, requested a whole round ahead: the chain is serial and a load takes
+    // longer than four of its steps
     const uint4 *g4 = reinterpret_cast<const uint4 *>(grouped);
-    uint4 cur = cnt > 0 ? g4[0] : make_uint4(0, 0, 0, 0);
-    for (int e = 0; e < cnt; e += 4) {
-      const uint4 nxt = e + 4 < cnt ? g4[(e >> 2) + 1] : make_uint4(0, 0, 0, 0);
-      list[cur.x >> 4] = small_step(cdf, (int)(cur.x & 15), n);
-      if (e + 1 < cnt) list[cur.y >> 4] = small_step(cdf, (int)(cur.y & 15), n);
-      if (e + 2 < cnt) list[cur.z >> 4] = small_step(cdf, (int)(cur.z & 15), n);
-      if (e + 3 < cnt) list[cur.w >> 4] = small_step(cdf, (int)(cur.w & 15), n);
-      cur = nxt;
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    uint4 c0 = cnt > 0 ? g4[0] : z, c1 = cnt > 4 ? g4[1] : z, c2 = cnt > 8 ? g4[2] : z, c3 = cnt > 12 ? g4[3] : z;
+    auto four = [&](const uint4 &v, int e) {
+      if (e < cnt) list[v.x >> 4] = small_step(cdf, (int)(v.x & 15), n);
+      if (e + 1 < cnt) list[v.y >> 4] = small_step(cdf, (int)(v.y & 15), n);
+      if (e + 2 < cnt) list[v.z >> 4] = small_step(cdf, (int)(v.z & 15), n);
+      if (e + 3 < cnt) list[v.w >> 4] = small_step(cdf, (int)(v.w & 15), n);
+    };
+#pragma unroll 1
+    for (int e = 0; e < cnt; e += 16) {
+      const uint4 *nx = g4 + (e >> 2) + 4;
+      const uint4 n0 = e + 16 < cnt ? nx[0] : z, n1 = e + 20 < cnt ? nx[1] : z, n2 = e + 24 < cnt ? nx[2] : z, n3 = e + 28 < cnt ? nx[3] : z;
+      four(c0, e); four(c1, e + 4); four(c2, e + 8); four(c3, e + 12);
+      c0 = n0; c1 = n1; c2 = n2; c3 = n3;
     }
   } else {
     uint16_t *cdf = s_big + lane * 16;
@@ -171,10 +204,11 @@ __global__ __launch_bounds__(64) void k_av1_chains(Av1EntLaunch L, int ntiles_al
       d[0] = iw[0];
       d[1] = n > 8 ? iw[1] : make_uint4(0, 0, 0, 0);
     }
+#pragma unroll 1
     for (int e = 0; e < cnt; e++) {
-      const uint32_t q = grouped[e];
-      const int s = (int)(q & 15);
-      list[q >> 4] = s >= kSplitHorz ? split_tuple(cdf, s) : big_step(cdf, s, n);
+      const uint32_t v = grouped[e];
+      const int s = (int)(v & 15);
+      list[v >> 4] = s >= kSplitHorz ? split_tuple(cdf, s) : big_step(cdf, s, n);
     }
   }
 }
@@ -186,7 +220,8 @@ __global__ __launch_bounds__(64) void k_av1_chains(Av1EntLaunch L, int ntiles_al
 //  * NO global memory in the steady state (a wait for memory on gfx9 waits for every outstanding vector-memory operation,
 //    stores included).  Words come from the LDS ring, bytes go to the LDS stage; both meet global memory in rare PHASES the whole
 //    wave takes together: 32 words per lane are requested into registers in one phase and written to the ring in the next (the
-//    loads have long landed), the stages are stored.  A phase is due when a lane has fewer than 16 words staged or a stage is full.
+//    loads have long landed), the stages are stored.  A phase is due when a lane has fewer than 24 words staged or a stage is
+//    nearly full; that is looked at every eight steps.
 constexpr int kRingOps = 64, kLaneWords = kRingOps * 2 + Coder::kStage + 8;     // uint16 per lane; + 8: the lanes start on different banks
 
 __global__ __launch_bounds__(64) void k_av1_code(Av1EntLaunch L, int ntiles_all) {
@@ -225,21 +260,24 @@ __global__ __launch_bounds__(64) void k_av1_code(Av1EntLaunch L, int ntiles_all)
   int i = 0, lit_left = 0;
   uint32_t op = ring[0], op_next = ring[1];
   for (;;) {
-    const bool has = lit_left > 0 || i < n;
-    if (!__any(has)) break;
-    if (__any((has && pend && w - i < 16) || c.stage_full())) {      // a phase
+    // the checks every eight steps: a lane advances by at most eight words and eight stage entries in between
+    if (!__any(lit_left > 0 || i < n)) break;
+    if (__any((pend && w - i < 24) || c.ns >= Coder::kStage - 8)) {      // a phase
       if (pend && w - i <= 32) { take(); request(); }
       c.spill();
     }
-    if (has) {
-      uint32_t tup = op;
-      if (lit_left == 0 && (op >> 31)) lit_left = (int)((op >> 27) & 15);
-      if (lit_left > 0) {         // one equiprobable bit: the tuples of (icdf 16384 | 0, symbol 1 of 2) and (32768 | 16384, symbol 0 of 2)
-        lit_left--;
-        tup = (op >> lit_left) & 1 ? (1u << 19) | (256u << 9) : (2u << 19) | (512u << 9) | 256u;
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      if (lit_left > 0 || i < n) {
+        uint32_t tup = op;
+        if (lit_left == 0 && (op >> 31)) lit_left = (int)((op >> 27) & 15);
+        if (lit_left > 0) {         // one equiprobable bit: the tuples of (icdf 16384 | 0, symbol 1 of 2) and (32768 | 16384, symbol 0 of 2)
+          lit_left--;
+          tup = (op >> lit_left) & 1 ? (1u << 19) | (256u << 9) : (2u << 19) | (512u << 9) | 256u;
+        }
+        c.encode_tuple(tup);
+        if (lit_left == 0) { i++; op = op_next; op_next = ring[(i + 1) & (kRingOps - 1)]; }
       }
-      c.encode_tuple(tup);
-      if (lit_left == 0) { i++; op = op_next; op_next = ring[(i + 1) & (kRingOps - 1)]; }
     }
   }
   if (!live) return;
@@ -288,14 +326,16 @@ __global__ __launch_bounds__(64) void k_av1_gather(Av1EntLaunch L) {
   if (tail0 + threadIdx.x < n) dst[tail0 + threadIdx.x] = src[tail0 + threadIdx.x];
 }
 
-hipError_t launch_av1_entropy(const Av1EntLaunch &L, hipStream_t s) {
-  if (L.nframes <= 0) return hipSuccess;
+hipError_t launch_av1_front(const Av1EntLaunch &L, hipStream_t s) {
   const long nb = (long)L.fv.w8 * L.fv.h8 * L.nframes;
-  const int ntiles_all = L.sbr_n * L.sbc_n * L.nframes;
+  const int ntiles_all = L.sbr_n * L.sbc_n * L.nframes, ngroups = (ntiles_all + 63) / 64;
   hipLaunchKernelGGL(k_av1_info, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, L);
   hipLaunchKernelGGL(k_av1_tokens, dim3((unsigned)ntiles_all), dim3(64), 0, s, L);
-  const int ngroups = (ntiles_all + 63) / 64, nslots = L.fv.key ? S_KEY_END : S_INTER_END;
-  hipLaunchKernelGGL(k_av1_chains, dim3((unsigned)(((ngroups + 7) / 8) * 8 * nslots)), dim3(64), 0, s, L, ntiles_all, ngroups);
+  hipLaunchKernelGGL(k_av1_chains, dim3((unsigned)(((ngroups + 7) / 8) * 8 * (L.fv.key ? S_KEY_END : S_INTER_END))), dim3(64), 0, s, L, ntiles_all, ngroups);
+  return hipGetLastError();
+}
+hipError_t launch_av1_back(const Av1EntLaunch &L, hipStream_t s) {
+  const int ntiles_all = L.sbr_n * L.sbc_n * L.nframes;
   hipLaunchKernelGGL(k_av1_code, dim3((unsigned)((ntiles_all + 63) / 64)), dim3(64), 0, s, L, ntiles_all);
   hipLaunchKernelGGL(k_av1_scan, dim3(1), dim3(1024), 0, s, L, ntiles_all);
   hipLaunchKernelGGL(k_av1_gather, dim3((unsigned)ntiles_all), dim3(64), 0, s, L);
@@ -306,8 +346,12 @@ hipError_t launch_av1_entropy(const Av1EntLaunch &L, hipStream_t s) {
 
 // ------------------------------------------------------------------------------------------------ C ABI
 struct av1mi_av1ent_state {      // per-context scratch of the coder, grown on demand (owned through av1mi_av1_entropy_release)
-  void *info = nullptr, *ops = nullptr, *grouped = nullptr, *slot_tb = nullptr, *nops = nullptr, *slots = nullptr, *tile_off = nullptr, *status = nullptr;
-  size_t info_b = 0, ops_b = 0, grouped_b = 0, slot_tb_b = 0, nops_b = 0, slots_b = 0, off_b = 0;
+  void *info = nullptr, *ops[2] = { nullptr, nullptr }, *nops[2] = { nullptr, nullptr }, *grouped = nullptr, *slot_tb = nullptr, *rec = nullptr, *slots = nullptr, *tile_off = nullptr, *status = nullptr;
+  size_t info_b = 0, ops_b[2] = { 0, 0 }, nops_b[2] = { 0, 0 }, grouped_b = 0, slot_tb_b = 0, rec_b = 0, slots_b = 0, off_b = 0;
+  // the lists (ops, nops) exist twice: job k uses set k & 1, so the front half of job k + 1 may run beside the back half of job k
+  hipEvent_t lists_ready[2] = { nullptr, nullptr }, lists_free[2] = { nullptr, nullptr };
+  bool free_recorded[2] = { false, false };
+  unsigned long jobs = 0;
   uint16_t *d_image[2][4] = {};   // [key][qcat] default CDF images
   int image_words[2] = { 0, 0 };
   av1ops::SlotTable tab[2];
@@ -329,7 +373,9 @@ extern "C" {
 uint32_t av1mi_av1_entropy_ops_per_tile(void) { return 24576; }
 uint32_t av1mi_av1_entropy_slot_bytes(void) { return 16384; }
 
-int av1mi_av1_entropy_encode_on(av1mi_ctx *ctx, const av1mi_av1_entropy_job *j, void *stream_handle) {
+}  // extern "C"
+
+int av1mi::av1_entropy_submit(av1mi_ctx *ctx, const av1mi_av1_entropy_job *j, hipStream_t front, hipStream_t back) {
   if (!ctx) return AV1MI_E_INVAL;
   if (!j) return av1mi::ctx_fail(ctx, AV1MI_E_INVAL, "null job");
   if (hipSetDevice(av1mi::ctx_device(ctx)) != hipSuccess) return av1mi::ctx_fail(ctx, AV1MI_E_DEVICE, "hipSetDevice failed");
@@ -342,7 +388,6 @@ int av1mi_av1_entropy_encode_on(av1mi_ctx *ctx, const av1mi_av1_entropy_job *j, 
   if (j->nframes == 0) return AV1MI_OK;
   av1mi_av1ent_state *st = av1mi::ctx_av1ent(ctx);
   if (!st) return av1mi::ctx_fail(ctx, AV1MI_E_NOMEM, "AV1 entropy state");
-  hipStream_t s = stream_handle ? (hipStream_t)stream_handle : av1mi::ctx_stream(ctx);
   const int key = j->key ? 1 : 0, qcat = j->base_q_idx <= 20 ? 0 : j->base_q_idx <= 60 ? 1 : j->base_q_idx <= 120 ? 2 : 3;
   if (!st->d_image[key][qcat]) {
     av1ops::SlotTable tab;
@@ -367,23 +412,43 @@ int av1mi_av1_entropy_encode_on(av1mi_ctx *ctx, const av1mi_av1_entropy_job *j, 
   const size_t nb = (size_t)L.fv.w8 * L.fv.h8 * j->nframes, nt = (size_t)L.sbr_n * L.sbc_n * j->nframes;
   L.ops_cap = av1mi_av1_entropy_ops_per_tile(); L.slot_cap = av1mi_av1_entropy_slot_bytes();
   L.grouped_cap = L.ops_cap + av1ops::kListAlign * av1ops::S_MAX;      // every slot's entries start on 16 bytes
+  const int par = (int)(st->jobs++ & 1);
   int rc;
-  if ((rc = grow(ctx, &st->info, &st->info_b, nb * sizeof(av1ops::BlockInfo))) || (rc = grow(ctx, &st->ops, &st->ops_b, nt * L.ops_cap * sizeof(av1ops::op_t))) ||
+  if ((rc = grow(ctx, &st->info, &st->info_b, nb * sizeof(av1ops::BlockInfo))) ||
+      (rc = grow(ctx, &st->ops[par], &st->ops_b[par], nt * L.ops_cap * sizeof(av1ops::op_t))) || (rc = grow(ctx, &st->nops[par], &st->nops_b[par], nt * 4)) ||
       (rc = grow(ctx, &st->grouped, &st->grouped_b, nt * L.grouped_cap * sizeof(uint32_t))) ||
-      (rc = grow(ctx, &st->slot_tb, &st->slot_tb_b, nt * av1ops::S_MAX * 4)) || (rc = grow(ctx, &st->nops, &st->nops_b, nt * 4)) || (rc = grow(ctx, &st->slots, &st->slots_b, nt * L.slot_cap)) ||
-      (rc = grow(ctx, &st->tile_off, &st->off_b, (nt + 1) * 8)))
+      (rc = grow(ctx, &st->slot_tb, &st->slot_tb_b, nt * av1ops::S_MAX * 4)) ||
+      (rc = grow(ctx, &st->rec, &st->rec_b, nt * av1ops::kBlocksPerTile * av1ops::kBlockRecords * sizeof(uint16_t))) ||
+      (rc = grow(ctx, &st->slots, &st->slots_b, nt * L.slot_cap)) || (rc = grow(ctx, &st->tile_off, &st->off_b, (nt + 1) * 8)))
     return rc;
-  L.info = (av1ops::BlockInfo *)st->info; L.ops = (av1ops::op_t *)st->ops; L.grouped = (uint32_t *)st->grouped; L.slot_total = (uint16_t *)st->slot_tb; L.slot_base = L.slot_total + nt * av1ops::S_MAX; L.nops = (uint32_t *)st->nops; L.slots = (uint8_t *)st->slots;
+  L.info = (av1ops::BlockInfo *)st->info; L.ops = (av1ops::op_t *)st->ops[par]; L.nops = (uint32_t *)st->nops[par]; L.grouped = (uint32_t *)st->grouped;
+  L.slot_total = (uint16_t *)st->slot_tb; L.slot_base = L.slot_total + nt * av1ops::S_MAX; L.rec = (uint16_t *)st->rec; L.slots = (uint8_t *)st->slots;
   L.tile_off = (uint64_t *)st->tile_off;
   L.tile_size = j->d_tile_size; L.out = j->d_out; L.out_cap = j->out_cap;
   L.status = (uint32_t *)(j->d_total + 1);
   L.cdf_image = st->d_image[key][qcat]; L.cdf_words = st->image_words[key]; L.tab = st->tab[key];
-  if (hipMemsetAsync(j->d_total, 0, 16, s) != hipSuccess) return av1mi::ctx_fail(ctx, AV1MI_E_DEVICE, "hipMemsetAsync failed");
-  const hipError_t e = av1mi::launch_av1_entropy(L, s);
-  if (e != hipSuccess) return av1mi::ctx_fail(ctx, AV1MI_E_DEVICE, "AV1 entropy launch: %s", hipGetErrorString(e));
-  // total bytes next to the status: tile_off[nt]
-  if (hipMemcpyAsync(j->d_total, L.tile_off + nt, 8, hipMemcpyDeviceToDevice, s) != hipSuccess) return av1mi::ctx_fail(ctx, AV1MI_E_DEVICE, "copy of the total failed");
+#define E_HIP(call) do { const hipError_t e_ = (call); if (e_ != hipSuccess) return av1mi::ctx_fail(ctx, AV1MI_E_DEVICE, "%s: %s", #call, hipGetErrorString(e_)); } while (0)
+  const bool two = front != back;
+  if (two) {
+    for (hipEvent_t *ev : { &st->lists_ready[par], &st->lists_free[par] }) if (!*ev) E_HIP(hipEventCreateWithFlags(ev, hipEventDisableTiming));
+    if (st->free_recorded[par]) E_HIP(hipStreamWaitEvent(front, st->lists_free[par], 0));      // the coder of two jobs ago still reads this set of lists
+  }
+  E_HIP(hipMemsetAsync(j->d_total, 0, 16, front));
+  E_HIP(av1mi::launch_av1_front(L, front));
+  if (two) { E_HIP(hipEventRecord(st->lists_ready[par], front)); E_HIP(hipStreamWaitEvent(back, st->lists_ready[par], 0)); }
+  E_HIP(av1mi::launch_av1_back(L, back));
+  E_HIP(hipMemcpyAsync(j->d_total, L.tile_off + nt, 8, hipMemcpyDeviceToDevice, back));      // total bytes next to the status: tile_off[nt]
+  if (two) { E_HIP(hipEventRecord(st->lists_free[par], back)); st->free_recorded[par] = true; }
+#undef E_HIP
   return AV1MI_OK;
+}
+
+extern "C" {
+
+int av1mi_av1_entropy_encode_on(av1mi_ctx *ctx, const av1mi_av1_entropy_job *j, void *stream_handle) {
+  if (!ctx) return AV1MI_E_INVAL;
+  hipStream_t s = stream_handle ? (hipStream_t)stream_handle : av1mi::ctx_stream(ctx);
+  return av1mi::av1_entropy_submit(ctx, j, s, s);
 }
 
 int av1mi_av1_entropy_encode(av1mi_ctx *ctx, const av1mi_av1_entropy_job *j) { return av1mi_av1_entropy_encode_on(ctx, j, nullptr); }
@@ -393,7 +458,8 @@ int av1mi_av1_entropy_encode(av1mi_ctx *ctx, const av1mi_av1_entropy_job *j) { r
 namespace av1mi {
 void av1ent_free(av1mi_av1ent_state *st) {
   if (!st) return;
-  for (void *p : { st->info, st->ops, st->grouped, st->slot_tb, st->nops, st->slots, st->tile_off }) if (p) (void)hipFree(p);
+  for (void *p : { st->info, st->ops[0], st->ops[1], st->nops[0], st->nops[1], st->grouped, st->slot_tb, st->rec, st->slots, st->tile_off }) if (p) (void)hipFree(p);
+  for (hipEvent_t ev : { st->lists_ready[0], st->lists_ready[1], st->lists_free[0], st->lists_free[1] }) if (ev) (void)hipEventDestroy(ev);
   for (auto &k : st->d_image) for (uint16_t *p : k) if (p) (void)hipFree(p);
   delete st;
 }

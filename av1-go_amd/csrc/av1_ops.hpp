@@ -123,33 +123,47 @@ typedef uint32_t op_t;
 struct SlotTable { uint16_t off[S_MAX]; uint8_t nsym[(S_MAX + 3) & ~3]; int words; };     // a whole number of dwords
 AV1_HD op_t op_lit(int n, unsigned v) { return (op_t)(0x80000000u | ((unsigned)n << 27) | (v & 0x7FFu)); }
 AV1_HD op_t make_tuple(uint32_t fl, uint32_t fh, int s, int n) { return (op_t)(((unsigned)(n - s) << 19) | ((fl >> 6) << 9) | (fh >> 6)); }
-enum { kBlocksPerTile = 64, kSplitHorz = 14, kSplitVert = 15, kListAlign = 4 };     // a slot's entries start on 16 bytes
+enum { kBlocksPerTile = 64, kSplitHorz = 14, kSplitVert = 15, kListAlign = 4, kBlockRecords = 512 };     // a slot's entries start on 16 bytes
 
-// Where the elements of one block go.  M[slot][block] (uint16, S_MAX x 64): in the counting pass (ops == nullptr) the number of
-// adaptive symbols the block codes in the slot; before the writing pass it is turned into the position of the block's first
-// entry of that slot in the tile's grouped entries (group_positions), so the writing pass scatters without any ordering step.
+// The tokenizer runs ONCE per block and leaves 16-bit RECORDS, one per syntax element in decoding order:
+//   literal: 1 | n (4 bits, 1..11, << 11) | value (11 bits);     adaptive symbol: 0 | slot (<< 4) | symbol (4 bits)
+// while it counts, per (slot, block), the adaptive symbols (cnt[slot][block], uint8).  Once the counts of all 64 blocks of the tile
+// are known every block's first entry of every slot has its place in the grouped entries (group_positions), and REPLAY turns
+// the block's records into list words and grouped entries without looking at the frame again.
 struct Sink {
-  op_t *ops;
-  uint32_t *grouped;
-  uint16_t *M;
-  int zi, n;
-  AV1_HD void entry(int slot, int s) {
-    uint16_t &m = M[slot * kBlocksPerTile + zi];
-    if (ops) grouped[m] = ((uint32_t)n << 4) | (uint32_t)s;
-    m++; n++;
+  uint16_t *rec;            // the block's records (kBlockRecords of them)
+  uint8_t *cnt;             // [S_MAX][64]
+  int zi, nrec, n;          // n: list words so far (a literal of more than 11 bits is several)
+  bool overflow;            // more records than the block's area holds, or 255 symbols of one slot in one block
+  AV1_HD void put(unsigned r) { if (nrec < kBlockRecords) rec[nrec] = (uint16_t)r; else overflow = true; nrec++; n++; }
+  AV1_HD void sym(int slot, int s) {
+    put(((unsigned)slot << 4) | (unsigned)s);
+    uint8_t &c = cnt[slot * kBlocksPerTile + zi];
+    if (c == 255) overflow = true; else c++;
   }
-  AV1_HD void sym(int slot, int s) { entry(slot, s); }
-  AV1_HD void split(int kind, int slot) { entry(slot, kind ? kSplitVert : kSplitHorz); }
-  AV1_HD void lit(unsigned v, int nbits) {                // most significant bits first, at most 11 per op
-    while (nbits > 11) { nbits -= 11; if (ops) ops[n] = op_lit(11, v >> nbits); n++; }
-    if (nbits > 0) { if (ops) ops[n] = op_lit(nbits, v & ((1u << nbits) - 1u)); n++; }
+  AV1_HD void split(int kind, int slot) { sym(slot, kind ? kSplitVert : kSplitHorz); }
+  AV1_HD void lit(unsigned v, int nbits) {                // most significant bits first, at most 11 per record
+    while (nbits > 11) { nbits -= 11; put(0x8000u | (11u << 11) | ((v >> nbits) & 0x7FFu)); }
+    if (nbits > 0) put(0x8000u | ((unsigned)nbits << 11) | (v & ((1u << nbits) - 1u)));
   }
 };
-// counts of ONE slot over the tile's 64 blocks -> running positions; returns the slot's number of entries
-AV1_HD int group_positions(uint16_t *m_slot, int base) {
+// counts of ONE slot over the tile's 64 blocks -> positions of the blocks' first entries; returns the slot's number of entries
+AV1_HD int group_positions(const uint8_t *cnt_slot, uint16_t *pos_slot, int base) {
   int run = base;
-  for (int b = 0; b < kBlocksPerTile; b++) { const int c = m_slot[b]; m_slot[b] = (uint16_t)run; run += c; }
+  for (int b = 0; b < kBlocksPerTile; b++) { const int c = cnt_slot[b]; pos_slot[b] = (uint16_t)run; run += c; }
   return run - base;
+}
+// the block's records -> list words (from index `first`) and grouped entries; pos = [S_MAX][64] running positions
+AV1_HD void replay_block(const uint16_t *rec, int nrec, uint16_t *pos, int zi, int first, op_t *list, uint32_t *grouped) {
+  int n = first;
+  for (int i0 = 0; i0 < nrec; i0 += 8) {
+    struct alignas(16) R8 { uint16_t v[8]; } q = *reinterpret_cast<const R8 *>(rec + i0);
+    for (int j = 0; j < 8 && i0 + j < nrec; j++, n++) {
+      const unsigned r = q.v[j];
+      if (r & 0x8000u) list[n] = op_lit((int)((r >> 11) & 15), r & 0x7FFu);
+      else { uint16_t &p = pos[(r >> 4) * kBlocksPerTile + zi]; grouped[p] = ((uint32_t)n << 4) | (r & 15u); p++; }
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ frame view

@@ -144,6 +144,11 @@ av1mi_av1ent_state *av1ent_new();
 void av1ent_free(av1mi_av1ent_state *st);
 av1mi_av1ent_state *ctx_av1ent(av1mi_ctx *ctx);
 hipStream_t ctx_side_stream(av1mi_ctx *ctx);
+hipStream_t ctx_back_stream(av1mi_ctx *ctx);
+// the AV1 tile coder of include/av1mi.h's av1mi_av1_entropy_job in two halves: info + tokens + chains on `front`, the serial range
+// coder + scan + gather on `back` (the same stream, or a second one: the lists are double-buffered, so the front half of the next
+// job runs beside the back half of this one)
+int av1_entropy_submit(av1mi_ctx *ctx, const struct av1mi_av1_entropy_job *j, hipStream_t front, hipStream_t back);
 // accessors of the opaque context for translation units other than capi.hip (gop_session.hip)
 hipStream_t ctx_stream(av1mi_ctx *ctx);
 int ctx_device(av1mi_ctx *ctx);

@@ -13,6 +13,7 @@ struct av1mi_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t side = nullptr;             // K9 asynchronous form: the coder overlaps the main stream's next launches
+  hipStream_t back = nullptr;             // AV1 coder of a GOP session: the serial range coder, beside the next batch's tokenizer on `side`
   hipEvent_t fork = nullptr;              // main -> side dependency
   hipEvent_t slot_done[8] = { nullptr };  // side -> main: the coder of slot i has finished
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -128,6 +129,12 @@ hipStream_t ctx_side_stream(av1mi_ctx *ctx) {
   }
   return ctx->side;
 }
+hipStream_t ctx_back_stream(av1mi_ctx *ctx) {
+  if (!ctx->back) {
+    if (hipStreamCreateWithFlags(&ctx->back, hipStreamNonBlocking) != hipSuccess) return nullptr;
+  }
+  return ctx->back;
+}
 int ctx_fail(av1mi_ctx *ctx, int code, const char *fmt, ...) {
   if (ctx) {
     va_list ap;
@@ -175,6 +182,7 @@ void av1mi_close(av1mi_ctx *ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); }
+  if (ctx->back) { (void)hipStreamSynchronize(ctx->back); (void)hipStreamDestroy(ctx->back); }
   if (ctx->fork) (void)hipEventDestroy(ctx->fork);
   for (hipEvent_t ev : ctx->slot_done) if (ev) (void)hipEventDestroy(ev);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
@@ -233,6 +241,7 @@ int av1mi_sync(av1mi_ctx *ctx) {
   BIND(ctx);
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   if (ctx->side) HIP_TRY(ctx, hipStreamSynchronize(ctx->side));
+  if (ctx->back) HIP_TRY(ctx, hipStreamSynchronize(ctx->back));
   return AV1MI_OK;
 }
 int av1mi_timer_begin(av1mi_ctx *ctx) {

@@ -59,6 +59,7 @@ struct Slot {
   void *h_ent_out = nullptr, *d_tile_size = nullptr, *h_tile_size = nullptr, *d_total = nullptr, *h_total = nullptr;
   hipEvent_t ent_done = nullptr;      // coder + download of sizes / total finished (side stream)
   bool ent_pending = false;
+  bool symbols_down = false;          // this batch's symbols were sent to the host at submit time
 };
 
 }  // namespace
@@ -218,6 +219,22 @@ void av1mi_gop_close(av1mi_gop *g) {
 }
 
 int av1mi_gop_max_in_flight(void) { return kSlots; }
+
+}  // extern "C"
+
+// modes (key frames) or vectors + skip flags (inter frames) of a slot -> its pinned host buffers
+static int download_modes(av1mi_gop *g, Slot &s, hipStream_t st) {
+  if (s.frame_type == 0) {
+    for (int k = 0; k < 2; k++) G_HIP(hipMemcpyAsync(s.h_modes[k], s.d_modes[k], g->nb, hipMemcpyDeviceToHost, st));
+  } else {
+    G_HIP(hipMemcpyAsync(s.h_mv, s.d_mv, g->nb * 4, hipMemcpyDeviceToHost, st));
+    G_HIP(hipMemcpyAsync(s.h_skip, s.d_skip, g->nb, hipMemcpyDeviceToHost, st));
+  }
+  return AV1MI_OK;
+}
+
+extern "C" {
+
 int av1mi_gop_pending(av1mi_gop *g) { return g ? (int)(g->submitted - g->collected) : 0; }
 long av1mi_gop_entropy_fallbacks(av1mi_gop *g) { return g ? g->fallbacks : 0; }
 
@@ -276,9 +293,10 @@ int av1mi_gop_submit(av1mi_gop *g, int frame_type) {
   s.kernel_pending = true;
   s.frame_type = frame_type;
   if (c.gpu_entropy) {
-    // the AV1 tile entropy coder on the context's side stream, beside the filters and the next batch's block pipeline
-    hipStream_t side = av1mi::ctx_side_stream(g->ctx);
-    if (!side) return av1mi::ctx_fail(g->ctx, AV1MI_E_DEVICE, "no side stream");
+    // the AV1 tile entropy coder beside the filters and the next batch's block pipeline: tokenizer + chains on the context's
+    // side stream, the serial range coder on its back stream (so the next batch's tokenizer does not wait for it)
+    hipStream_t side = av1mi::ctx_side_stream(g->ctx), back = av1mi::ctx_back_stream(g->ctx);
+    if (!side || !back) return av1mi::ctx_fail(g->ctx, AV1MI_E_DEVICE, "no side stream");
     G_HIP(hipStreamWaitEvent(side, s.kernel_done, 0));
     const av1mi_frame_params &P = g->params[frame_type];
     av1mi_av1_entropy_job ej;
@@ -290,23 +308,21 @@ int av1mi_gop_submit(av1mi_gop *g, int frame_type) {
     ej.lr_on[0] = P.lr_unit_y[0] == 1; ej.lr_on[1] = ej.lr_on[2] = P.lr_unit_uv[0] == 1;
     memcpy(ej.lr_unit_y, P.lr_unit_y, 8); memcpy(ej.lr_unit_uv, P.lr_unit_uv, 8);
     ej.d_out = (uint8_t *)s.h_ent_out; ej.out_cap = g->ent_cap; ej.d_tile_size = (uint32_t *)s.d_tile_size; ej.d_total = (uint64_t *)s.d_total;
-    G_TRY(av1mi_av1_entropy_encode_on(g->ctx, &ej, side));
-    G_HIP(hipMemcpyAsync(s.h_tile_size, s.d_tile_size, (size_t)g->tiles * S * 4, hipMemcpyDeviceToHost, side));
-    G_HIP(hipMemcpyAsync(s.h_total, s.d_total, 16, hipMemcpyDeviceToHost, side));
-    G_HIP(hipEventRecord(s.ent_done, side));
+    G_TRY(av1mi::av1_entropy_submit(g->ctx, &ej, side, back));
+    G_HIP(hipMemcpyAsync(s.h_tile_size, s.d_tile_size, (size_t)g->tiles * S * 4, hipMemcpyDeviceToHost, back));
+    G_HIP(hipMemcpyAsync(s.h_total, s.d_total, 16, hipMemcpyDeviceToHost, back));
+    G_HIP(hipEventRecord(s.ent_done, back));
     s.ent_pending = true;
   }
-  // symbols -> pinned host memory, beside the filters
-  G_HIP(hipStreamWaitEvent(g->down, s.kernel_done, 0));
-  if (c.gpu_entropy != 1)
+  // symbols -> pinned host memory, beside the filters.  Not when the GPU codes the tiles (gpu_entropy == 1): the host then needs
+  // the payloads only (and a fifth busy stream would share a hardware queue with one of the other four)
+  s.symbols_down = c.gpu_entropy != 1;
+  if (s.symbols_down) {
+    G_HIP(hipStreamWaitEvent(g->down, s.kernel_done, 0));
     for (int p = 0; p < 3; p++) G_HIP(hipMemcpyAsync(s.h_lev[p], s.d_lev[p], (p ? g->nc : g->ny) * 2, hipMemcpyDeviceToHost, g->down));
-  if (frame_type == 0) {
-    for (int k = 0; k < 2; k++) G_HIP(hipMemcpyAsync(s.h_modes[k], s.d_modes[k], g->nb, hipMemcpyDeviceToHost, g->down));
-  } else {
-    G_HIP(hipMemcpyAsync(s.h_mv, s.d_mv, g->nb * 4, hipMemcpyDeviceToHost, g->down));
-    G_HIP(hipMemcpyAsync(s.h_skip, s.d_skip, g->nb, hipMemcpyDeviceToHost, g->down));
+    G_TRY(download_modes(g, s, g->down));
+    G_HIP(hipEventRecord(s.downloaded, g->down));
   }
-  G_HIP(hipEventRecord(s.downloaded, g->down));
   // in-loop filters: reconstruction -> reference of the next frame
   const av1mi_frame_params &P = g->params[frame_type];
   for (int p = 0; p < 3; p++) {
@@ -342,27 +358,31 @@ int av1mi_gop_collect(av1mi_gop *g, av1mi_gop_frame *out) {
   if (g->submitted == g->collected) return av1mi::ctx_fail(g->ctx, AV1MI_E_INVAL, "nothing in flight");
   G_HIP(hipSetDevice(av1mi::ctx_device(g->ctx)));
   Slot &s = g->slot[g->collected % kSlots];
-  G_HIP(hipEventSynchronize(s.downloaded));
+  if (s.symbols_down) G_HIP(hipEventSynchronize(s.downloaded));
   memset(out, 0, sizeof(*out));
   out->params = g->params[s.frame_type];
   out->segments = g->cfg.segments;
   out->blocks_per_frame = g->nb / (size_t)g->cfg.segments;
-  if (s.frame_type == 0) { out->y_mode = (const uint8_t *)s.h_modes[0]; out->uv_mode = (const uint8_t *)s.h_modes[1]; }
-  else { out->mv = (const int16_t *)s.h_mv; out->skip = (const uint8_t *)s.h_skip; }
-  if (g->cfg.gpu_entropy != 1) { out->lev_y = (const int16_t *)s.h_lev[0]; out->lev_u = (const int16_t *)s.h_lev[1]; out->lev_v = (const int16_t *)s.h_lev[2]; }
+  auto symbols = [&](bool levels) {
+    if (s.frame_type == 0) { out->y_mode = (const uint8_t *)s.h_modes[0]; out->uv_mode = (const uint8_t *)s.h_modes[1]; }
+    else { out->mv = (const int16_t *)s.h_mv; out->skip = (const uint8_t *)s.h_skip; }
+    if (levels) { out->lev_y = (const int16_t *)s.h_lev[0]; out->lev_u = (const int16_t *)s.h_lev[1]; out->lev_v = (const int16_t *)s.h_lev[2]; }
+  };
+  if (s.symbols_down) symbols(true);
   if (g->cfg.gpu_entropy) {
     G_HIP(hipEventSynchronize(s.ent_done));
     const uint64_t total = ((const uint64_t *)s.h_total)[0], status = ((const uint64_t *)s.h_total)[1];
     // the payloads are already here: k_av1_gather wrote them into the slot's pinned buffer (a copy enqueued NOW would queue
-    // behind the next batch's work, which is already submitted)
+    // behind the next batches' work, which is already submitted)
     if (status || total > g->ent_cap) {
-      // A tile exceeded the coder's op-list / payload capacity (very fine quantisers on dense content).  The batch is not lost:
-      // its symbols are still in the slot's device buffers (the next kernel that overwrites them is kSlots submits away), so they
-      // are downloaded now and handed out like in host mode: tile_size stays NULL, the caller entropy-codes this batch itself.
-      if (g->cfg.gpu_entropy == 1) {
+      // A tile exceeded the coder's list / record / payload capacity (very fine quantisers on dense content).  The batch is not
+      // lost: its symbols are still in the slot's device buffers (the next kernel that overwrites them is kSlots submits away),
+      // so they are downloaded now and handed out like in host mode: tile_size stays NULL, the caller entropy-codes this batch.
+      if (!s.symbols_down) {
         for (int p = 0; p < 3; p++) G_HIP(hipMemcpyAsync(s.h_lev[p], s.d_lev[p], (p ? g->nc : g->ny) * 2, hipMemcpyDeviceToHost, g->down));
+        G_TRY(download_modes(g, s, g->down));
         G_HIP(hipStreamSynchronize(g->down));
-        out->lev_y = (const int16_t *)s.h_lev[0]; out->lev_u = (const int16_t *)s.h_lev[1]; out->lev_v = (const int16_t *)s.h_lev[2];
+        symbols(true);
       }
       g->fallbacks++;
     } else {

@@ -61,36 +61,37 @@ bool opstream_tiles(const av1mi_obu_frame &f, std::vector<std::vector<uint8_t>> 
   const int nslots = v.key ? S_KEY_END : S_INTER_END;
   std::vector<op_t> list;
   std::vector<uint32_t> grouped;
-  std::vector<uint16_t> M((size_t)S_MAX * kBlocksPerTile);
+  std::vector<uint8_t> cnt((size_t)S_MAX * kBlocksPerTile);
+  std::vector<uint16_t> pos((size_t)S_MAX * kBlocksPerTile), rec((size_t)kBlocksPerTile * kBlockRecords);
   ScanTables scan;
   fill_scan_tables(&scan);
   alignas(16) uint8_t mag[kMagBytes];
   const TokScratch ts = { mag, &scan };
   for (int sbr = 0; sbr < sbr_n; sbr++)
     for (int sbc = 0; sbc < sbc_n; sbc++) {
-      // stage 1, tokenize (the GPU: one thread per block): count, place, write
-      std::fill(M.begin(), M.end(), 0);
-      int first[kBlocksPerTile + 1];
+      // stage 1, tokenize (the GPU: one thread per block): records + counts, place, replay
+      std::fill(cnt.begin(), cnt.end(), 0);
+      int first[kBlocksPerTile + 1], nrec[kBlocksPerTile];
       first[0] = 0;
       for (int zi = 0; zi < kBlocksPerTile; zi++) {
-        Sink count = { nullptr, nullptr, M.data(), zi, 0 };
-        tok_block(v, count, ts, sbr, sbc, zi);
-        first[zi + 1] = first[zi] + count.n;
+        Sink k = { &rec[(size_t)zi * kBlockRecords], cnt.data(), zi, 0, 0, false };
+        tok_block(v, k, ts, sbr, sbc, zi);
+        if (k.overflow) { if (err) *err = "a block exceeds the tokenizer's record area"; return false; }
+        nrec[zi] = k.nrec;
+        first[zi + 1] = first[zi] + k.n;
       }
       const int nops = first[kBlocksPerTile];
       int base[S_MAX], total[S_MAX], run = 0;
       for (int sl = 0; sl < nslots; sl++) {
         base[sl] = run;
-        total[sl] = group_positions(&M[(size_t)sl * kBlocksPerTile], run);
+        total[sl] = group_positions(&cnt[(size_t)sl * kBlocksPerTile], &pos[(size_t)sl * kBlocksPerTile], run);
         run = (run + total[sl] + kListAlign - 1) & ~(kListAlign - 1);
       }
       if (run > 65535) { if (err) *err = "tile too large for 16-bit entry positions"; return false; }
       list.assign((size_t)nops, 0);
       grouped.assign((size_t)run, 0);
-      for (int zi = 0; zi < kBlocksPerTile; zi++) {
-        Sink w = { list.data(), grouped.data(), M.data(), zi, first[zi] };
-        tok_block(v, w, ts, sbr, sbc, zi);
-      }
+      for (int zi = 0; zi < kBlocksPerTile; zi++)
+        replay_block(&rec[(size_t)zi * kBlockRecords], nrec[zi], pos.data(), zi, first[zi], list.data(), grouped.data());
       // stage 2, one chain per slot (the GPU: the tile's threads take the slots, longest first)
       for (int sl = 0; sl < nslots; sl++)
         if (total[sl]) run_chain(&image[tab.off[sl]], tab.nsym[sl], &grouped[(size_t)base[sl]], total[sl], list.data());

@@ -84,8 +84,8 @@ void DescribeSessionFrame(const av1mi_gop_frame &fr, int seg, int width, int hei
   f.lr_units[0] = d->lr_y.data(); f.lr_units[1] = f.lr_units[2] = d->lr_uv.data();
   f.tile_cols_log2 = f.tile_rows_log2 = -1;      // one superblock per tile: the independence the GPU pipeline's prediction assumes
   const size_t nb = fr.blocks_per_frame, o = (size_t)seg * nb;
-  if (p.frame_type == 0) { f.y_mode = fr.y_mode + o; f.uv_mode = fr.uv_mode + o; }
-  else { f.mv = fr.mv + o * 2; f.skip = fr.skip + o; }
+  if (fr.y_mode) { f.y_mode = fr.y_mode + o; f.uv_mode = fr.uv_mode + o; }       // the symbols are absent when the tiles were coded on the GPU
+  if (fr.mv) { f.mv = fr.mv + o * 2; f.skip = fr.skip + o; }
   if (fr.lev_y) { f.lev_y = fr.lev_y + o * 64; f.lev_u = fr.lev_u + o * 16; f.lev_v = fr.lev_v + o * 16; }     // absent when the tiles were coded on the GPU
 }
 

@@ -348,10 +348,11 @@ typedef struct av1mi_gop_frame {    /* one collected frame batch; host pointers 
   av1mi_frame_params params;
   int segments;                     /* batch size */
   size_t blocks_per_frame;          /* (width / 8) * (height / 8); per-block arrays hold segments * blocks_per_frame entries */
+  /* the symbols: NULL with gpu_entropy = 1 (the host gets the coded payloads only), unless the GPU coder gave the batch back */
   const uint8_t *y_mode, *uv_mode;  /* key frames: intra modes per 8x8 block (0 DC .. 12 PAETH) */
   const int16_t *mv;                /* inter frames: (x, y) per block in 1/8 luma samples */
   const uint8_t *skip;              /* inter frames: 1 = no non-zero level in the block */
-  const int16_t *lev_y, *lev_u, *lev_v;   /* 64 / 16 / 16 levels per block, row-major inside a block (NULL with gpu_entropy = 1) */
+  const int16_t *lev_y, *lev_u, *lev_v;   /* 64 / 16 / 16 levels per block, row-major inside a block */
   /* gpu_entropy != 0: the finished tile payloads of the batch, frame-major / raster inside a frame, back to back */
   int tiles_per_frame;
   const uint32_t *tile_size;        /* segments * tiles_per_frame entries */

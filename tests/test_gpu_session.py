@@ -162,7 +162,7 @@ def test_gpu_tile_entropy_coder_bytes_equal_the_host_writer(ctx, av1mi, w, h, bd
         s.close()
 
 
-def test_gpu_entropy_only_mode_downloads_no_levels(ctx, av1mi):
+def test_gpu_entropy_only_mode_downloads_no_symbols(ctx, av1mi):
     import av1stream
     import synth
     w, h, bd, q = 192, 128, 8, 120
@@ -177,7 +177,7 @@ def test_gpu_entropy_only_mode_downloads_no_levels(ctx, av1mi):
                     dst[:] = src
                 s.submit()
             fa, fb = a.collect(), b.collect()
-            assert "lev_y" not in fa and "tile_size" not in fb
+            assert "lev_y" not in fa and "mv" not in fa and "y_mode" not in fa and "tile_size" not in fb
             assert av1stream.session_frame_unit_gpu(w, h, bd, fa, 0) == av1stream.session_frame_unit(w, h, bd, fb, 0)
     finally:
         a.close()

@@ -18,6 +18,7 @@ ap.add_argument("--segs", type=int, default=8)
 ap.add_argument("--frames", type=int, default=10)
 ap.add_argument("--size", default="3840x2160")
 ap.add_argument("--bd", type=int, default=10)
+ap.add_argument("--sync", action="store_true", help="wait for the GPU after every submit: kernel durations without the next batch beside them")
 ap.add_argument("--verbose", action="store_true", help="per-iteration host timing of fill / submit / collect")
 ap.add_argument("--threads", type=int, default=16, help="host threads that fill the pinned input (like bench.py's end-to-end leg)")
 args = ap.parse_args()
@@ -40,6 +41,9 @@ for t in range(args.frames):
         j.result()
     ta = time.perf_counter()
     s.submit()
+    if args.sync:
+        ctx.sync()
+        time.sleep(0.01)     # the side stream's coder is not on the context's stream
     tb = time.perf_counter()
     if t >= s.max_in_flight() - 1:
         fr = s.collect()
