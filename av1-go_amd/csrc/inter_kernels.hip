@@ -268,7 +268,7 @@ __device__ __forceinline__ void mc_row(const ES *win, int ws, int16_t *im, int l
 
 // The same filter split in two, so that the candidates of a refinement round that share a horizontal phase share its
 // (more expensive) horizontal pass: mc_h16 filters all 16 rows of the luma window for one horizontal displacement,
-// mc_rows9 + mc_v9 produce row `lane` of the prediction for the vertical displacements from that intermediate.
+// mc_rows7 + mc_v7 produce row `lane` of the prediction for the vertical displacements from that intermediate.
 template <typename ES>
 __device__ __forceinline__ void mc_h16(const ES *win, int ws, int16_t *im, int lane, int posx, const int16_t (*filt)[8]) {
   const int ox = 4 + (posx >> 4) - 3;            // 0 or 1
@@ -311,18 +311,19 @@ __device__ __forceinline__ void mc_h16(const ES *win, int ws, int16_t *im, int l
         sum[c] = __builtin_amdgcn_sdot4(F0, (int)d[c], __builtin_amdgcn_sdot4(F1, (int)d[c + 4], acc0 + fx[3] * p3, false), false);
       }
     } else {
-      // 10-bit: sample pairs (m, m + 1) for m = 0..14 (odd m by funnel shift), 8 taps = four v_dot2_i32_i16
-      uint32_t pm[15];
+      // 10-bit: the regular filter has SIX taps (taps 0 and 7 are 0 at every phase): sample pairs (m, m + 1) for m = 1..12 (odd
+      // m by funnel shift) against the tap pairs (t1, t2) (t3, t4) (t5, t6) = three v_dot2_i32_i16 per sample
+      uint32_t pm[13];
 #pragma unroll
-      for (int m = 0; m < 15; m++) pm[m] = (m & 1) ? __builtin_amdgcn_alignbit(a[(m + 1) >> 1], a[m >> 1], 16) : a[m >> 1];
-      // the tap row is 8 int16 = the four (even, odd) tap pairs as they lie in memory
+      for (int m = 1; m < 13; m++) pm[m] = (m & 1) ? __builtin_amdgcn_alignbit(a[(m + 1) >> 1], a[m >> 1], 16) : a[m >> 1];
+      // the tap row is 8 int16 = (t0, t1) (t2, t3) (t4, t5) (t6, t7) as they lie in memory: the pairs one tap further by funnel shift
       const uint4 fq = *reinterpret_cast<const uint4 *>(filt[posx & 15]);
-      const s16x2 fp[4] = { __builtin_bit_cast(s16x2, fq.x), __builtin_bit_cast(s16x2, fq.y), __builtin_bit_cast(s16x2, fq.z), __builtin_bit_cast(s16x2, fq.w) };
+      const uint32_t g1 = __builtin_amdgcn_alignbit(fq.y, fq.x, 16), g2 = __builtin_amdgcn_alignbit(fq.z, fq.y, 16), g3 = __builtin_amdgcn_alignbit(fq.w, fq.z, 16);
 #pragma unroll
       for (int c = 0; c < 8; c++) {
-        int acc = dot2_start(pm[c], __builtin_bit_cast(uint32_t, fp[0]), 128);   // taps x 32 (see below): the rounding constant 4 x 32
-#pragma unroll
-        for (int u = 1; u < 4; u++) acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, pm[c + 2 * u]), fp[u], acc, false);
+        int acc = dot2_start(pm[c + 1], g1, 128);   // taps x 32 (see below): the rounding constant 4 x 32
+        acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, pm[c + 3]), __builtin_bit_cast(s16x2, g2), acc, false);
+        acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, pm[c + 5]), __builtin_bit_cast(s16x2, g3), acc, false);
         sum[c] = acc;
       }
     }
@@ -360,21 +361,21 @@ __device__ __forceinline__ void mc_h16_copy(const ES *win, int ws, int16_t *im, 
     *reinterpret_cast<uint4 *>(im + j * 8) = make_uint4(o[0], o[1], o[2], o[3]);
   }
 }
-// The vertical displacements of one refinement round differ by less than a sample, so row `lane` of all of them reads
-// intermediate rows lane .. lane + 8: those nine rows (16 bytes each) are loaded ONCE per horizontal position (mc_rows9) and
-// every vertical candidate is a 9-tap sum over them — the 8 taps of its phase shifted by its integer part, a zero at the
-// other end (mc_v9).  The first version of k_inter_pipe was LDS-bound (LDS busy 85 % of the kernel by PMC); this cut the
-// reads of the vertical pass from 8 per candidate to 9 per three candidates.
-// After the LDS diet the kernel is VALU-bound, so the vertical sums run on v_dot2_i32_i16: the nine rows are interleaved
-// once per horizontal position into row PAIRS per column, pr[kp][c] = (row 2kp, row 2kp + 1) of column c (row 9 = 0), and a
-// candidate is 5 dot2 per sample instead of 9 multiply-adds + 9 extracts (exact: int16 x int16 into int32).
-__device__ __forceinline__ void mc_rows9(const int16_t *im, int lane, uint32_t (*pr)[8]) {
-  uint4 rw[10];
+// The vertical displacements of one refinement round differ by less than a sample and the regular filter has six taps (1..6),
+// so row `lane` of all of them reads intermediate rows lane + 1 .. lane + 7: those seven rows (16 bytes each) are loaded ONCE
+// per horizontal position (mc_rows7) and every vertical candidate is a 7-tap sum over them — the six taps of its phase shifted
+// by its integer part, a zero at the other end (mc_v7).  The first version of k_inter_pipe was LDS-bound (LDS busy 85 % of the
+// kernel by PMC); this cut the reads of the vertical pass from 8 per candidate to 7 per three candidates.
+// After the LDS diet the kernel is VALU-bound, so the vertical sums run on v_dot2_i32_i16: the rows are interleaved once per
+// horizontal position into row PAIRS per column, pr[kp][c] = (row 2kp + 1, row 2kp + 2) of column c ("row 8" = a constant), and
+// a candidate is 4 dot2 per sample instead of 7 multiply-adds + 7 extracts (exact: int16 x int16 into int32).
+__device__ __forceinline__ void mc_rows7(const int16_t *im, int lane, uint32_t (*pr)[8]) {
+  uint4 rw[8];
 #pragma unroll
-  for (int k = 0; k < 9; k++) rw[k] = *reinterpret_cast<const uint4 *>(im + (lane + k) * 8);
-  rw[9] = make_uint4(0x00020002u, 0x00020002u, 0x00020002u, 0x00020002u);   // "row 9" = the constant 2: carries mc_v9's rounding term
+  for (int k = 0; k < 7; k++) rw[k] = *reinterpret_cast<const uint4 *>(im + (lane + 1 + k) * 8);
+  rw[7] = make_uint4(0x00020002u, 0x00020002u, 0x00020002u, 0x00020002u);   // "row 8" = the constant 2: carries mc_v7's rounding term
 #pragma unroll
-  for (int kp = 0; kp < 5; kp++) {
+  for (int kp = 0; kp < 4; kp++) {
     const uint32_t x[4] = { rw[2 * kp].x, rw[2 * kp].y, rw[2 * kp].z, rw[2 * kp].w };
     const uint32_t y[4] = { rw[2 * kp + 1].x, rw[2 * kp + 1].y, rw[2 * kp + 1].z, rw[2 * kp + 1].w };
 #pragma unroll
@@ -387,23 +388,23 @@ __device__ __forceinline__ void mc_rows9(const int16_t *im, int lane, uint32_t (
 // `filt32` holds the taps times 32: (32 s + 32768) >> 16 == (s + 1024) >> 11 exactly, and the result is then the high half of
 // the accumulator — one v_perm takes the high halves of two sums, shift and pack in one instruction (the products stay far
 // inside int32: |intermediate| < 2^15, sum of |taps| x 32 < 2^13).  Returns row `lane` of the prediction as four packed pairs.
-__device__ __forceinline__ void mc_v9(const uint32_t (*pr)[8], int posy, const int16_t (*filt32)[8], int bd, uint32_t *ow) {
+__device__ __forceinline__ void mc_v7(const uint32_t (*pr)[8], int posy, const int16_t (*filt32)[8], int bd, uint32_t *ow) {
   const int oy = 4 + (posy >> 4) - 3;            // 0 or 1
-  // the nine taps over rows lane .. lane + 8 as five pairs: the row of 8 taps as it lies in memory (oy = 0: pairs P0..P3, 0),
-  // or moved up by one row (oy = 1: (0,t0) (t1,t2) (t3,t4) (t5,t6) (t7,0)) — one funnel shift per pair
-  const uint4 fq = *reinterpret_cast<const uint4 *>(filt32[posy & 15]);
-  // The last pair's second row is the constant 2 (mc_rows9) and its tap 16384: 2 x 16384 = 32768 is the rounding term, so the
+  // the taps over rows lane + 1 .. lane + 7 as pairs.  The tap row lies in memory as (t0, t1) (t2, t3) (t4, t5) (t6, t7), t0 = t7 = 0:
+  //   oy = 1 (rows 2 .. 7 carry t1 .. t6): (0, t1) (t2, t3) (t4, t5) (t6, .)   = the row as it lies;
+  //   oy = 0 (rows 1 .. 6 carry t1 .. t6): (t1, t2) (t3, t4) (t5, t6) (0, .)   = one funnel shift per pair.
+  // The last pair's second row is the constant 2 (mc_rows7) and its tap 16384: 2 x 16384 = 32768 is the rounding term, so the
   // accumulators start at 0 — an inline constant of the first dot2 instead of a v_mov of a literal per column.
-  const uint32_t P[6] = { 0u, fq.x, fq.y, fq.z, fq.w, 0x40000000u };
-  int s[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+  const uint4 fq = *reinterpret_cast<const uint4 *>(filt32[posy & 15]);
+  const uint32_t g[4] = { oy ? fq.x : __builtin_amdgcn_alignbit(fq.y, fq.x, 16), oy ? fq.y : __builtin_amdgcn_alignbit(fq.z, fq.y, 16),
+                          oy ? fq.z : __builtin_amdgcn_alignbit(fq.w, fq.z, 16), (oy ? (fq.w & 0xFFFFu) : 0u) | 0x40000000u };
+  int s[8];
 #pragma unroll
-  for (int kp = 0; kp < 5; kp++) {
-    uint32_t g = oy ? __builtin_amdgcn_alignbit(P[kp + 1], P[kp], 16) : P[kp + 1];
-    if (kp == 4) g = (oy ? (P[4] >> 16) : 0u) | 0x40000000u;    // (t7 or 0, 16384)
-    const s16x2 gp = __builtin_bit_cast(s16x2, g);
+  for (int kp = 0; kp < 4; kp++) {
+    const s16x2 gp = __builtin_bit_cast(s16x2, g[kp]);
 #pragma unroll
     for (int c = 0; c < 8; c++)
-      s[c] = kp == 0 ? dot2_start(pr[kp][c], g, 0) : __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, pr[kp][c]), gp, s[c], false);
+      s[c] = kp == 0 ? dot2_start(pr[kp][c], g[kp], 0) : __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, pr[kp][c]), gp, s[c], false);
   }
   const s16x2 zero = { 0, 0 }, top = { (short)((1 << bd) - 1), (short)((1 << bd) - 1) };
 #pragma unroll
@@ -437,7 +438,7 @@ __global__ __launch_bounds__(256) void k_inter_pipe(InterLaunch L) {
   __shared__ __attribute__((aligned(16))) unsigned char regb[GPW * REG_BYTES];
   // the two filter families this policy uses, copied next to the windows: a lane's taps depend on its block's vector, and a
   // per-lane indexed read of __constant__ memory is a vector memory load (hundreds of cycles) in front of every candidate
-  __shared__ __attribute__((aligned(16))) int16_t s_filt[3][16][8];   // regular 8-tap, regular 4-tap, regular 8-tap x 32 (mc_v9)
+  __shared__ __attribute__((aligned(16))) int16_t s_filt[3][16][8];   // regular 8-tap, regular 4-tap, regular 8-tap x 32 (mc_h16 at 10 bits, mc_v7)
   if (threadIdx.x < 128) {
     const int t = threadIdx.x;
     reinterpret_cast<uint32_t *>(s_filt)[t] = t < 64 ? reinterpret_cast<const uint32_t *>(kRegular8)[t] : reinterpret_cast<const uint32_t *>(kRegular4)[t - 64];
@@ -541,13 +542,13 @@ __global__ __launch_bounds__(256) void k_inter_pipe(InterLaunch L) {
       const int fx = cx + (ix - 1) * step;
       mc_h16<ES>(wy, YWS, im, lane, fx * 2, sizeof(ES) == 2 ? s_filt[2] : s_filt[0]);
       AV1MI_GROUP_SYNC();
-      uint32_t pr[5][8];
-      mc_rows9(im, lane, pr);
+      uint32_t pr[4][8];
+      mc_rows7(im, lane, pr);
 #pragma unroll
       for (int iy = 0; iy < 3; iy++) {     // unrolled: the three vertical candidates of a column overlap
         const int fy = cy + (iy - 1) * step, k = iy * 3 + ix;
         uint32_t ow[4];
-        mc_v9(pr, fy * 2, s_filt[2], bd, ow);
+        mc_v7(pr, fy * 2, s_filt[2], bd, ow);
         const unsigned key = ((unsigned)sad_of(ow) << 4) | (unsigned)(k == 4 ? 0 : k + 1);
         const bool better = key < bestkey;
         bestkey = min(bestkey, key);

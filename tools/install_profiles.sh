@@ -13,3 +13,5 @@ cp gpurun_out/${T}_bench_1080p8-gop_under_rocprof.json profiles/${R}_bench_1080p
 cp gpurun_out/${T}_kt_1080p8/*/*_kernel_stats.csv profiles/${R}_bench_1080p8_intra_kernel_stats.csv
 cp gpurun_out/${T}_bench_1080p8_under_rocprof.json profiles/${R}_bench_1080p8_intra_under_rocprof.json
 cp gpurun_out/${T}_stages.json profiles/${R}_stages.json
+cp "$(ls -t gpurun_out/${T}_kt_session/*/*_kernel_stats.csv | head -1)" profiles/${R}_session_gpu_entropy_kernel_stats.csv
+cp gpurun_out/${T}_session.log profiles/${R}_session_gpu_entropy.log

@@ -13,4 +13,7 @@ for w in 4k10-gop 1080p8-gop 1080p8; do
   timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/${TAG}_kt_$w -- python3 $ROOT/bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline --no-e2e \
     > $ROOT/gpurun_out/${TAG}_bench_${w}_under_rocprof.json 2> $ROOT/gpurun_out/${TAG}_kt_$w.err || exit 1
 done
+# the GOP session with the GPU tile entropy coder (the product path of RunTranscode): all kernels of an end-to-end batch
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/${TAG}_kt_session -- python3 $ROOT/tools/prof_session.py --segs 8 --frames 16 \
+  > $ROOT/gpurun_out/${TAG}_session.log 2> $ROOT/gpurun_out/${TAG}_kt_session.err || exit 1
 cd $ROOT && bash tools/prof_pmc.sh $TAG "--steps 1 --warmup 1 --no-cpu-baseline --no-e2e"
