@@ -69,7 +69,7 @@ long long av1mi_obu_assemble_temporal_unit(const av1mi_obu_frame *f, const uint8
 
 /* The drop-in for RunTranscode (transcode.go:194-315): argv as TranscodeArgs (transcode.go:17) builds it — the backend reads
  * "-i <input.y4m>", "-global_quality:v:0 <q>" and the output path (last argument), plus its own "-g", "-av1mi_device",
- * "-av1mi_segments", "-threads"; everything else is accepted and ignored.  Returns 0 and leaves the output file in place on
+ * "-av1mi_segments", "-av1mi_gpu_entropy", "-threads"; everything else is accepted and ignored.  Returns 0 and leaves the output file in place on
  * success; -1 when the backend could not run at all (no HIP device: transcode.go:311); another non-zero code on failure.
  * err receives the reference-shaped text ("av1mi failed with exit code N: ...", at most 800 characters + "..."). */
 int av1mi_run_transcode(int argc, const char *const *argv, char *err, size_t errcap);
