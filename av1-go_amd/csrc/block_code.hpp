@@ -74,8 +74,9 @@ constexpr unsigned kModeHorzAdst = 0x1AD4u;   // H D135 D157 D203 SMOOTH SMOOTH_
 
 // s[]: source row, bp[]: prediction row.  Writes this lane's row of levels to lev_row and returns its reconstruction in
 // rec[]; the return value is non-zero when the row holds a non-zero level.  SEL = the block may use the ADST in either
-// direction (vadst: column / vertical pass, hadst: row / horizontal pass); otherwise DCT_DCT.
-template <int B, typename Pix, bool SEL = false>
+// direction (vadst: column / vertical pass, hadst: row / horizontal pass); otherwise DCT_DCT.  AC_ROUND: the quantiser's rounding
+// offset for AC coefficients in 1/128 of the step (txfm_cfg.hpp: one half in key frames, a dead zone in inter frames).
+template <int B, typename Pix, bool SEL = false, int AC_ROUND = kAcRoundIntra>
 __device__ __forceinline__ int code_residual(int32_t *T, int lane, const int *s, const int *bp, int dc_q, int ac_q, int dc_quant, int ac_quant, int16_t *lev_row,
                                              int *rec, bool vadst = false, bool hadst = false) {
   constexpr int RS = B + 4, bd = sizeof(Pix) == 1 ? 8 : 10;
@@ -104,7 +105,7 @@ __device__ __forceinline__ int code_residual(int32_t *T, int lane, const int *s,
   // dc_quant / ac_quant = (1 << 16) / step come from the host: written here as a division, the compiler sank the (loop-invariant)
   // division into the conditional block of every coefficient — ~25 scalar or ~30 vector instructions and a divergent branch, 8
   // times per row of every block
-  const int dc_rnd = (64 * dc_q) >> 7, ac_rnd = (64 * ac_q) >> 7;
+  const int dc_rnd = (64 * dc_q) >> 7, ac_rnd = (AC_ROUND * ac_q) >> 7;
   const int maxv = (1 << (7 + bd)) - 1, minv = -(1 << (7 + bd));
   int lv[B];
 #pragma unroll

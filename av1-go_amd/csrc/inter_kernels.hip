@@ -567,7 +567,7 @@ __global__ __launch_bounds__(256) void k_inter_pipe(InterLaunch L) {
   const int mvx = imx * 8 + bfx, mvy = imy * 8 + bfy;   // final vector, 1/8 luma samples
   if (lane == 0) { mvs[0] = (int16_t)mvx; mvs[1] = (int16_t)mvy; }
   int rec[8];
-  int nz = code_residual<8, Pix>(T, lane, s, bp, L.dc_q, L.ac_q, L.dc_quant, L.ac_quant, L.lev[0] + (size_t)f * L.w * L.h + (size_t)blk * 64 + lane * 8, rec);
+  int nz = code_residual<8, Pix, false, kAcRoundInter>(T, lane, s, bp, L.dc_q, L.ac_q, L.dc_quant, L.ac_quant, L.lev[0] + (size_t)f * L.w * L.h + (size_t)blk * 64 + lane * 8, rec);
   store_row<8>(rec_y + row_off(y + lane, L.stride_y) + x, rec);
 
   // chroma: lanes 0-3 code the U block, lanes 4-7 the V block (4x4 each, 4-tap regular filter rows)
@@ -593,7 +593,7 @@ __global__ __launch_bounds__(256) void k_inter_pipe(InterLaunch L) {
     load_row<4>(src_c + row_off(cy0 + cl, L.stride_uv) + cx0, sc);
     AV1MI_GROUP_SYNC();
     mc_row<4, ES, 2, 6>(wc, CWS, imc, cl, mvx & 15, mvy & 15, s_filt[1], bd, pc);
-    nz |= code_residual<4, Pix>(T + pl * 32, cl, sc, pc, L.dc_q, L.ac_q, L.dc_quant, L.ac_quant,
+    nz |= code_residual<4, Pix, false, kAcRoundInter>(T + pl * 32, cl, sc, pc, L.dc_q, L.ac_q, L.dc_quant, L.ac_quant,
                                 L.lev[1 + pl] + (size_t)f * cw * chh + (size_t)blk * 16 + cl * 4, rc);
     store_row<4>(rec_c + row_off(cy0 + cl, L.stride_uv) + cx0, rc);
   }

@@ -6,6 +6,12 @@
 
 namespace av1mi {
 
+// The quantiser's rounding offset for AC coefficients in 1/128 of the step (DC: always 64 = one half, libaom's quantize_fp).  Key
+// frames keep one half; inter frames use 51 = 0.4, a dead zone: -3.6 % BD-rate on the synthetic GOPs (0.336: -2.0 %, 0.25: +1.5 %),
+// while on key frames alone it loses slightly against libaom's curve.  Non-normative; oracle/av1o_pipeline.c
+// (AV1O_AC_ROUND_INTER) is the same constant.
+constexpr int kAcRoundIntra = 64, kAcRoundInter = 51;
+
 __host__ __device__ constexpr int imin(int a, int b) { return a < b ? a : b; }
 __host__ __device__ constexpr int imax(int a, int b) { return a > b ? a : b; }
 

@@ -10,6 +10,10 @@
 int av1o_fwd_txfm2d(const int16_t *resid, int stride, int32_t *coef, int tx_size, int tx_type, int bd);
 int av1o_inv_txfm2d_add(const int32_t *coef, void *dst, int stride, int tx_size, int tx_type, int bd, int libaom_clamps);
 int av1o_quantize(const int32_t *coef, int n, int dc_q, int ac_q, int log_scale, int16_t *levels, int32_t *dqcoef);
+int av1o_quantize_r(const int32_t *coef, int n, int dc_q, int ac_q, int log_scale, int ac_round, int16_t *levels, int32_t *dqcoef);
+/* Encoder policy (non-normative): the quantiser's AC rounding offset in inter frames, in 1/128 of the step: 0.4, a dead zone
+ * (key frames: 64 = one half, libaom's quantize_fp).  -3.6 % BD-rate on the synthetic GOPs; kernels: txfm_cfg.hpp kAcRoundInter. */
+#define AV1O_AC_ROUND_INTER 51
 void av1o_dequantize(const int16_t *levels, int n, int dc_q, int ac_q, int log_scale, int bd, int32_t *dqcoef);
 int av1o_tx_scale(int tx_size);
 int av1o_dc_q(int qindex, int delta, int bd);
@@ -192,7 +196,7 @@ static void code_inter_plane(const void *src, void *rec, int stride, int bd, int
       px_set(rec, bd, (size_t)(y + r) * stride + x + c, pred[r * bs + c]);
     }
   av1o_fwd_txfm2d(resid, bs, coef, tx_size, DCT_DCT, bd);
-  av1o_quantize(coef, n, dc_q, ac_q, 0, levels, NULL);
+  av1o_quantize_r(coef, n, dc_q, ac_q, 0, AV1O_AC_ROUND_INTER, levels, NULL);
   av1o_dequantize(levels, n, dc_q, ac_q, 0, bd, dq);
   av1o_inv_txfm2d_add(dq, (char *)rec + ((size_t)y * stride + x) * bps, stride, tx_size, DCT_DCT, bd, 1);
 }

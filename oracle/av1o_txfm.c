@@ -600,13 +600,14 @@ int av1o_tx_scale(int tx_size) {
  * dc_q/ac_q are the dequant steps.  levels: int16.  dqcoef (may be NULL): int32 dequantised.
  * returns the number of non-zero levels.
  */
-int av1o_quantize(const int32_t *coef, int n, int dc_q, int ac_q, int log_scale, int16_t *levels,
-                  int32_t *dqcoef) {
+/* ac_round: the rounding offset of AC coefficients in 1/128 of the step (64 = one half = libaom's quantize_fp; smaller = a dead
+ * zone, an encoder policy: see av1o_pipeline.c AV1O_AC_ROUND_INTER) */
+int av1o_quantize_r(const int32_t *coef, int n, int dc_q, int ac_q, int log_scale, int ac_round, int16_t *levels, int32_t *dqcoef) {
   int nz = 0;
   for (int i = 0; i < n; i++) {
     const int q = i ? ac_q : dc_q;
     const int quant = (1 << 16) / q;                 /* libaom quant_fp */
-    const int round = av1o_round2((64 * q) >> 7, log_scale); /* libaom round_fp, ROUND_POWER_OF_TWO(.., log_scale) */
+    const int round = av1o_round2(((i ? ac_round : 64) * q) >> 7, log_scale); /* libaom round_fp, ROUND_POWER_OF_TWO(.., log_scale) */
     const int32_t c = coef[i];
     const int sign = c < 0;
     int64_t a = sign ? -(int64_t)c : c;
@@ -625,6 +626,9 @@ int av1o_quantize(const int32_t *coef, int n, int dc_q, int ac_q, int log_scale,
     nz += lvl != 0;
   }
   return nz;
+}
+int av1o_quantize(const int32_t *coef, int n, int dc_q, int ac_q, int log_scale, int16_t *levels, int32_t *dqcoef) {
+  return av1o_quantize_r(coef, n, dc_q, ac_q, log_scale, 64, levels, dqcoef);
 }
 /* spec §7.12.3 dequantisation (normative) == libaom read_coeffs_txb tail: (level*q & 0xFFFFFF) >> shift, clamp. */
 void av1o_dequantize(const int16_t *levels, int n, int dc_q, int ac_q, int log_scale, int bd, int32_t *dqcoef) {

@@ -123,12 +123,12 @@ def test_session_api_misuse_is_reported(ctx, av1mi):
 
 
 @pytest.mark.parametrize("w,h,bd,q,gop,segs", [(192, 128, 8, 110, 4, 2), (136, 72, 10, 40, 3, 3), (64, 64, 8, 30, 2, 1), (328, 184, 8, 200, 2, 5),
-                                                (640, 360, 10, 15, 2, 1), (1920, 1080, 8, 128, 3, 2), (3840, 2160, 10, 128, 3, 2)])
+                                                (640, 360, 10, 50, 2, 1), (1920, 1080, 8, 128, 3, 2), (3840, 2160, 10, 128, 3, 2)])
 def test_gpu_tile_entropy_coder_bytes_equal_the_host_writer(ctx, av1mi, w, h, bd, q, gop, segs):
     """K9 for the real syntax: the AV1 tile entropy coder on the GPU (csrc/av1_entropy_kernels.hip).  With gpu_entropy = 2 the
     session hands out both the symbols and the GPU-coded tile payloads: the temporal unit assembled around the GPU's payloads
     must be byte-identical to the one the host writer makes of the symbols — key and inter frames, partial superblocks at the
-    frame edge (1080 and 2160 are not multiples of 64), 8 and 10 bit, a single tile, fine (15) and coarse (200) quantisers, a
+    frame edge (1080 and 2160 are not multiples of 64), 8 and 10 bit, a single tile, fine (30 / 50) and coarse (200) quantisers, a
     tile count that is not a multiple of the coder's groups of 64, full 1080p / 4K sizes — and dav1d (when present) decodes it to
     the GPU's reference frames."""
     import av1stream
