@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void k_me_int(InterLaunch L) {
   const int per = NP * NG;                         // (dy triple, dx group) items per block
   int16_t *mvs = L.mvs + (size_t)f * bw * bh * 2;
   // A lane scores THREE vertically adjacent displacements of four horizontal ones: they share six of their eight window
-  // rows, so ten rows of three dwords and ONE copy of the source block are read for 48 QSADs (pairs: nine rows and a source
+  // rows, so ten rows of three dwords and ONE copy of the source block's even rows are read for 24 QSADs (pairs: nine rows and a source
   // copy per 32; the QSADs are half of the kernel's cycles, the reads and the per-item arithmetic the other half, and +-8 is
   // 17 = 6 x 3 - 1 rows: as little padding as pairs).  The 16 blocks of a wave form ONE item space (16 x per): with +-8 a
   // block has 30 items, which alone would leave a 64-lane wave half empty; the per-block minimum is an LDS atomic instead of a
@@ -120,9 +120,10 @@ __global__ __launch_bounds__(256) void k_me_int(InterLaunch L) {
         const int dp = (int)(((float)t + 0.5f) * inv_ng), g = t - __mul24(dp, NG);    // dy = 3 dp - R + {0, 1, 2}, dx0 = -R4 + 4 g
         const uint8_t *p = win + __mul24(by * 8 + HD * dp, WS) + bx * 8 + 4 * g;
         const uint8_t *s = srct + (by * 8) * 64 + bx * 8;
-        uint2 sr[8];
+        // the SAD runs over the block's EVEN rows (policy; the oracle's block_sad8): half the QSADs, the same vectors on the test clips
+        uint2 sr[4];
 #pragma unroll
-        for (int r = 0; r < 8; r++) sr[r] = *reinterpret_cast<const uint2 *>(s + r * 64);
+        for (int r = 0; r < 4; r++) sr[r] = *reinterpret_cast<const uint2 *>(s + 2 * r * 64);
         unsigned long long acc[HD] = { 0, 0, 0 };
 #pragma unroll
         for (int r = 0; r < 8 + HD - 1; r++) {
@@ -131,9 +132,9 @@ __global__ __launch_bounds__(256) void k_me_int(InterLaunch L) {
           const unsigned long long w12 = (unsigned long long)q[1] | ((unsigned long long)q[2] << 32);
 #pragma unroll
           for (int h = 0; h < HD; h++)
-            if (r - h >= 0 && r - h < 8) {
-              acc[h] = __builtin_amdgcn_qsad_pk_u16_u8(w01, sr[r - h].x, acc[h]);
-              acc[h] = __builtin_amdgcn_qsad_pk_u16_u8(w12, sr[r - h].y, acc[h]);
+            if (r - h >= 0 && r - h < 8 && ((r - h) & 1) == 0) {
+              acc[h] = __builtin_amdgcn_qsad_pk_u16_u8(w01, sr[(r - h) >> 1].x, acc[h]);
+              acc[h] = __builtin_amdgcn_qsad_pk_u16_u8(w12, sr[(r - h) >> 1].y, acc[h]);
             }
         }
         // key = SAD << 10 | rank: (0,0) ranks first (0), the others in raster order (1 + (dy + R) NC + dx + R < 1024); ties keep

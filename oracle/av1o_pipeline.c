@@ -161,7 +161,7 @@ int av1o_intra_encode_frame(const void *src_y, const void *src_u, const void *sr
  * Inter (P) frame encoder loop (BASELINE config 3), the checker of k_me_int + k_inter_pipe.
  * Encoder policy (ours, non-normative): every block bs x bs (8) is inter-predicted from ONE reference frame
  * (the previous reconstructed, loop-filtered frame); integer full search +-range around the co-located block
- * by SAD of the 8 most significant bits ((0,0) first, then raster order, strict improvement), then one half-pel refinement round
+ * by SAD of the 8 most significant bits on the block's even rows ((0,0) first, then raster order, strict improvement), then one half-pel refinement round
  * scored with the bilinear filter and one quarter-pel round scored with the regular 8-tap filter (8 neighbours each, fixed
  * order, strict improvement); the prediction itself always uses the regular 8-tap filter; chroma uses the same
  * vector; DCT_DCT residual coding as in the intra loop.  The prediction arithmetic is av1o_mc_block (spec 7.11.3.4).
@@ -170,10 +170,11 @@ int av1o_intra_encode_frame(const void *src_y, const void *src_u, const void *sr
 int av1o_mc_block(const void *ref, int stride, int plane_w, int plane_h, int bd, int x, int y, int w, int h, int mvx,
                   int mvy, int filt_x, int filt_y, uint16_t *pred);
 
-/* integer-search cost: SAD on the 8 most significant bits of source and prediction (policy of k_me_int) */
+/* integer-search cost: SAD on the 8 most significant bits of source and prediction, over the EVEN rows of the block (policy of
+ * k_me_int; libaom's "downsampled SAD" speed feature: on the synthetic GOPs the vectors, bytes and PSNR do not change at all) */
 static long block_sad8(const void *src, int stride, int bd, int x, int y, int bs, const uint16_t *pred) {
   long s = 0;
-  for (int r = 0; r < bs; r++)
+  for (int r = 0; r < bs; r += 2)
     for (int c = 0; c < bs; c++)
       s += labs((long)(px_get(src, bd, (size_t)(y + r) * stride + x + c) >> (bd - 8)) - (pred[r * bs + c] >> (bd - 8)));
   return s;
