@@ -12,6 +12,7 @@
 // symbols of frame t the GPU already works on frames t + 1 and t + 2 (three batches in flight).
 #include "backend.hpp"
 #include <sys/stat.h>
+#include <unistd.h>
 #include <cstdio>
 #include <cstring>
 #include <thread>
@@ -57,12 +58,24 @@ bool y4m_open(const std::string &path, Y4m *y, std::string *err) {
   return true;
 }
 // frame `idx` into the three plane pointers; false on a malformed or truncated frame
-bool y4m_read(Y4m *y, long idx, unsigned char *Y, unsigned char *U, unsigned char *V) {
-  if (fseeko(y->f, (off_t)y->hdr_len + (off_t)idx * (off_t)(6 + y->frame_bytes), SEEK_SET)) return false;
+// frame idx -> the three planes; pread, so the segments of a batch are read by threads of their own (a single thread copies
+// ~5 GB/s out of the page cache: 215 frames/s at 4K 10-bit, one eighth of what the GPU takes)
+bool y4m_read(const Y4m *y, long idx, unsigned char *Y, unsigned char *U, unsigned char *V) {
+  const int fd = fileno(y->f);
+  off_t off = (off_t)y->hdr_len + (off_t)idx * (off_t)(6 + y->frame_bytes);
+  auto rd = [&](void *dst, size_t n) {
+    unsigned char *p = (unsigned char *)dst;
+    while (n) {
+      const ssize_t k = pread(fd, p, n, off);
+      if (k <= 0) return false;
+      p += k; off += k; n -= (size_t)k;
+    }
+    return true;
+  };
   char tag[6];
-  if (fread(tag, 1, 6, y->f) != 6 || memcmp(tag, "FRAME\n", 6)) return false;
+  if (!rd(tag, 6) || memcmp(tag, "FRAME\n", 6)) return false;
   const size_t ny = y->frame_bytes * 2 / 3, nc = ny / 4;
-  return fread(Y, 1, ny, y->f) == ny && fread(U, 1, nc, y->f) == nc && fread(V, 1, nc, y->f) == nc;
+  return rd(Y, ny) && rd(U, nc) && rd(V, nc);
 }
 
 }  // namespace
@@ -150,12 +163,19 @@ int RunBackend(const BackendJob &job, std::string *err) {
       for (int t = 0; t < T; t++) {
         void *py, *pu, *pv;
         CHK(av1mi_gop_acquire_input(gop, &py, &pu, &pv));
+        // a shorter last GOP / fewer GOPs than segments: the slot keeps stale pixels, its output is dropped
+        std::vector<std::thread> readers;
+        std::vector<char> ok((size_t)S, 1);
         for (int s = 0; s < S; s++) {
-          if (!exists(s, t)) continue;     // a shorter last GOP / fewer GOPs than segments: the slot keeps stale pixels, its output is dropped
-          if (!y4m_read(&y, (g0 + s) * G + t, (unsigned char *)py + fy * s, (unsigned char *)pu + fc * s, (unsigned char *)pv + fc * s)) {
-            *err = job.input + ": Invalid data found when processing input (truncated frame)"; code = 1; goto done;
-          }
+          if (!exists(s, t)) continue;
+          auto job_s = [&, s]() {
+            ok[(size_t)s] = y4m_read(&y, (g0 + s) * G + t, (unsigned char *)py + fy * s, (unsigned char *)pu + fc * s, (unsigned char *)pv + fc * s);
+          };
+          if (S > 1) readers.emplace_back(job_s); else job_s();
         }
+        for (auto &th : readers) th.join();
+        for (int s = 0; s < S; s++)
+          if (!ok[(size_t)s]) { *err = job.input + ": Invalid data found when processing input (truncated frame)"; code = 1; goto done; }
         CHK(av1mi_gop_submit(gop, t == 0 ? 0 : 1));
         if (t >= lag && !code_oldest(t - lag)) { code = 2; goto done; }    // the GPU works on the frames after it meanwhile
       }
