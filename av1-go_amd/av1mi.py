@@ -69,7 +69,8 @@ class InterJob(C.Structure):
                 ("d_ref_y", C.c_void_p), ("d_ref_u", C.c_void_p), ("d_ref_v", C.c_void_p),
                 ("d_rec_y", C.c_void_p), ("d_rec_u", C.c_void_p), ("d_rec_v", C.c_void_p),
                 ("d_lev_y", C.c_void_p), ("d_lev_u", C.c_void_p), ("d_lev_v", C.c_void_p),
-                ("d_mvs", C.c_void_p), ("d_skip", C.c_void_p)]
+                ("d_mvs", C.c_void_p), ("d_skip", C.c_void_p),
+                ("d_ref_alt_y", C.c_void_p), ("d_ref_alt_u", C.c_void_p), ("d_ref_alt_v", C.c_void_p), ("d_ref_sel", C.c_void_p)]
 
 
 class EntropyJob(C.Structure):
@@ -94,7 +95,7 @@ class GopFrame(C.Structure):
     _fields_ = [("params", FrameParams), ("segments", C.c_int), ("blocks_per_frame", C.c_size_t), ("y_mode", C.c_void_p),
                 ("uv_mode", C.c_void_p), ("mv", C.c_void_p), ("skip", C.c_void_p), ("lev_y", C.c_void_p), ("lev_u", C.c_void_p),
                 ("lev_v", C.c_void_p), ("tiles_per_frame", C.c_int), ("tile_size", C.c_void_p), ("tile_payload", C.c_void_p),
-                ("payload_bytes", C.c_uint64)]
+                ("payload_bytes", C.c_uint64), ("lr_on", C.c_void_p)]
 
 
 def policy_frame_params(base_q_idx, bit_depth, frame_type):
@@ -155,7 +156,7 @@ class GopSession:
         """dict of numpy views (valid until the next submit) + params"""
         f = self.collect_raw()
         S, nb = f.segments, f.blocks_per_frame
-        out = dict(params=f.params, frame_type=f.params.frame_type)
+        out = dict(params=f.params, frame_type=f.params.frame_type, lr_on=_view(f.lr_on, (S, 3), np.uint8))      # restoration on / off per segment and plane
         if f.lev_y:
             out.update(lev_y=_view(f.lev_y, (S, nb, 8, 8), np.int16), lev_u=_view(f.lev_u, (S, nb, 4, 4), np.int16),
                        lev_v=_view(f.lev_v, (S, nb, 4, 4), np.int16))
@@ -387,6 +388,17 @@ class Context:
     def lr_frames(self, d_cdef, d_dbl, d_out, stride, w, h, bd, ss, unit_size, d_units, unit_frame_stride, nframes):
         self._chk(self.lib.av1mi_lr_frames(self.h, C.c_void_p(d_cdef.ptr), C.c_void_p(d_dbl.ptr), C.c_void_p(d_out.ptr), stride, w, h, bd,
                                            int(ss), unit_size, C.c_void_p(d_units.ptr), C.c_size_t(unit_frame_stride), nframes))
+
+    def lr_decide_scratch_bytes(self, h, ss, nframes):
+        self.lib.av1mi_lr_decide_scratch_bytes.restype = C.c_size_t
+        return int(self.lib.av1mi_lr_decide_scratch_bytes(h, int(ss), nframes))
+
+    def lr_frames_decide(self, d_cdef, d_dbl, d_out, stride, w, h, bd, ss, unit_size, d_units, unit_frame_stride, nframes, d_orig, d_scratch, d_on,
+                         on_offset=0, on_stride=1):
+        """restoration + the per-frame ON / OFF decision against the source d_orig; d_on: uint8 buffer, entry on_offset + f * on_stride"""
+        self._chk(self.lib.av1mi_lr_frames_decide(self.h, C.c_void_p(d_cdef.ptr), C.c_void_p(d_dbl.ptr), C.c_void_p(d_out.ptr), stride, w, h, bd,
+                                                  int(ss), unit_size, C.c_void_p(d_units.ptr), C.c_size_t(unit_frame_stride), nframes,
+                                                  C.c_void_p(d_orig.ptr), C.c_void_p(d_scratch.ptr), C.c_void_p(d_on.ptr + on_offset), int(on_stride)))
 
     # ---- fused intra-only segment pipeline
     def intra_encode(self, job):

@@ -124,7 +124,7 @@ def assemble_temporal_unit(width, height, bit_depth, base_q_idx, payloads, sizes
 def session_frame_unit_gpu(width, height, bit_depth, frame, seg, with_sequence_header=None):
     """the temporal unit of segment `seg` of a collected batch whose tiles were entropy-coded on the GPU (gpu_entropy != 0)"""
     p = frame["params"]
-    hdr = header_from_params(p, width, height)
+    hdr = header_from_params(p, width, height, frame["lr_on"][seg])
     nt = frame["tiles_per_frame"]
     sizes = frame["tile_size"][seg * nt:(seg + 1) * nt]
     start = int(frame["tile_size"][:seg * nt].sum(dtype=np.uint64))
@@ -133,21 +133,24 @@ def session_frame_unit_gpu(width, height, bit_depth, frame, seg, with_sequence_h
     return assemble_temporal_unit(width, height, bit_depth, p.base_q_idx, pay, sizes, with_sequence_header=sh, **hdr)
 
 
-def header_from_params(p, width, height):
-    """keyword arguments of temporal_unit() for a frame whose filter parameters are an av1mi_frame_params (GOP session policy)"""
+def header_from_params(p, width, height, lr_on=None):
+    """keyword arguments of temporal_unit() for a frame whose filter parameters are an av1mi_frame_params (GOP session policy);
+    lr_on: the encoder's restoration ON / OFF decision per plane (the session's frame["lr_on"][segment]; None = the policy's types)"""
     ur = lambda n: max(1, (n + p.lr_unit_size // 2) // p.lr_unit_size)
     uy = np.tile(np.array(list(p.lr_unit_y), np.int8), (ur(height), ur(width), 1))
     uc = np.tile(np.array(list(p.lr_unit_uv), np.int8), (ur(height // 2), ur(width // 2), 1))
     shift = {64: 0, 128: 1, 256: 2}[p.lr_unit_size]
+    types = [int(p.lr_unit_y[0]), int(p.lr_unit_uv[0]), int(p.lr_unit_uv[0])]
+    if lr_on is not None:
+        types = [t if int(k) else 0 for t, k in zip(types, lr_on)]
     return dict(frame_type=p.frame_type, lf_level=tuple(p.lf_level), lf_sharpness=p.lf_sharpness, cdef_damping=p.cdef_damping,
-                cdef_y=(p.cdef_y,), cdef_uv=(p.cdef_uv,), lr_type=(int(p.lr_unit_y[0]), int(p.lr_unit_uv[0]), int(p.lr_unit_uv[0])),
-                lr_unit_shift=shift, lr_uv_shift=0, lr_units=(uy, uc, uc))
+                cdef_y=(p.cdef_y,), cdef_uv=(p.cdef_uv,), lr_type=tuple(types), lr_unit_shift=shift, lr_uv_shift=0, lr_units=(uy, uc, uc))
 
 
 def session_frame_unit(width, height, bit_depth, frame, seg, with_sequence_header=None, threads=1):
     """the temporal unit of segment `seg` of a collected GOP-session batch (av1mi.GopSession.collect())"""
     p = frame["params"]
-    hdr = header_from_params(p, width, height)
+    hdr = header_from_params(p, width, height, frame["lr_on"][seg])
     if p.frame_type == 0:
         sym = dict(y_mode=frame["y_mode"][seg], uv_mode=frame["uv_mode"][seg])
     else:

@@ -38,6 +38,7 @@ struct Av1EntLaunch {
   uint8_t *out; uint64_t out_cap;
   const uint16_t *cdf_image; int cdf_words;   // default slot image of this frame type / q category
   SlotTable tab;
+  const uint8_t *lr_on_frame;   // optional: [frame * 3 + plane], 0 = restoration of the plane is off in that frame
 };
 
 __device__ __forceinline__ FrameView frame_view(const Av1EntLaunch &L, int f) {
@@ -47,6 +48,7 @@ __device__ __forceinline__ FrameView frame_view(const Av1EntLaunch &L, int f) {
   else { v.mv += nb * 2 * f; v.skip += nb * f; }
   v.lev_y += nb * 64 * f; v.lev_u += nb * 16 * f; v.lev_v += nb * 16 * f;
   v.info = L.info + nb * f;
+  if (L.lr_on_frame) for (int p = 0; p < 3; p++) v.lr_on[p] = v.lr_on[p] && L.lr_on_frame[f * 3 + p];
   return v;
 }
 
@@ -427,6 +429,7 @@ int av1mi::av1_entropy_submit(av1mi_ctx *ctx, const av1mi_av1_entropy_job *j, hi
   L.tile_size = j->d_tile_size; L.out = j->d_out; L.out_cap = j->out_cap;
   L.status = (uint32_t *)(j->d_total + 1);
   L.cdf_image = st->d_image[key][qcat]; L.cdf_words = st->image_words[key]; L.tab = st->tab[key];
+  L.lr_on_frame = j->d_lr_on;
 #define E_HIP(call) do { const hipError_t e_ = (call); if (e_ != hipSuccess) return av1mi::ctx_fail(ctx, AV1MI_E_DEVICE, "%s: %s", #call, hipGetErrorString(e_)); } while (0)
   const bool two = front != back;
   if (two) {

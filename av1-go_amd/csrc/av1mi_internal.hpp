@@ -95,8 +95,13 @@ struct LrLaunch {
   const void *cdef, *dbl; void *out;
   int stride, w, h, bd, ss, unit_size, nframes;
   const int8_t *units; size_t unit_frame_stride;   // 8 bytes per unit; units between frames (0 = shared)
+  // the on/off decision (orig != nullptr): the source plane, and per (frame, stripe) two 64-bit sums: squared error of the restored
+  // samples, of the CDEF samples (zeroed by the caller; sse_stripes = lr_stripes(h, ss))
+  const void *orig; unsigned long long *sse; int sse_stripes;
 };
 hipError_t launch_lr(const LrLaunch &L, hipStream_t s);
+int lr_stripes(int h, int ss);
+hipError_t launch_lr_decide(const unsigned long long *sse, int nframes, int stripes, uint8_t *on, int on_stride, hipStream_t s);
 
 // inter (P-frame) pipeline over the t-th frames of a batch of segments, stacked like the intra job
 struct InterLaunch {
@@ -104,6 +109,7 @@ struct InterLaunch {
   int16_t *mvs; uint8_t *skip;
   int w, h, stride_y, stride_uv, bd, nframes, dc_q, ac_q, range;
   int dc_quant, ac_quant;   // (1 << 16) / step (libaom quant_fp): computed once by the host, see block_code.hpp
+  const void *ref_alt[3]; const uint8_t *ref_sel;   // optional: ref_sel[f * 3 + p] == 0 -> frame f predicts plane p from ref_alt[p]
 };
 hipError_t launch_me_int(const InterLaunch &L, hipStream_t s);
 hipError_t launch_inter_pipe(const InterLaunch &L, hipStream_t s);

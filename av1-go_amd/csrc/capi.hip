@@ -431,8 +431,32 @@ int av1mi_lr_frames(av1mi_ctx *ctx, const void *d_cdef, const void *d_deblocked,
     return fail(ctx, AV1MI_E_INVAL, "restoration unit size %d not allowed", unit_size);
   if (nframes < 0 || nframes > 65535) return fail(ctx, AV1MI_E_INVAL, "nframes %d out of range", nframes);
   if (nframes == 0) return AV1MI_OK;
-  av1mi::LrLaunch L = { d_cdef, d_deblocked, d_out, stride, w, h, bd, subsampled ? 1 : 0, unit_size, nframes, d_units, unit_frame_stride };
+  av1mi::LrLaunch L = { d_cdef, d_deblocked, d_out, stride, w, h, bd, subsampled ? 1 : 0, unit_size, nframes, d_units, unit_frame_stride, nullptr, nullptr, 0 };
   { ProfScope ps(ctx, AV1MI_K_LR); HIP_TRY(ctx, av1mi::launch_lr(L, ctx->stream)); }
+  return AV1MI_OK;
+}
+
+size_t av1mi_lr_decide_scratch_bytes(int h, int subsampled, int nframes) {
+  return (size_t)(nframes > 0 ? nframes : 0) * (size_t)av1mi::lr_stripes(h, subsampled ? 1 : 0) * 16;
+}
+int av1mi_lr_frames_decide(av1mi_ctx *ctx, const void *d_cdef, const void *d_deblocked, void *d_out, int stride, int w, int h, int bd, int subsampled,
+                           int unit_size, const int8_t *d_units, size_t unit_frame_stride, int nframes, const void *d_orig, void *d_scratch, uint8_t *d_on,
+                           int on_stride) {
+  BIND(ctx);
+  if (!d_cdef || !d_deblocked || !d_out || !d_units || !d_orig || !d_scratch || !d_on || d_out == d_cdef || d_out == d_deblocked)
+    return fail(ctx, AV1MI_E_INVAL, "null or aliased device pointer");
+  if (bd != 8 && bd != 10) return fail(ctx, AV1MI_E_INVAL, "bit depth %d not supported (8 or 10)", bd);
+  if (w <= 0 || h <= 0 || stride < w) return fail(ctx, AV1MI_E_INVAL, "bad plane geometry %dx%d stride %d", w, h, stride);
+  if (!(unit_size == 64 || unit_size == 128 || unit_size == 256 || (unit_size == 32 && subsampled)))
+    return fail(ctx, AV1MI_E_INVAL, "restoration unit size %d not allowed", unit_size);
+  if (nframes < 0 || nframes > 65535 || on_stride < 1) return fail(ctx, AV1MI_E_INVAL, "nframes %d / on_stride %d out of range", nframes, on_stride);
+  if (nframes == 0) return AV1MI_OK;
+  const int stripes = av1mi::lr_stripes(h, subsampled ? 1 : 0);
+  HIP_TRY(ctx, hipMemsetAsync(d_scratch, 0, av1mi_lr_decide_scratch_bytes(h, subsampled, nframes), ctx->stream));
+  av1mi::LrLaunch L = { d_cdef, d_deblocked, d_out, stride, w, h, bd, subsampled ? 1 : 0, unit_size, nframes, d_units, unit_frame_stride, d_orig,
+                        (unsigned long long *)d_scratch, stripes };
+  { ProfScope ps(ctx, AV1MI_K_LR); HIP_TRY(ctx, av1mi::launch_lr(L, ctx->stream)); }
+  HIP_TRY(ctx, av1mi::launch_lr_decide((const unsigned long long *)d_scratch, nframes, stripes, d_on, on_stride, ctx->stream));
   return AV1MI_OK;
 }
 
@@ -478,6 +502,8 @@ int av1mi_inter_encode(av1mi_ctx *ctx, const av1mi_inter_job *j) {
   av1mi::InterLaunch L;
   L.src[0] = j->d_src_y; L.src[1] = j->d_src_u; L.src[2] = j->d_src_v;
   L.ref[0] = j->d_ref_y; L.ref[1] = j->d_ref_u; L.ref[2] = j->d_ref_v;
+  L.ref_alt[0] = j->d_ref_alt_y; L.ref_alt[1] = j->d_ref_alt_u; L.ref_alt[2] = j->d_ref_alt_v; L.ref_sel = j->d_ref_sel;
+  if (L.ref_sel && (!L.ref_alt[0] || !L.ref_alt[1] || !L.ref_alt[2])) return fail(ctx, AV1MI_E_INVAL, "d_ref_sel without d_ref_alt_*");
   L.rec[0] = j->d_rec_y; L.rec[1] = j->d_rec_u; L.rec[2] = j->d_rec_v;
   L.lev[0] = j->d_lev_y; L.lev[1] = j->d_lev_u; L.lev[2] = j->d_lev_v;
   L.mvs = j->d_mvs; L.skip = j->d_skip;

@@ -4,7 +4,7 @@
 // to its FFmpeg child (internal/ffmpeg/transcode.go:120,194); the caller it serves is internal/daemon/daemon.go:101.
 //
 // Streams.  The context's stream runs the kernels; the session adds an upload stream and a download stream.  Per batch:
-//   up:   wait slot.kernel_done (the kernel that last read this slot's source)  -> H2D of the three source planes -> uploaded
+//   up:   wait slot.filters_done (the kernels that last read this slot's source)  -> H2D of the three source planes -> uploaded
 //   main: wait uploaded -> k_intra_pipe | k_me_int + k_inter_pipe -> symbols_ready -> deblock x3, CDEF, LR x3 -> reference
 //   down: wait symbols_ready -> D2H of the symbols into pinned memory -> downloaded
 //   side: (GPU entropy coding) wait symbols_ready -> k_av1_* -> payloads gathered into the slot's pinned buffer -> ent_done
@@ -52,8 +52,10 @@ struct Slot {
   void *d_lev[3] = { nullptr, nullptr, nullptr }, *h_lev[3] = { nullptr, nullptr, nullptr };
   void *d_modes[2] = { nullptr, nullptr }, *h_modes[2] = { nullptr, nullptr };
   void *d_mv = nullptr, *h_mv = nullptr, *d_skip = nullptr, *h_skip = nullptr;
-  hipEvent_t uploaded = nullptr, kernel_done = nullptr, downloaded = nullptr;
+  hipEvent_t uploaded = nullptr, kernel_done = nullptr, filters_done = nullptr, downloaded = nullptr;
   bool upload_pending = false, kernel_pending = false;
+  // restoration on / off per (segment, plane), decided by the GPU against the source (k_lr + k_lr_decide): device + pinned mirror
+  void *d_lr_on = nullptr, *h_lr_on = nullptr;
   int frame_type = 0;
   // GPU entropy coding (gpu_entropy != 0): coded tile payloads (pinned host memory, written by the GPU) + sizes (device + pinned mirror)
   void *h_ent_out = nullptr, *d_tile_size = nullptr, *h_tile_size = nullptr, *d_total = nullptr, *h_total = nullptr;
@@ -73,6 +75,8 @@ struct av1mi_gop {
   void *d_rec[3] = {}, *d_dbl[3] = {}, *d_cdef[3] = {}, *d_ref[3] = {};
   void *d_mi[2][2] = {};                       // [key / inter][luma / chroma] deblocking mode-info maps (one frame, shared by the batch)
   void *d_cdef_sb[2] = {}, *d_lr[2] = {}, *d_zero_skip = nullptr;
+  void *d_lr_scratch[3] = {};                  // the restoration decision's partial sums, per plane
+  int last = 0;                                // slot of the most recent batch (its d_lr_on selects the next batch's references)
   av1mi_frame_params params[2];                // key, inter
   size_t ent_cap = 0; int tiles = 0;           // GPU entropy coding: payload capacity of a batch, tiles per frame
   long submitted = 0, collected = 0;           // batches
@@ -125,6 +129,8 @@ int setup(av1mi_gop *g) {
     G_TRY(host_alloc(g, &s.h_skip, g->nb)); G_TRY(dev_alloc(g, &s.d_skip, g->nb));
     G_HIP(hipEventCreateWithFlags(&s.uploaded, hipEventDisableTiming));
     G_HIP(hipEventCreateWithFlags(&s.kernel_done, hipEventDisableTiming));
+    G_HIP(hipEventCreateWithFlags(&s.filters_done, hipEventDisableTiming));
+    G_TRY(dev_alloc(g, &s.d_lr_on, (size_t)S * 3)); G_TRY(host_alloc(g, &s.h_lr_on, (size_t)S * 3));
     G_HIP(hipEventCreateWithFlags(&s.downloaded, hipEventDisableTiming));
     if (c.gpu_entropy) {
       g->tiles = ((w + 63) / 64) * ((h + 63) / 64);
@@ -139,6 +145,7 @@ int setup(av1mi_gop *g) {
     const size_t n = (p ? g->nc : g->ny) * g->bps;
     G_TRY(dev_alloc(g, &g->d_rec[p], n)); G_TRY(dev_alloc(g, &g->d_dbl[p], n)); G_TRY(dev_alloc(g, &g->d_cdef[p], n)); G_TRY(dev_alloc(g, &g->d_ref[p], n));
   }
+  for (int p = 0; p < 3; p++) G_TRY(dev_alloc(g, &g->d_lr_scratch[p], av1mi_lr_decide_scratch_bytes(p ? h / 2 : h, p > 0, S)));
   G_TRY(dev_alloc(g, &g->d_zero_skip, g->nb));
   G_TRY(av1mi_memset(g->ctx, g->d_zero_skip, 0, g->nb));
   // constant side information: one map per frame type, shared by every frame of a batch (frame stride 0)
@@ -210,6 +217,7 @@ void av1mi_gop_close(av1mi_gop *g) {
   for (Slot &s : g->slot) {
     if (s.uploaded) (void)hipEventDestroy(s.uploaded);
     if (s.kernel_done) (void)hipEventDestroy(s.kernel_done);
+    if (s.filters_done) (void)hipEventDestroy(s.filters_done);
     if (s.downloaded) (void)hipEventDestroy(s.downloaded);
     if (s.ent_done) (void)hipEventDestroy(s.ent_done);
   }
@@ -261,8 +269,8 @@ int av1mi_gop_submit(av1mi_gop *g, int frame_type) {
   const int w = c.width, h = c.height, S = c.segments, bd = c.bit_depth;
   Slot &s = g->slot[g->submitted % kSlots];
   hipStream_t main = av1mi::ctx_stream(g->ctx);
-  // upload: not before the kernel that last read this slot's source has finished
-  if (s.kernel_pending) G_HIP(hipStreamWaitEvent(g->up, s.kernel_done, 0));
+  // upload: not before the kernels that last read this slot's source have finished (the restoration decision is the last reader)
+  if (s.kernel_pending) G_HIP(hipStreamWaitEvent(g->up, s.filters_done, 0));
   for (int p = 0; p < 3; p++) G_HIP(hipMemcpyAsync(s.d_src[p], s.h_src[p], (p ? g->nc : g->ny) * g->bps, hipMemcpyHostToDevice, g->up));
   G_HIP(hipEventRecord(s.uploaded, g->up));
   s.upload_pending = true;
@@ -287,33 +295,14 @@ int av1mi_gop_submit(av1mi_gop *g, int frame_type) {
     j.d_rec_y = g->d_rec[0]; j.d_rec_u = g->d_rec[1]; j.d_rec_v = g->d_rec[2];
     j.d_lev_y = (int16_t *)s.d_lev[0]; j.d_lev_u = (int16_t *)s.d_lev[1]; j.d_lev_v = (int16_t *)s.d_lev[2];
     j.d_mvs = (int16_t *)s.d_mv; j.d_skip = (uint8_t *)s.d_skip;
+    // per segment and plane: the restored plane of the previous frame, or its CDEF output where restoration was switched off
+    j.d_ref_alt_y = g->d_cdef[0]; j.d_ref_alt_u = g->d_cdef[1]; j.d_ref_alt_v = g->d_cdef[2];
+    j.d_ref_sel = (const uint8_t *)g->slot[g->last].d_lr_on;
     G_TRY(av1mi_inter_encode(g->ctx, &j));
   }
   G_HIP(hipEventRecord(s.kernel_done, main));
   s.kernel_pending = true;
   s.frame_type = frame_type;
-  if (c.gpu_entropy) {
-    // the AV1 tile entropy coder beside the filters and the next batch's block pipeline: tokenizer + chains on the context's
-    // side stream, the serial range coder on its back stream (so the next batch's tokenizer does not wait for it)
-    hipStream_t side = av1mi::ctx_side_stream(g->ctx), back = av1mi::ctx_back_stream(g->ctx);
-    if (!side || !back) return av1mi::ctx_fail(g->ctx, AV1MI_E_DEVICE, "no side stream");
-    G_HIP(hipStreamWaitEvent(side, s.kernel_done, 0));
-    const av1mi_frame_params &P = g->params[frame_type];
-    av1mi_av1_entropy_job ej;
-    memset(&ej, 0, sizeof(ej));
-    ej.width = w; ej.height = h; ej.nframes = S; ej.key = frame_type == 0; ej.base_q_idx = c.base_q_idx;
-    ej.d_lev_y = (const int16_t *)s.d_lev[0]; ej.d_lev_u = (const int16_t *)s.d_lev[1]; ej.d_lev_v = (const int16_t *)s.d_lev[2];
-    ej.d_modes_y = (const uint8_t *)s.d_modes[0]; ej.d_modes_uv = (const uint8_t *)s.d_modes[1];
-    ej.d_mvs = (const int16_t *)s.d_mv; ej.d_skip = (const uint8_t *)s.d_skip;
-    ej.lr_on[0] = P.lr_unit_y[0] == 1; ej.lr_on[1] = ej.lr_on[2] = P.lr_unit_uv[0] == 1;
-    memcpy(ej.lr_unit_y, P.lr_unit_y, 8); memcpy(ej.lr_unit_uv, P.lr_unit_uv, 8);
-    ej.d_out = (uint8_t *)s.h_ent_out; ej.out_cap = g->ent_cap; ej.d_tile_size = (uint32_t *)s.d_tile_size; ej.d_total = (uint64_t *)s.d_total;
-    G_TRY(av1mi::av1_entropy_submit(g->ctx, &ej, side, back));
-    G_HIP(hipMemcpyAsync(s.h_tile_size, s.d_tile_size, (size_t)g->tiles * S * 4, hipMemcpyDeviceToHost, back));
-    G_HIP(hipMemcpyAsync(s.h_total, s.d_total, 16, hipMemcpyDeviceToHost, back));
-    G_HIP(hipEventRecord(s.ent_done, back));
-    s.ent_pending = true;
-  }
   // symbols -> pinned host memory, beside the filters.  Not when the GPU codes the tiles (gpu_entropy == 1): the host then needs
   // the payloads only (and a fifth busy stream would share a hardware queue with one of the other four)
   s.symbols_down = c.gpu_entropy != 1;
@@ -321,9 +310,8 @@ int av1mi_gop_submit(av1mi_gop *g, int frame_type) {
     G_HIP(hipStreamWaitEvent(g->down, s.kernel_done, 0));
     for (int p = 0; p < 3; p++) G_HIP(hipMemcpyAsync(s.h_lev[p], s.d_lev[p], (p ? g->nc : g->ny) * 2, hipMemcpyDeviceToHost, g->down));
     G_TRY(download_modes(g, s, g->down));
-    G_HIP(hipEventRecord(s.downloaded, g->down));
   }
-  // in-loop filters: reconstruction -> reference of the next frame
+  // in-loop filters: reconstruction -> what the next frame predicts from
   const av1mi_frame_params &P = g->params[frame_type];
   for (int p = 0; p < 3; p++) {
     const int pw = p ? w / 2 : w, ph = p ? h / 2 : h;
@@ -337,16 +325,47 @@ int av1mi_gop_submit(av1mi_gop *g, int frame_type) {
   cj.d_dst_y = g->d_cdef[0]; cj.d_dst_u = g->d_cdef[1]; cj.d_dst_v = g->d_cdef[2];
   cj.d_sb_strength = (const uint8_t *)g->d_cdef_sb[0]; cj.sb_frame_stride = 0;
   // key frames are coded with skip = 0 everywhere (no block is exempt from CDEF); P frames: the kernel's skip flags, per frame
+  // (the slot's next inter kernel is kSlots batches away and ordered behind this CDEF on the main stream, nothing else writes them)
   cj.d_skip8 = (const uint8_t *)(frame_type == 0 ? g->d_zero_skip : s.d_skip); cj.skip_frame_stride = frame_type == 0 ? 0 : (size_t)(w / 8) * (h / 8);
   G_TRY(av1mi_cdef_frames(g->ctx, &cj));
+  // loop restoration of every frame, and the decision per segment and plane whether it stays ON (it must lower the squared error
+  // against the source): d_ref always receives the restored planes, the next batch's kernels choose between d_ref and d_cdef
   for (int p = 0; p < 3; p++) {
     const int pw = p ? w / 2 : w, ph = p ? h / 2 : h;
-    G_TRY(av1mi_lr_frames(g->ctx, g->d_cdef[p], g->d_dbl[p], g->d_ref[p], pw, pw, ph, bd, p > 0, P.lr_unit_size, (const int8_t *)g->d_lr[p > 0], 0, S));
+    G_TRY(av1mi_lr_frames_decide(g->ctx, g->d_cdef[p], g->d_dbl[p], g->d_ref[p], pw, pw, ph, bd, p > 0, P.lr_unit_size, (const int8_t *)g->d_lr[p > 0], 0, S,
+                                 s.d_src[p], g->d_lr_scratch[p], (uint8_t *)s.d_lr_on + p, 3));
   }
-  if (frame_type == 1) {
-    // the skip flags are read by CDEF after symbols_ready: the slot's next inter kernel is kSlots batches away and ordered behind
-    // this CDEF on the main stream, nothing else writes them
+  G_HIP(hipEventRecord(s.filters_done, main));
+  if (s.symbols_down) {
+    G_HIP(hipStreamWaitEvent(g->down, s.filters_done, 0));
+    G_HIP(hipMemcpyAsync(s.h_lr_on, s.d_lr_on, (size_t)S * 3, hipMemcpyDeviceToHost, g->down));
+    G_HIP(hipEventRecord(s.downloaded, g->down));
   }
+  if (c.gpu_entropy) {
+    // the AV1 tile entropy coder beside the next batch's block pipeline: tokenizer + chains on the context's side stream (after
+    // the filters: the restoration units a tile codes depend on the decision), the serial range coder on its back stream (so the
+    // next batch's tokenizer does not wait for it)
+    hipStream_t side = av1mi::ctx_side_stream(g->ctx), back = av1mi::ctx_back_stream(g->ctx);
+    if (!side || !back) return av1mi::ctx_fail(g->ctx, AV1MI_E_DEVICE, "no side stream");
+    G_HIP(hipStreamWaitEvent(side, s.filters_done, 0));
+    av1mi_av1_entropy_job ej;
+    memset(&ej, 0, sizeof(ej));
+    ej.width = w; ej.height = h; ej.nframes = S; ej.key = frame_type == 0; ej.base_q_idx = c.base_q_idx;
+    ej.d_lev_y = (const int16_t *)s.d_lev[0]; ej.d_lev_u = (const int16_t *)s.d_lev[1]; ej.d_lev_v = (const int16_t *)s.d_lev[2];
+    ej.d_modes_y = (const uint8_t *)s.d_modes[0]; ej.d_modes_uv = (const uint8_t *)s.d_modes[1];
+    ej.d_mvs = (const int16_t *)s.d_mv; ej.d_skip = (const uint8_t *)s.d_skip;
+    ej.lr_on[0] = P.lr_unit_y[0] == 1; ej.lr_on[1] = ej.lr_on[2] = P.lr_unit_uv[0] == 1;
+    ej.d_lr_on = (const uint8_t *)s.d_lr_on;
+    memcpy(ej.lr_unit_y, P.lr_unit_y, 8); memcpy(ej.lr_unit_uv, P.lr_unit_uv, 8);
+    ej.d_out = (uint8_t *)s.h_ent_out; ej.out_cap = g->ent_cap; ej.d_tile_size = (uint32_t *)s.d_tile_size; ej.d_total = (uint64_t *)s.d_total;
+    G_TRY(av1mi::av1_entropy_submit(g->ctx, &ej, side, back));
+    G_HIP(hipMemcpyAsync(s.h_tile_size, s.d_tile_size, (size_t)g->tiles * S * 4, hipMemcpyDeviceToHost, back));
+    G_HIP(hipMemcpyAsync(s.h_total, s.d_total, 16, hipMemcpyDeviceToHost, back));
+    G_HIP(hipMemcpyAsync(s.h_lr_on, s.d_lr_on, (size_t)S * 3, hipMemcpyDeviceToHost, back));
+    G_HIP(hipEventRecord(s.ent_done, back));
+    s.ent_pending = true;
+  }
+  g->last = (int)(g->submitted % kSlots);
   g->submitted++;
   g->gop_pos = frame_type == 0 ? 1 % c.gop_length : (g->gop_pos + 1) % c.gop_length;
   g->acquired = false;
@@ -361,6 +380,7 @@ int av1mi_gop_collect(av1mi_gop *g, av1mi_gop_frame *out) {
   if (s.symbols_down) G_HIP(hipEventSynchronize(s.downloaded));
   memset(out, 0, sizeof(*out));
   out->params = g->params[s.frame_type];
+  out->lr_on = (const uint8_t *)s.h_lr_on;
   out->segments = g->cfg.segments;
   out->blocks_per_frame = g->nb / (size_t)g->cfg.segments;
   auto symbols = [&](bool levels) {
@@ -396,8 +416,16 @@ int av1mi_gop_collect(av1mi_gop *g, av1mi_gop_frame *out) {
 int av1mi_gop_download_reference(av1mi_gop *g, void *y, void *u, void *v) {
   if (!g || !y || !u || !v) return AV1MI_E_INVAL;
   G_TRY(av1mi_sync(g->ctx));
+  // per segment and plane the restored plane or, where restoration was switched off, the CDEF output: what the decoder outputs
+  const int S = g->cfg.segments;
+  std::vector<uint8_t> on((size_t)S * 3, 1);
+  if (g->submitted) G_TRY(av1mi_download(g->ctx, on.data(), g->slot[g->last].d_lr_on, on.size()));
   void *dst[3] = { y, u, v };
-  for (int p = 0; p < 3; p++) G_TRY(av1mi_download(g->ctx, dst[p], g->d_ref[p], (p ? g->nc : g->ny) * g->bps));
+  for (int p = 0; p < 3; p++) {
+    const size_t per = (p ? g->nc : g->ny) * g->bps / (size_t)S;
+    for (int sg = 0; sg < S; sg++)
+      G_TRY(av1mi_download(g->ctx, (char *)dst[p] + per * sg, (const char *)(on[(size_t)sg * 3 + p] ? g->d_ref[p] : g->d_cdef[p]) + per * sg, per));
+  }
   return AV1MI_OK;
 }
 

@@ -33,6 +33,12 @@ __constant__ int16_t kRegular4[16][8] = {
   { 0, 0, -12, 76, 76, -12, 0, 0 }, { 0, 0, -10, 66, 84, -12, 0, 0 }, { 0, 0, -10, 58, 94, -14, 0, 0 }, { 0, 0, -10, 48, 102, -12, 0, 0 },
   { 0, 0, -8, 38, 110, -12, 0, 0 }, { 0, 0, -6, 28, 116, -10, 0, 0 }, { 0, 0, -4, 18, 122, -8, 0, 0 }, { 0, 0, -2, 8, 126, -4, 0, 0 } };
 
+// the plane frame f predicts from: the restored one, or (ref_sel given and 0 for this frame and plane) the CDEF output — the
+// restoration on / off decision of the previous frame (lr_kernel.hip k_lr_decide) without a copy
+__device__ __forceinline__ const void *ref_plane(const InterLaunch &L, int f, int p) {
+  return (L.ref_sel && !L.ref_sel[f * 3 + p]) ? L.ref_alt[p] : L.ref[p];
+}
+
 // ------------------------------------------------------------------------------------------ integer search
 // The search runs on the 8 most significant bits of the samples (10-bit content is shifted down by 2: encoder policy,
 // mirrored by the oracle), which lets one v_qsad_pk_u16_u8 score FOUR horizontally adjacent candidate vectors against
@@ -58,7 +64,7 @@ __global__ __launch_bounds__(256) void k_me_int(InterLaunch L) {
   const Tile3 tl = xcd_tile(sbw, (L.h + 63) / 64, L.nframes);
   const int f = tl.z, sby = tl.y, sbx = tl.x;
   const Pix *src = reinterpret_cast<const Pix *>(L.src[0]) + (size_t)f * L.h * L.stride_y;
-  const Pix *ref = reinterpret_cast<const Pix *>(L.ref[0]) + (size_t)f * L.h * L.stride_y;
+  const Pix *ref = reinterpret_cast<const Pix *>(ref_plane(L, f, 0)) + (size_t)f * L.h * L.stride_y;
   // staging, four samples per lane per step (the window starts on a 4-sample boundary and its width is a multiple of 4);
   // groups that lie inside the plane are one vector load, the others clamp sample by sample (the spec's edge extension)
   const int wg = WDX >> 2;
@@ -460,7 +466,7 @@ __global__ __launch_bounds__(256) void k_inter_pipe(InterLaunch L) {
   int32_t *T = reinterpret_cast<int32_t *>(reg);
 
   const Pix *src_y = reinterpret_cast<const Pix *>(L.src[0]) + (size_t)f * L.h * L.stride_y;
-  const Pix *ref_y = reinterpret_cast<const Pix *>(L.ref[0]) + (size_t)f * L.h * L.stride_y;
+  const Pix *ref_y = reinterpret_cast<const Pix *>(ref_plane(L, f, 0)) + (size_t)f * L.h * L.stride_y;
   Pix *rec_y = reinterpret_cast<Pix *>(L.rec[0]) + (size_t)f * L.h * L.stride_y;
   int16_t *mvs = L.mvs + ((size_t)f * bw * bh + blk) * 2;
   const int imx = mvs[0] >> 3, imy = mvs[1] >> 3;   // integer vector from k_me_int (multiples of 8)
@@ -576,7 +582,7 @@ __global__ __launch_bounds__(256) void k_inter_pipe(InterLaunch L) {
     const int pl = lane >> 2, cl = lane & 3;
     const int cw = L.w / 2, chh = L.h / 2, cx0 = x / 2, cy0 = y / 2;
     const Pix *src_c = reinterpret_cast<const Pix *>(L.src[1 + pl]) + (size_t)f * chh * L.stride_uv;
-    const Pix *ref_c = reinterpret_cast<const Pix *>(L.ref[1 + pl]) + (size_t)f * chh * L.stride_uv;
+    const Pix *ref_c = reinterpret_cast<const Pix *>(ref_plane(L, f, 1 + pl)) + (size_t)f * chh * L.stride_uv;
     Pix *rec_c = reinterpret_cast<Pix *>(L.rec[1 + pl]) + (size_t)f * chh * L.stride_uv;
     // the vector in 1/16 chroma samples is the luma vector in 1/8 luma samples
     const int cix = mvx >> 4, ciy = mvy >> 4;         // integer chroma displacement (floor)

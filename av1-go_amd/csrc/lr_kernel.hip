@@ -55,12 +55,37 @@ __global__ __launch_bounds__(256) void k_lr(LrLaunch L) {
   const int U[8] = { (int8_t)(U8.x & 255), (int8_t)((U8.x >> 8) & 255), (int8_t)((U8.x >> 16) & 255), (int8_t)(U8.x >> 24),
                      (int8_t)(U8.y & 255), (int8_t)((U8.y >> 8) & 255), (int8_t)((U8.y >> 16) & 255), (int8_t)(U8.y >> 24) };
   const int type = U[0];
-
+  // the on/off decision's two sums (L.orig != nullptr): squared error of the restored samples and of the CDEF samples this workgroup
+  // covers, against the source; per lane in 32 bits (16 samples x 2^20), per wave and stripe into 64-bit words (lr_finish)
+  // The sums run over a QUARTER of the plane — the 64-column x stripe tiles with (column + stripe) % 4 == 0, a diagonal pattern
+  // over the whole picture (every tile when the plane has fewer than 16) — so the decision costs a quarter of a source read.
+  const int ntx64 = (L.w + 63) >> 6, nst = (L.h + off + SH - 1) / SH;
+  const bool sampled = ntx64 * nst < 16 || (((X0 >> 6) + stripe) & 3) == 0;
+  const Pix *orig = L.orig && sampled ? reinterpret_cast<const Pix *>(L.orig) + (size_t)f * L.h * L.stride : nullptr;
+  unsigned e_lr = 0, e_cd = 0;
+  auto lr_acc = [&](int o, int cd, int sv) { const int a = o - sv, b = cd - sv; e_lr += (unsigned)(a * a); e_cd += (unsigned)(b * b); };
+  __shared__ unsigned long long s_sse[2][4];
+  auto lr_finish = [&]() {      // every thread of the workgroup comes here exactly once (uniform control flow up to the returns)
+    if (!orig) return;       // (uniform: no decision asked for, or a tile outside the sample)
+    unsigned long long a = e_lr, b = e_cd;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { a += __shfl_down(a, d, 64); b += __shfl_down(b, d, 64); }
+    if ((tid & 63) == 0) { s_sse[0][tid >> 6] = a; s_sse[1][tid >> 6] = b; }
+    __syncthreads();
+    if (tid == 0) {
+      unsigned long long *dst = L.sse + ((size_t)f * L.sse_stripes + stripe) * 2;
+      atomicAdd(dst, s_sse[0][0] + s_sse[0][1] + s_sse[0][2] + s_sse[0][3]);
+      atomicAdd(dst + 1, s_sse[1][0] + s_sse[1][1] + s_sse[1][2] + s_sse[1][3]);
+    }
+  };
   if (type == 0) {   // no restoration: copy the CDEF output
     for (int i = tid; i < bh * bw; i += 256) {
       const int r = i / bw, c = i - r * bw;
-      out[row_off(y0 + r, L.stride) + X0 + c] = cdef[row_off(y0 + r, L.stride) + X0 + c];
+      const Pix v = cdef[row_off(y0 + r, L.stride) + X0 + c];
+      out[row_off(y0 + r, L.stride) + X0 + c] = v;
+      if (orig) lr_acc(v, v, orig[row_off(y0 + r, L.stride) + X0 + c]);
     }
+    lr_finish();
     return;
   }
   // stage (bh + 6) rows x (bw + 8) columns of source samples: local row 0 == y0 - 3, local column 0 == X0 - 4 (4-aligned)
@@ -200,6 +225,23 @@ __global__ __launch_bounds__(256) void k_lr(LrLaunch L) {
 #pragma unroll
           for (int k = 0; k < 4; k++) o[k] = min(max((half ? so[k] : se[k]) >> 11, 0), maxpix);
           Pix *d = out + row_off(y0 + r + half, L.stride) + X0 + c;
+          if (orig) {
+            // four source samples as one load (the plane rows and X0 + c are 4-sample aligned wherever the output store is),
+            // the four CDEF samples as one LDS read
+            const Pix *sp = orig + row_off(y0 + r + half, L.stride) + X0 + c;
+            const uint2 cq = *reinterpret_cast<const uint2 *>(src + (r + half + 3) * SS + c + 4);
+            const int cdv[4] = { (int)(cq.x & 0xffff), (int)(cq.x >> 16), (int)(cq.y & 0xffff), (int)(cq.y >> 16) };
+            int sv[4];
+            if (((uintptr_t)sp & (4 * sizeof(Pix) - 1)) == 0) {
+              if constexpr (sizeof(Pix) == 1) { const uint32_t u = *reinterpret_cast<const uint32_t *>(sp); sv[0] = u & 255; sv[1] = (u >> 8) & 255; sv[2] = (u >> 16) & 255; sv[3] = u >> 24; }
+              else { const uint2 u = *reinterpret_cast<const uint2 *>(sp); sv[0] = u.x & 0xffff; sv[1] = u.x >> 16; sv[2] = u.y & 0xffff; sv[3] = u.y >> 16; }
+            } else {
+#pragma unroll
+              for (int k = 0; k < 4; k++) sv[k] = sp[k];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) lr_acc(o[k], cdv[k], sv[k]);
+          }
           if (((uintptr_t)d & (4 * sizeof(Pix) - 1)) == 0) {
             if constexpr (sizeof(Pix) == 1) *reinterpret_cast<uint32_t *>(d) = (uint32_t)o[0] | ((uint32_t)o[1] << 8) | ((uint32_t)o[2] << 16) | ((uint32_t)o[3] << 24);
             else { uint2 u; u.x = (uint32_t)o[0] | ((uint32_t)o[1] << 16); u.y = (uint32_t)o[2] | ((uint32_t)o[3] << 16); *reinterpret_cast<uint2 *>(d) = u; }
@@ -209,6 +251,7 @@ __global__ __launch_bounds__(256) void k_lr(LrLaunch L) {
           }
         }
       }
+      lr_finish();
       return;
     }
     for (int i = tid; i < (bh + 6) * bw; i += 256) {
@@ -225,8 +268,11 @@ __global__ __launch_bounds__(256) void k_lr(LrLaunch L) {
       int sum = 0;
 #pragma unroll
       for (int t = 0; t < 7; t++) sum += vf[t] * inter[(r + t) * MAXW + c];
-      out[row_off(y0 + r, L.stride) + X0 + c] = (Pix)min(max((sum + 1024) >> 11, 0), maxpix);
+      const int o = min(max((sum + 1024) >> 11, 0), maxpix);
+      out[row_off(y0 + r, L.stride) + X0 + c] = (Pix)o;
+      if (orig) lr_acc(o, src[(r + 3) * SS + c + 4], orig[row_off(y0 + r, L.stride) + X0 + c]);
     }
+    lr_finish();
     return;
   }
   // self-guided
@@ -288,10 +334,27 @@ __global__ __launch_bounds__(256) void k_lr(LrLaunch L) {
     int v = w1 * u;
     v += w0 * (r0 ? flt[0][k] : u);
     v += w2 * (r1 ? flt[1][k] : u);
-    out[row_off(y0 + i, L.stride) + X0 + j] = (Pix)min(max((v + 1024) >> 11, 0), maxpix);
+    const int o = min(max((v + 1024) >> 11, 0), maxpix);
+    out[row_off(y0 + i, L.stride) + X0 + j] = (Pix)o;
+    if (orig) lr_acc(o, src[(i + 3) * SS + j + 4], orig[row_off(y0 + i, L.stride) + X0 + j]);
   }
+  lr_finish();
 }
 
+// restoration stays on for frame f of the plane when it lowered the squared error: on[f * on_stride] = sum over the stripes
+__global__ __launch_bounds__(64) void k_lr_decide(const unsigned long long *sse, int nframes, int stripes, uint8_t *on, int on_stride) {
+  const int f = blockIdx.x * 64 + threadIdx.x;
+  if (f >= nframes) return;
+  unsigned long long a = 0, b = 0;
+  for (int s = 0; s < stripes; s++) { a += sse[((size_t)f * stripes + s) * 2]; b += sse[((size_t)f * stripes + s) * 2 + 1]; }
+  on[(size_t)f * on_stride] = a < b;
+}
+
+int lr_stripes(int h, int ss) { return (h + (8 >> ss) + (64 >> ss) - 1) / (64 >> ss); }
+hipError_t launch_lr_decide(const unsigned long long *sse, int nframes, int stripes, uint8_t *on, int on_stride, hipStream_t s) {
+  hipLaunchKernelGGL(k_lr_decide, dim3((unsigned)((nframes + 63) / 64)), dim3(64), 0, s, sse, nframes, stripes, on, on_stride);
+  return hipGetLastError();
+}
 hipError_t launch_lr(const LrLaunch &L, hipStream_t s) {
   const int SH = 64 >> L.ss, off = 8 >> L.ss;
   const int tw = L.unit_size < 64 ? L.unit_size : 64;

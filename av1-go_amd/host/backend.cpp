@@ -92,7 +92,11 @@ void DescribeSessionFrame(const av1mi_gop_frame &fr, int seg, int width, int hei
   d->lr_y.resize(uy * 8); d->lr_uv.resize(uc * 8);
   for (size_t i = 0; i < uy; i++) memcpy(&d->lr_y[i * 8], p.lr_unit_y, 8);
   for (size_t i = 0; i < uc; i++) memcpy(&d->lr_uv[i * 8], p.lr_unit_uv, 8);
-  f.lr_type[0] = p.lr_unit_y[0]; f.lr_type[1] = f.lr_type[2] = p.lr_unit_uv[0];
+  // restoration per plane: the policy's type where the encoder kept it ON for this segment's frame (fr.lr_on), NONE elsewhere
+  const uint8_t *on = fr.lr_on ? fr.lr_on + (size_t)seg * 3 : nullptr;
+  f.lr_type[0] = (!on || on[0]) ? p.lr_unit_y[0] : 0;
+  f.lr_type[1] = (!on || on[1]) ? p.lr_unit_uv[0] : 0;
+  f.lr_type[2] = (!on || on[2]) ? p.lr_unit_uv[0] : 0;
   f.lr_unit_shift = p.lr_unit_size == 64 ? 0 : p.lr_unit_size == 128 ? 1 : 2; f.lr_uv_shift = 0;
   f.lr_units[0] = d->lr_y.data(); f.lr_units[1] = f.lr_units[2] = d->lr_uv.data();
   f.tile_cols_log2 = f.tile_rows_log2 = -1;      // one superblock per tile: the independence the GPU pipeline's prediction assumes

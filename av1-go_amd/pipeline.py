@@ -204,20 +204,24 @@ class GopPipeline:
         self.ent_cap = segments * (width * height * 3 // 2 + 65536)
         self.ent_out = [ctx.alloc(self.ent_cap) for _ in range(gop)] if entropy_tile else []     # one stream per frame index t
         self.ent_off = [ctx.alloc((segments + 1) * 8) for _ in range(gop)] if entropy_tile else []
-        self.d_ref = [ctx.alloc(self.src[0][i].nbytes) for i in range(3)]      # loop-filtered previous frame
+        self.d_ref = [ctx.alloc(self.src[0][i].nbytes) for i in range(3)]      # restored previous frame (see d_lr_on)
+        # restoration ON / OFF per (segment, plane) of every frame index, decided on the GPU against the source (the session's policy:
+        # av1mi_lr_frames_decide); frame t + 1 predicts from d_ref where ON and from the CDEF output where OFF
+        self.d_lr_on = [ctx.to_device(np.ones(segments * 3, np.uint8)) for _ in range(gop)]
+        self.d_lr_scratch = [ctx.alloc(ctx.lr_decide_scratch_bytes(height >> (p > 0), p > 0, segments)) for p in range(3)]
         self.zero_skip = ctx.to_device(np.zeros(segments * nb, np.uint8))
         self.samples = sum(a.size for a in self.src[0]) * gop
         self.bps = k.bps
 
     def describe(self):
         return ("%dx%d %d-bit 4:2:0, %d closed GOPs of %d frames in lockstep (1 key + %d P frames, single reference, +-%d full "
-                "search + half/quarter-pel refinement, 8x8 blocks), deblock + CDEF + Wiener LR on every frame; %s"
+                "search + half/quarter-pel refinement, 8x8 blocks), deblock + CDEF + Wiener LR + its on/off decision on every frame; %s"
                 % (self.width, self.height, self.bd, self.segments, self.gop, self.gop - 1, self.range,
                    ("symbols coded on the GPU by the tile entropy coder (%dx%d tiles, own syntax, not an AV1 bitstream%s)"
                     % (self.entropy_tile, self.entropy_tile, "; side stream" if self.entropy_async else ""))
                    if self.entropy_tile else "symbols stay uncoded in HBM"))
 
-    def _filters(self, skip_buf, skip_stride, key):
+    def _filters(self, skip_buf, skip_stride, key, t):
         c, k, d = self.ctx, self.key, self.key.d
         w, h, f = self.width, self.height, self.segments
         mi_y, mi_c = (d["mi_y"], d["mi_c"]) if key else (d["mi_y_p"], d["mi_c_p"])     # the policy's level depends on the frame type
@@ -227,9 +231,15 @@ class GopPipeline:
         job = av1mi.CdefJob(w, h, self.bd, f, k.cdef_damping, w, w // 2, d["dbl_y"].ptr, d["dbl_u"].ptr, d["dbl_v"].ptr,
                             d["cdef_y"].ptr, d["cdef_u"].ptr, d["cdef_v"].ptr, d["cdef_sb"].ptr, 0, skip_buf.ptr, skip_stride)
         c.cdef_frames(job)
-        c.lr_frames(d["cdef_y"], d["dbl_y"], self.d_ref[0], w, w, h, self.bd, 0, k.lr_unit, d["lr_y"], 0, f)
-        c.lr_frames(d["cdef_u"], d["dbl_u"], self.d_ref[1], w // 2, w // 2, h // 2, self.bd, 1, k.lr_unit, d["lr_c"], 0, f)
-        c.lr_frames(d["cdef_v"], d["dbl_v"], self.d_ref[2], w // 2, w // 2, h // 2, self.bd, 1, k.lr_unit, d["lr_c"], 0, f)
+        s, on, scr = self.d_src[t], self.d_lr_on[t], self.d_lr_scratch
+        c.lr_frames_decide(d["cdef_y"], d["dbl_y"], self.d_ref[0], w, w, h, self.bd, 0, k.lr_unit, d["lr_y"], 0, f, s[0], scr[0], on, 0, 3)
+        c.lr_frames_decide(d["cdef_u"], d["dbl_u"], self.d_ref[1], w // 2, w // 2, h // 2, self.bd, 1, k.lr_unit, d["lr_c"], 0, f, s[1], scr[1], on, 1, 3)
+        c.lr_frames_decide(d["cdef_v"], d["dbl_v"], self.d_ref[2], w // 2, w // 2, h // 2, self.bd, 1, k.lr_unit, d["lr_c"], 0, f, s[2], scr[2], on, 2, 3)
+
+    def lr_on(self, t):
+        """[segments, 3] restoration ON / OFF flags of the t-th frames after the last step"""
+        self.ctx.sync()
+        return self.d_lr_on[t].download((self.segments, 3), np.uint8)
 
     def step(self, on_frame=None):
         c, k, d = self.ctx, self.key, self.key.d
@@ -249,7 +259,8 @@ class GopPipeline:
             else:
                 job = av1mi.InterJob(w, h, self.bd, f, self.qindex, self.range, w, w // 2, s[0].ptr, s[1].ptr, s[2].ptr,
                                      self.d_ref[0].ptr, self.d_ref[1].ptr, self.d_ref[2].ptr, d["rec_y"].ptr, d["rec_u"].ptr,
-                                     d["rec_v"].ptr, y["lev_y"].ptr, y["lev_u"].ptr, y["lev_v"].ptr, y["mvs"].ptr, y["skip"].ptr)
+                                     d["rec_v"].ptr, y["lev_y"].ptr, y["lev_u"].ptr, y["lev_v"].ptr, y["mvs"].ptr, y["skip"].ptr,
+                                     d["cdef_y"].ptr, d["cdef_u"].ptr, d["cdef_v"].ptr, self.d_lr_on[t - 1].ptr)
                 c.inter_encode(job)
             if self.entropy_tile:
                 ej = av1mi.EntropyJob(w, h, f, int(t == 0), self.entropy_tile, y["lev_y"].ptr, y["lev_u"].ptr, y["lev_v"].ptr,
@@ -259,7 +270,7 @@ class GopPipeline:
                     c.entropy_encode_async(ej, slot)
                 else:
                     c.entropy_encode(ej)
-            self._filters(self.zero_skip if t == 0 else y["skip"], 0 if t == 0 else nb, t == 0)
+            self._filters(self.zero_skip if t == 0 else y["skip"], 0 if t == 0 else nb, t == 0, t)
             if on_frame:
                 on_frame(t)
 
@@ -290,6 +301,6 @@ class GopPipeline:
         for t in self.d_src:
             for b in t:
                 b.free()
-        for b in [self.d_mvs, self.d_skip, self.zero_skip] + self.d_ref + self.ent_out + self.ent_off + (list(self.sym[1].values()) if len(self.sym) > 1 else []):
+        for b in [self.d_mvs, self.d_skip, self.zero_skip] + self.d_ref + self.d_lr_on + self.d_lr_scratch + self.ent_out + self.ent_off + (list(self.sym[1].values()) if len(self.sym) > 1 else []):
             b.free()
         self.key.close()

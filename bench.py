@@ -94,23 +94,24 @@ def cpu_baseline_gop(pipe, p_frames=2):
     k, gop = pipe.key, pipe.gop
     h, w = pipe.height, pipe.width
 
-    def filters(r, skip8, t):
+    def filters(r, skip8, t, src):
         mi_y, mi_c, damping, cdef_sb, lr_unit, lr_y, lr_c = pipe.oracle_filter_args(t)
         dbl = [O.deblock_plane(r["rec_y"], pipe.bd, 0, mi_y), O.deblock_plane(r["rec_u"], pipe.bd, 1, mi_c), O.deblock_plane(r["rec_v"], pipe.bd, 1, mi_c)]
         cdef = O.cdef_frame(dbl[0], dbl[1], dbl[2], pipe.bd, damping, cdef_sb, skip8)
-        return [O.lr_plane(cdef[0], dbl[0], pipe.bd, 0, lr_unit, lr_y), O.lr_plane(cdef[1], dbl[1], pipe.bd, 1, lr_unit, lr_c),
-                O.lr_plane(cdef[2], dbl[2], pipe.bd, 1, lr_unit, lr_c)]
+        lr = [O.lr_plane(cdef[0], dbl[0], pipe.bd, 0, lr_unit, lr_y), O.lr_plane(cdef[1], dbl[1], pipe.bd, 1, lr_unit, lr_c),
+              O.lr_plane(cdef[2], dbl[2], pipe.bd, 1, lr_unit, lr_c)]
+        return O.lr_select(src, cdef, lr, pipe.bd)[0]      # the restoration ON / OFF decision against the source
 
     def one(worker):
         s = worker % pipe.segments
         t0 = time.perf_counter()
         src = [pipe.src[0][i][s] for i in range(3)]
-        ref = filters(O.intra_encode_frame(src[0], src[1], src[2], pipe.bd, 8, pipe.qindex), np.zeros((h // 8, w // 8), np.uint8), 0)
+        ref = filters(O.intra_encode_frame(src[0], src[1], src[2], pipe.bd, 8, pipe.qindex), np.zeros((h // 8, w // 8), np.uint8), 0, src)
         t1 = time.perf_counter()
         for t in range(1, 1 + p_frames):
             src = [pipe.src[t][i][s] for i in range(3)]
             r = O.inter_encode_frame(src, ref, pipe.bd, pipe.qindex, pipe.range)
-            ref = filters(r, r["skip"].reshape(h // 8, w // 8), t)
+            ref = filters(r, r["skip"].reshape(h // 8, w // 8), t, src)
         return t1 - t0, (time.perf_counter() - t1) / p_frames
 
     t0 = time.perf_counter()
@@ -147,11 +148,15 @@ def quality(pipe, bd):
     if hasattr(pipe, "d_ref"):                     # closed GOPs: the last P frames of all segments
         src = pipe.src[pipe.gop - 1][0]
         rec = pipe.d_ref[0].download(src.shape, src.dtype)
+        # what a decoder outputs: the restored plane, or the CDEF output in the segments where restoration was switched off
+        on, cdef = pipe.lr_on(pipe.gop - 1)[:, 0], pipe.key.d["cdef_y"].download(src.shape, src.dtype)
+        rec = np.where(on[:, None, None] != 0, rec, cdef)
     else:
         src = pipe.src[0]
         rec = pipe.d["out_y"].download(src.shape, src.dtype)
     mse = float(np.mean((rec.astype(np.float64) - src.astype(np.float64)) ** 2))
-    return {"psnr_y_db": 10.0 * np.log10(peak * peak / mse) if mse > 0 else None, "frames": int(src.shape[0]),
+    extra = {"restoration_on_in_segments": int(on.sum())} if hasattr(pipe, "d_ref") else {}
+    return {"psnr_y_db": 10.0 * np.log10(peak * peak / mse) if mse > 0 else None, "frames": int(src.shape[0]), **extra,
             "note": "fixed qindex, no rate control; the comparison with libaom on the same key frame is under e2e.vs_libaom"}
 
 

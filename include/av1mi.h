@@ -209,6 +209,16 @@ int av1mi_cdef_frames(av1mi_ctx *ctx, const av1mi_cdef_job *job);
 int av1mi_lr_frames(av1mi_ctx *ctx, const void *d_cdef, const void *d_deblocked, void *d_out, int stride, int w, int h,
                     int bd, int subsampled, int unit_size, const int8_t *d_units, size_t unit_frame_stride, int nframes);
 
+/* The same restoration followed by the encoder's ON / OFF decision per frame of the plane (policy, non-normative; oracle:
+ * av1o_lr_keep): d_on[f * on_stride] = 1 when the restored samples are closer to the source d_orig (same geometry) than the CDEF
+ * samples — sum of squared differences, strictly smaller — else 0: the plane the next frame predicts from is then d_cdef's, and
+ * the frame header signals lr_type NONE for it.  d_out always receives the restored samples.  d_scratch: device memory of
+ * av1mi_lr_decide_scratch_bytes(h, subsampled, nframes) bytes, 8-byte aligned. */
+size_t av1mi_lr_decide_scratch_bytes(int h, int subsampled, int nframes);
+int av1mi_lr_frames_decide(av1mi_ctx *ctx, const void *d_cdef, const void *d_deblocked, void *d_out, int stride, int w, int h, int bd, int subsampled,
+                           int unit_size, const int8_t *d_units, size_t unit_frame_stride, int nframes, const void *d_orig, void *d_scratch, uint8_t *d_on,
+                           int on_stride);
+
 /* ---- the intra-only segment pipeline (BASELINE config 2): what stands in for the encode the reference delegates
  * to `ffmpeg -c:v:0 av1_vaapi` (transcode.go:120) for key frames.  One launch codes `nframes` frames that are
  * stacked in the plane buffers (frame f starts at row f*height of the luma planes, f*height/2 of the chroma planes).
@@ -241,6 +251,11 @@ typedef struct av1mi_inter_job {
   int16_t *d_lev_y, *d_lev_u, *d_lev_v;
   int16_t *d_mvs;       /* nframes * (w/8)*(h/8) * 2 */
   uint8_t *d_skip;      /* nframes * (w/8)*(h/8) */
+  /* optional (NULL = not used): the reference per frame and plane without a copy.  d_ref_sel[f * 3 + p] == 0 makes frame f predict
+   * plane p from d_ref_alt_* (the CDEF output of the previous frame: its restoration was switched off, av1mi_lr_frames_decide)
+   * instead of d_ref_* (the restored planes). */
+  const void *d_ref_alt_y, *d_ref_alt_u, *d_ref_alt_v;
+  const uint8_t *d_ref_sel;
 } av1mi_inter_job;
 int av1mi_inter_encode(av1mi_ctx *ctx, const av1mi_inter_job *job);
 
@@ -293,6 +308,7 @@ typedef struct av1mi_av1_entropy_job {
   uint8_t *d_out; size_t out_cap;
   uint32_t *d_tile_size;
   uint64_t *d_total;                           /* 2 entries, 8-byte aligned */
+  const uint8_t *d_lr_on;                      /* optional: [frame * 3 + plane] 0 switches lr_on[plane] off for that frame */
 } av1mi_av1_entropy_job;
 int av1mi_av1_entropy_encode(av1mi_ctx *ctx, const av1mi_av1_entropy_job *job);
 /* the same on another HIP stream of the caller's (hipStream_t passed as void *; NULL = the context's stream) */
@@ -358,6 +374,9 @@ typedef struct av1mi_gop_frame {    /* one collected frame batch; host pointers 
   const uint32_t *tile_size;        /* segments * tiles_per_frame entries */
   const uint8_t *tile_payload;
   uint64_t payload_bytes;
+  /* restoration ON (1) / OFF (0) per segment and plane, [segment * 3 + plane]: the encoder keeps params.lr_unit_* for a plane only
+   * where it lowered the squared error against the source; an OFF plane is signalled with lr_type NONE in the frame header */
+  const uint8_t *lr_on;
 } av1mi_gop_frame;
 
 typedef struct av1mi_gop av1mi_gop;

@@ -134,3 +134,27 @@ int av1o_lr_plane(const void *cdef, const void *dbl, void *out, int stride, int 
   }
   return 0;
 }
+
+/*
+ * Encoder policy (non-normative): restoration stays ON for a plane of a frame exactly when it lowers the squared error against
+ * the source: returns 1 when sum (lr - src)^2 < sum (cdef - src)^2 over the sampled tiles (the plane the next frame predicts from is then `lr`, else
+ * `cdef`, and the frame header signals lr_type NONE for the plane).  The kernels accumulate the same two integer sums (k_lr) and
+ * compare them (k_lr_decide); fixed default taps lower PSNR on most inter frames of the synthetic clips and raise it on key frames.
+ */
+int av1o_lr_keep(const void *src, const void *cdef, const void *lr, int stride, int w, int h, int bd, int ss) {
+  /* the sums run over a quarter of the plane: the tiles (64 columns x one restoration stripe) with (column + stripe) % 4 == 0,
+   * every tile when the plane has fewer than 16 (k_lr reads the source for those tiles only) */
+  const int sh = 64 >> ss, off = 8 >> ss;
+  const int ntx = (w + 63) >> 6, nst = (h + off + sh - 1) / sh, dense = ntx * nst < 16;
+  unsigned long long e_lr = 0, e_cdef = 0;
+  for (int y = 0; y < h; y++) {
+    const int stripe = (y + off) / sh;
+    for (int x = 0; x < w; x++) {
+      if (!dense && (((x >> 6) + stripe) & 3)) continue;
+      const long s = gp(src, bd, (size_t)y * stride + x);
+      const long a = gp(lr, bd, (size_t)y * stride + x) - s, b = gp(cdef, bd, (size_t)y * stride + x) - s;
+      e_lr += (unsigned long long)(a * a); e_cdef += (unsigned long long)(b * b);
+    }
+  }
+  return e_lr < e_cdef;
+}

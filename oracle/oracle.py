@@ -287,6 +287,22 @@ def lr_plane(cdef, dbl, bd, ss, unit_size, units):
     return out
 
 
+def lr_select(src, cdef, lr, bd, ss=None):
+    """the restoration on/off policy per plane (av1o_lr_keep): src / cdef / lr are (Y, U, V) triples of one frame (ss: the planes' chroma
+    flag when they are not a Y, U, V triple).
+    Returns (planes the next frame predicts from, [on_y, on_u, on_v])"""
+    dt = np.uint8 if bd == 8 else np.uint16
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    out, on = [], []
+    for p, (s_, c_, l_) in enumerate(zip(src, cdef, lr)):
+        s_, c_, l_ = (np.ascontiguousarray(a, dt) for a in (s_, c_, l_))
+        h, w = s_.shape
+        k = int(lib().av1o_lr_keep(vp(s_), vp(c_), vp(l_), w, w, h, bd, int(ss if ss is not None else p > 0)))
+        on.append(k)
+        out.append(l_ if k else c_)
+    return out, on
+
+
 def inter_encode_frame(src, ref, bd, qindex, search_range=8, bs=8):
     """src, ref: (Y, U, V) tuples; returns dict(rec_y/u/v, lev_y/u/v, mvs [nb,2], skip [nb])"""
     dt = np.uint8 if bd == 8 else np.uint16

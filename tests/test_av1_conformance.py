@@ -15,15 +15,20 @@ import dav1d_ref as D
 pytestmark = pytest.mark.skipif(not D.available(), reason="no dav1d in this image (pillow.libs/libavif)")
 
 
-def _filters(O, P, r, bd, q, frame_type, w, h, skip8):
-    """deblock -> CDEF -> loop restoration of the oracle with the library's policy numbers; returns (header kwargs, stages)"""
+def _filters(O, P, r, bd, q, frame_type, w, h, skip8, src=None):
+    """deblock -> CDEF -> loop restoration of the oracle with the library's policy numbers; with the source planes `src` also the
+    encoder's restoration ON / OFF decision per plane (the last stage is then what the next frame predicts from, and the header
+    carries lr_type NONE for the planes switched off); returns (header kwargs, stages)"""
     import av1stream
     a = P.policy_arrays(q, bd, frame_type, w, h)
     dbl = [O.deblock_plane(r["rec_y"], bd, 0, a["mi_y"]), O.deblock_plane(r["rec_u"], bd, 1, a["mi_c"]), O.deblock_plane(r["rec_v"], bd, 1, a["mi_c"])]
     cdef = O.cdef_frame(dbl[0], dbl[1], dbl[2], bd, a["cdef_damping"], a["cdef_sb"], skip8)
     out = [O.lr_plane(cdef[0], dbl[0], bd, 0, a["lr_unit"], a["lr_units_y"]), O.lr_plane(cdef[1], dbl[1], bd, 1, a["lr_unit"], a["lr_units_c"]),
            O.lr_plane(cdef[2], dbl[2], bd, 1, a["lr_unit"], a["lr_units_c"])]
-    hdr = av1stream.header_from_params(a["params"], w, h)
+    on = None
+    if src is not None:
+        out, on = O.lr_select(src, cdef, out, bd)
+    hdr = av1stream.header_from_params(a["params"], w, h, on)
     hdr.pop("frame_type")
     return hdr, [dbl, list(cdef), out]
 
@@ -32,7 +37,7 @@ def _chain(O, P, Y, U, V, bd, q):
     """the oracle's key-frame chain with the library's parameter policy; returns symbols + header kwargs + the four stages"""
     h, w = Y.shape
     r = O.intra_encode_frame(Y, U, V, bd, 8, q)
-    hdr, st = _filters(O, P, r, bd, q, 0, w, h, np.zeros((h // 8, w // 8), np.uint8))
+    hdr, st = _filters(O, P, r, bd, q, 0, w, h, np.zeros((h // 8, w // 8), np.uint8), (Y, U, V))
     return r, hdr, [[r["rec_y"], r["rec_u"], r["rec_v"]]] + st
 
 
@@ -86,7 +91,7 @@ def _gop(O, P, w, h, bd, q, nframes, first=3):
             ref = stages[3]
         else:
             r = O.inter_encode_frame((Y[t], U[t], V[t]), ref, bd, q, 8)
-            hdr_p, st = _filters(O, P, r, bd, q, 1, w, h, r["skip"].reshape(h // 8, w // 8))     # inter frames: their own deblocking level
+            hdr_p, st = _filters(O, P, r, bd, q, 1, w, h, r["skip"].reshape(h // 8, w // 8), (Y[t], U[t], V[t]))     # inter frames: their own deblocking level
             stream += av1stream.temporal_unit(w, h, bd, q, frame_type=1, with_sequence_header=False, mv=r["mvs"], skip=r["skip"],
                                               lev_y=r["lev_y"], lev_u=r["lev_u"], lev_v=r["lev_v"], **hdr_p)
             ref = st[2]

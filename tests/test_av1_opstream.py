@@ -38,7 +38,7 @@ def test_inter_frame_bytes_equal_the_sequential_writer(O, w, h, bd, q, n):
     ref = st[3]
     for t in range(1, n):
         r = O.inter_encode_frame((Y[t], U[t], V[t]), ref, bd, q, 8)
-        hp, st = _filters(O, P, r, bd, q, 1, w, h, r["skip"].reshape(h // 8, w // 8))
+        hp, st = _filters(O, P, r, bd, q, 1, w, h, r["skip"].reshape(h // 8, w // 8), (Y[t], U[t], V[t]))
         ref = st[2]
         sym = dict(frame_type=1, with_sequence_header=False, mv=r["mvs"], skip=r["skip"], lev_y=r["lev_y"], lev_u=r["lev_u"], lev_v=r["lev_v"])
         assert av1stream.temporal_unit(w, h, bd, q, **sym, **hp) == av1stream.temporal_unit(w, h, bd, q, opstream=True, **sym, **hp), "frame %d" % t

@@ -68,3 +68,33 @@ def test_lr_1080p_fixed_point(ctx, O):
     rng = np.random.default_rng(96)
     units = _random_units(rng, O, 64, h, w)
     assert (_run(ctx, flat, flat, 8, 0, 64, units) == 131).all()
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+@pytest.mark.parametrize("ss", [0, 1])
+def test_lr_on_off_decision_equals_the_oracle(ctx, O, bd, ss):
+    """av1mi_lr_frames_decide: the restored plane as before, and per frame the ON / OFF flag = av1o_lr_keep (squared error against
+    the source, strictly smaller) — frames built so that both outcomes occur, every unit type, odd sizes, chroma stripes"""
+    rng = np.random.default_rng(190 + bd + ss)
+    for (h, w), unit in (((136, 200), 64), ((72, 100), 32 if ss else 64), ((300, 260), 128), ((40, 24), 64), ((200, 712), 64)):      # the last one: >= 16 tiles, sampled
+        nf = 4
+        cdef = np.stack([make_image(rng, h, w, bd) for _ in range(nf)])
+        dbl = cdef.copy()
+        units = np.stack([_random_units(rng, O, unit, h, w) for _ in range(nf)])
+        lr = np.stack([O.lr_plane(cdef[f], dbl[f], bd, ss, unit, units[f]) for f in range(nf)])
+        # sources: frames 0, 1 lie at the CDEF samples (restoration loses), 2 at the restored ones (it wins unless no unit filters), 3 between
+        mx = (1 << bd) - 1
+        noise = rng.integers(-1, 2, cdef.shape)
+        src = np.stack([np.clip(cdef[0].astype(int) + noise[0], 0, mx), cdef[1], lr[2],
+                        (cdef[3].astype(int) + lr[3].astype(int) + 1) >> 1]).astype(cdef.dtype)
+        d_c, d_d, d_u, d_s = ctx.to_device(cdef), ctx.to_device(dbl), ctx.to_device(units), ctx.to_device(src)
+        d_o, d_on = ctx.alloc(cdef.nbytes), ctx.to_device(np.full(3 * nf, 7, np.uint8))
+        d_scr = ctx.alloc(ctx.lr_decide_scratch_bytes(h, ss, nf))
+        ctx.lr_frames_decide(d_c, d_d, d_o, w, w, h, bd, ss, unit, d_u, units.shape[1] * units.shape[2], nf, d_s, d_scr, d_on, on_offset=1, on_stride=3)
+        got, on = d_o.download(cdef.shape, cdef.dtype), d_on.download((nf, 3), np.uint8)
+        for b in (d_c, d_d, d_u, d_s, d_o, d_on, d_scr):
+            b.free()
+        assert (got == lr).all()
+        exp = [O.lr_select((src[f],), (cdef[f],), (lr[f],), bd, ss)[1][0] for f in range(nf)]
+        assert on[:, 1].tolist() == exp and (on[:, 0] == 7).all() and (on[:, 2] == 7).all(), ((h, w), unit, on.tolist(), exp)
+        assert exp[1] == 0 and (exp[2] == 1 or (lr[2] == cdef[2]).mean() > 0.2)

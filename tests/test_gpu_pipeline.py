@@ -66,6 +66,7 @@ def test_closed_gop_chain_matches_oracle(ctx, O, w, h, bd, q, segs, gop, rng_):
     got = []
     dl = lambda bufs, shapes: [b.download(s.shape, s.dtype) for b, s in zip(bufs, shapes)]
     gp.step(on_frame=lambda t: got.append(dl(gp.d_ref, gp.src[t])))
+    lr_on = [gp.lr_on(t) for t in range(gop)]
     k = gp.key
     for s in range(segs):
         ref = None
@@ -80,10 +81,13 @@ def test_closed_gop_chain_matches_oracle(ctx, O, w, h, bd, q, segs, gop, rng_):
             mi_y, mi_c, damping, cdef_sb, lr_unit, lr_y, lr_c = gp.oracle_filter_args(t)
             dbl = [O.deblock_plane(r["rec_y"], bd, 0, mi_y), O.deblock_plane(r["rec_u"], bd, 1, mi_c), O.deblock_plane(r["rec_v"], bd, 1, mi_c)]
             cdef = O.cdef_frame(dbl[0], dbl[1], dbl[2], bd, damping, cdef_sb, skip8)
-            ref = [O.lr_plane(cdef[0], dbl[0], bd, 0, lr_unit, lr_y), O.lr_plane(cdef[1], dbl[1], bd, 1, lr_unit, lr_c),
-                   O.lr_plane(cdef[2], dbl[2], bd, 1, lr_unit, lr_c)]
+            lr = [O.lr_plane(cdef[0], dbl[0], bd, 0, lr_unit, lr_y), O.lr_plane(cdef[1], dbl[1], bd, 1, lr_unit, lr_c),
+                  O.lr_plane(cdef[2], dbl[2], bd, 1, lr_unit, lr_c)]
             for i in range(3):
-                assert (got[t][i][s] == ref[i]).all(), (s, t, i)
+                assert (got[t][i][s] == lr[i]).all(), (s, t, i)
+            # the restoration ON / OFF decision against the source: frame t + 1 predicts from the restored or the CDEF plane
+            ref, on = O.lr_select(src, cdef, lr, bd)
+            assert lr_on[t][s].tolist() == on, (s, t, lr_on[t][s].tolist(), on)
     gp.close()
 
 
@@ -149,8 +153,9 @@ def test_closed_gop_chain_coded_records(ctx, O, use_async):
             mi_y, mi_c, damping, cdef_sb, lr_unit, lr_y, lr_c = gp.oracle_filter_args(t)
             dbl = [O.deblock_plane(r["rec_y"], bd, 0, mi_y), O.deblock_plane(r["rec_u"], bd, 1, mi_c), O.deblock_plane(r["rec_v"], bd, 1, mi_c)]
             cdef = O.cdef_frame(dbl[0], dbl[1], dbl[2], bd, damping, cdef_sb, skip8)
-            ref = [O.lr_plane(cdef[0], dbl[0], bd, 0, lr_unit, lr_y), O.lr_plane(cdef[1], dbl[1], bd, 1, lr_unit, lr_c),
-                   O.lr_plane(cdef[2], dbl[2], bd, 1, lr_unit, lr_c)]
+            lr = [O.lr_plane(cdef[0], dbl[0], bd, 0, lr_unit, lr_y), O.lr_plane(cdef[1], dbl[1], bd, 1, lr_unit, lr_c),
+                  O.lr_plane(cdef[2], dbl[2], bd, 1, lr_unit, lr_c)]
+            ref, _ = O.lr_select(src, cdef, lr, bd)
     for _ in range(2):
         gp.step()
         for t in range(gop):

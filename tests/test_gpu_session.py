@@ -10,7 +10,9 @@ import dav1d_ref as D
 pytestmark = pytest.mark.gpu
 
 
-def _oracle_filters(O, r, bd, p, w, h, skip8):
+def _oracle_filters(O, r, bd, p, w, h, skip8, src):
+    """the oracle's filter chain with the session's parameters + its restoration ON / OFF decision against the source planes `src`:
+    returns (the planes the next frame predicts from = what a decoder outputs, [on_y, on_u, on_v])"""
     mi_y = np.full((h // 4, w // 4), int(O.lf_mi(3, 3, p.lf_level[0], p.lf_level[1])), np.uint32)
     mi_c = np.full((h // 8, w // 8), int(O.lf_mi(2, 2, p.lf_level[2], p.lf_level[2])), np.uint32)
     dbl = [O.deblock_plane(r["rec_y"], bd, 0, mi_y, p.lf_sharpness), O.deblock_plane(r["rec_u"], bd, 1, mi_c, p.lf_sharpness),
@@ -21,7 +23,8 @@ def _oracle_filters(O, r, bd, p, w, h, skip8):
     ur = lambda n: max(1, (n + 32) // 64)
     uy = np.tile(np.array(list(p.lr_unit_y), np.int8), (ur(h), ur(w), 1))
     uc = np.tile(np.array(list(p.lr_unit_uv), np.int8), (ur(h // 2), ur(w // 2), 1))
-    return [O.lr_plane(cdef[0], dbl[0], bd, 0, 64, uy), O.lr_plane(cdef[1], dbl[1], bd, 1, 64, uc), O.lr_plane(cdef[2], dbl[2], bd, 1, 64, uc)]
+    lr = [O.lr_plane(cdef[0], dbl[0], bd, 0, 64, uy), O.lr_plane(cdef[1], dbl[1], bd, 1, 64, uc), O.lr_plane(cdef[2], dbl[2], bd, 1, 64, uc)]
+    return O.lr_select(src, cdef, lr, bd)
 
 
 @pytest.mark.parametrize("w,h,bd,q", [(192, 128, 8, 110), (136, 72, 10, 150)])
@@ -58,7 +61,8 @@ def test_session_symbols_and_references_match_the_oracle_chain(ctx, av1mi, O, w,
                     skip8 = r["skip"].reshape(h // 8, w // 8)
                 for k in ("lev_y", "lev_u", "lev_v"):
                     assert (fr[k][sgi] == r[k]).all(), (t, sgi, k)
-                ref[sgi] = _oracle_filters(O, r, bd, p, w, h, skip8)
+                ref[sgi], on = _oracle_filters(O, r, bd, p, w, h, skip8, (Y[f], U[f], V[f]))
+                assert fr["lr_on"][sgi].tolist() == on, (t, sgi, fr["lr_on"][sgi].tolist(), on)
                 for got, exp, hh in ((gy, ref[sgi][0], h), (gu, ref[sgi][1], h // 2), (gv, ref[sgi][2], h // 2)):
                     assert (got[sgi * hh:(sgi + 1) * hh] == exp).all(), "frame %d segment %d: reference differs from the oracle chain" % (t, sgi)
     finally:

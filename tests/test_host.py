@@ -185,7 +185,7 @@ def test_run_transcode_and_process_job_on_gpu(host, tmp_path, O):
                 r = O.inter_encode_frame((Y[i], U[i], V[i]), ref, 8, q, 8)
                 skip8 = r["skip"].reshape(h // 8, w // 8)
             from test_gpu_session import _oracle_filters
-            ref = _oracle_filters(O, r, 8, p, w, h, skip8)
+            ref, _ = _oracle_filters(O, r, 8, p, w, h, skip8, (Y[i], U[i], V[i]))
             for pl in range(3):
                 assert (got[i][pl] == ref[pl]).all(), "frame %d plane %d: the decoded file differs from the oracle chain" % (i, pl)
     # lifecycle: tight ratio -> skipped with markers; generous ratio -> success, and the SOURCE IS KEPT (video-only output)
