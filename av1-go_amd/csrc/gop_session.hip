@@ -130,7 +130,7 @@ int setup(av1mi_gop *g) {
     G_HIP(hipEventCreateWithFlags(&s.uploaded, hipEventDisableTiming));
     G_HIP(hipEventCreateWithFlags(&s.kernel_done, hipEventDisableTiming));
     G_HIP(hipEventCreateWithFlags(&s.filters_done, hipEventDisableTiming));
-    G_TRY(dev_alloc(g, &s.d_lr_on, (size_t)S * 3)); G_TRY(host_alloc(g, &s.h_lr_on, (size_t)S * 3));
+    G_TRY(dev_alloc(g, &s.d_lr_on, (size_t)S * 3 + 4)); G_TRY(host_alloc(g, &s.h_lr_on, (size_t)S * 3));      // (+ 4: the kernels read the flags as aligned dwords)
     G_HIP(hipEventCreateWithFlags(&s.downloaded, hipEventDisableTiming));
     if (c.gpu_entropy) {
       g->tiles = ((w + 63) / 64) * ((h + 63) / 64);

@@ -35,8 +35,12 @@ __constant__ int16_t kRegular4[16][8] = {
 
 // the plane frame f predicts from: the restored one, or (ref_sel given and 0 for this frame and plane) the CDEF output — the
 // restoration on / off decision of the previous frame (lr_kernel.hip k_lr_decide) without a copy
+// (the flag is read as the aligned dword that holds it: f is uniform in a workgroup, so this is a scalar load)
 __device__ __forceinline__ const void *ref_plane(const InterLaunch &L, int f, int p) {
-  return (L.ref_sel && !L.ref_sel[f * 3 + p]) ? L.ref_alt[p] : L.ref[p];
+  if (!L.ref_sel) return L.ref[p];
+  const int i = f * 3 + p;
+  const uint32_t w = reinterpret_cast<const uint32_t *>(L.ref_sel)[i >> 2];
+  return ((w >> (8 * (i & 3))) & 0xffu) ? L.ref[p] : L.ref_alt[p];
 }
 
 // ------------------------------------------------------------------------------------------ integer search

@@ -207,7 +207,7 @@ class GopPipeline:
         self.d_ref = [ctx.alloc(self.src[0][i].nbytes) for i in range(3)]      # restored previous frame (see d_lr_on)
         # restoration ON / OFF per (segment, plane) of every frame index, decided on the GPU against the source (the session's policy:
         # av1mi_lr_frames_decide); frame t + 1 predicts from d_ref where ON and from the CDEF output where OFF
-        self.d_lr_on = [ctx.to_device(np.ones(segments * 3, np.uint8)) for _ in range(gop)]
+        self.d_lr_on = [ctx.to_device(np.ones(segments * 3 + 4, np.uint8)) for _ in range(gop)]      # (+ 4: read as aligned dwords)
         self.d_lr_scratch = [ctx.alloc(ctx.lr_decide_scratch_bytes(height >> (p > 0), p > 0, segments)) for p in range(3)]
         self.zero_skip = ctx.to_device(np.zeros(segments * nb, np.uint8))
         self.samples = sum(a.size for a in self.src[0]) * gop

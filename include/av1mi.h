@@ -253,7 +253,7 @@ typedef struct av1mi_inter_job {
   uint8_t *d_skip;      /* nframes * (w/8)*(h/8) */
   /* optional (NULL = not used): the reference per frame and plane without a copy.  d_ref_sel[f * 3 + p] == 0 makes frame f predict
    * plane p from d_ref_alt_* (the CDEF output of the previous frame: its restoration was switched off, av1mi_lr_frames_decide)
-   * instead of d_ref_* (the restored planes). */
+   * instead of d_ref_* (the restored planes).  d_ref_sel: 4-byte aligned, allocated up to a multiple of 4 bytes (read as dwords). */
   const void *d_ref_alt_y, *d_ref_alt_u, *d_ref_alt_v;
   const uint8_t *d_ref_sel;
 } av1mi_inter_job;
