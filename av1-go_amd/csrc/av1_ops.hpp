@@ -499,7 +499,7 @@ AV1_HD void tok_block(const FrameView &f, Sink &k, const TokScratch &ts, int sbr
   tok_partition_prefix(f, k, sbr, sbc, bx, by);
   const int b = r8 * f.w8 + c8;
   const bool au = by > 0, al = bx > 0;
-  const BlockInfo zero = { { 0, 0, 0 }, { 0, 0, 0 }, 0, 0 };
+  const BlockInfo zero = {};
   const BlockInfo ia = au ? f.info[b - f.w8] : zero, il = al ? f.info[b - 1] : zero;
   const int skip = f.key ? 0 : f.skip[b];
   k.sym(S_SKIP + (au && !f.key ? f.skip[b - f.w8] : 0) + (al && !f.key ? f.skip[b - 1] : 0), skip);
