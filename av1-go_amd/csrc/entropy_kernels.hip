@@ -349,7 +349,9 @@ __global__ void k_ent_frames(EntropyLaunch L) {
   if (threadIdx.x || blockIdx.x) return;
   uint64_t acc = 0;
   for (int f = 0; f < L.nframes; f++) { L.frame_off[f] = acc; acc += L.frame_size[f]; }
-  L.frame_off[L.nframes] = acc;
+  // a tile that overran its slot (status bit 1 of k_ent_code: nothing is packed then) is reported through the same word the host
+  // already checks against its capacity: a total no buffer can hold
+  L.frame_off[L.nframes] = (L.status[0] & 2u) ? ~0ull : acc;
   if (acc > L.out_cap) atomicOr(L.status, 1u);
 }
 __global__ void __launch_bounds__(64) k_ent_pack(EntropyLaunch L, int tpf, int tile_log2) {

@@ -268,7 +268,8 @@ int av1mi_inter_encode(av1mi_ctx *ctx, const av1mi_inter_job *job);
  * this project's own symbols and initial CDFs — not an AV1 bitstream).  Every tile (tile x tile luma samples, tile =
  * 32, 64 or 128) has an independent coder state: one GPU lane per tile.  d_frame_off receives nframes + 1 byte
  * offsets into d_out (the last one = total size).  If the total exceeds out_cap nothing is written to d_out and
- * d_frame_off[nframes] still holds the size needed (worst case 6 bytes per coefficient + 64 per tile).
+ * d_frame_off[nframes] still holds the size needed (worst case 6 bytes per coefficient + 64 per tile); if a tile overran its
+ * scratch slot (levels beyond that bound) d_frame_off[nframes] = UINT64_MAX and nothing is written.
  * Scratch (one slot per tile) is owned by the context and grows on demand. */
 typedef struct av1mi_entropy_job {
   int width, height, nframes, key, tile;
