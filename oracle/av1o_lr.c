@@ -142,15 +142,15 @@ int av1o_lr_plane(const void *cdef, const void *dbl, void *out, int stride, int 
  * compare them (k_lr_decide); fixed default taps lower PSNR on most inter frames of the synthetic clips and raise it on key frames.
  */
 int av1o_lr_keep(const void *src, const void *cdef, const void *lr, int stride, int w, int h, int bd, int ss) {
-  /* the sums run over a quarter of the plane: the tiles (64 columns x one restoration stripe) with (column + stripe) % 4 == 0,
-   * every tile when the plane has fewer than 16 (k_lr reads the source for those tiles only) */
+  /* the sums run over an eighth of the plane: the tiles (64 columns x one restoration stripe) with (column + stripe) % 8 == 0,
+   * every tile when the plane has fewer than 32 (k_lr reads the source for those tiles only) */
   const int sh = 64 >> ss, off = 8 >> ss;
-  const int ntx = (w + 63) >> 6, nst = (h + off + sh - 1) / sh, dense = ntx * nst < 16;
+  const int ntx = (w + 63) >> 6, nst = (h + off + sh - 1) / sh, dense = ntx * nst < 32;
   unsigned long long e_lr = 0, e_cdef = 0;
   for (int y = 0; y < h; y++) {
     const int stripe = (y + off) / sh;
     for (int x = 0; x < w; x++) {
-      if (!dense && (((x >> 6) + stripe) & 3)) continue;
+      if (!dense && (((x >> 6) + stripe) & 7)) continue;
       const long s = gp(src, bd, (size_t)y * stride + x);
       const long a = gp(lr, bd, (size_t)y * stride + x) - s, b = gp(cdef, bd, (size_t)y * stride + x) - s;
       e_lr += (unsigned long long)(a * a); e_cdef += (unsigned long long)(b * b);

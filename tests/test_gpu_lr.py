@@ -76,7 +76,7 @@ def test_lr_on_off_decision_equals_the_oracle(ctx, O, bd, ss):
     """av1mi_lr_frames_decide: the restored plane as before, and per frame the ON / OFF flag = av1o_lr_keep (squared error against
     the source, strictly smaller) — frames built so that both outcomes occur, every unit type, odd sizes, chroma stripes"""
     rng = np.random.default_rng(190 + bd + ss)
-    for (h, w), unit in (((136, 200), 64), ((72, 100), 32 if ss else 64), ((300, 260), 128), ((40, 24), 64), ((200, 712), 64)):      # the last one: >= 16 tiles, sampled
+    for (h, w), unit in (((136, 200), 64), ((72, 100), 32 if ss else 64), ((300, 260), 128), ((40, 24), 64), ((200, 712), 64)):      # the last one: >= 32 tiles, sampled
         nf = 4
         cdef = np.stack([make_image(rng, h, w, bd) for _ in range(nf)])
         dbl = cdef.copy()
