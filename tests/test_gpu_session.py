@@ -218,3 +218,47 @@ def test_gpu_coder_capacity_overflow_falls_back_to_the_host(ctx, av1mi):
         assert len(got) == 2 and all((got[t][i] == refs[t][i]).all() for t in range(2) for i in range(3))
     finally:
         s.close()
+
+
+@pytest.mark.parametrize("mode", [1, 0])
+def test_three_batches_in_flight_give_the_bytes_of_lockstep(ctx, av1mi, mode):
+    """The pipelined use (submit t + 2 before collect t: uploads, kernels, the two coder streams and the host overlap, every slot
+    and both list sets of the coder are reused several times) must produce exactly the temporal units of the one-batch-at-a-time
+    use — GPU tile coder (mode 1) and symbols for the host coder (mode 0), three GOPs per segment."""
+    import av1stream
+    import synth
+    w, h, bd, q, gop, segs, n = 640, 360, 10, 120, 4, 3, 12
+    Y, U, V = synth.frames(w, h, segs * n, bd, 2)
+
+    def run(lag):
+        s = av1mi.GopSession(ctx, w, h, bd, q, gop, segs, gpu_entropy=mode)
+        units = []
+
+        def take():
+            fr = s.collect()
+            for sgi in range(segs):
+                units.append(av1stream.session_frame_unit_gpu(w, h, bd, fr, sgi) if mode else av1stream.session_frame_unit(w, h, bd, fr, sgi, threads=4))
+        try:
+            for t in range(n):
+                planes = s.input_planes()
+                for sgi in range(segs):
+                    f = sgi * n + t
+                    planes[0][sgi * h:(sgi + 1) * h] = Y[f]
+                    planes[1][sgi * h // 2:(sgi + 1) * h // 2] = U[f]
+                    planes[2][sgi * h // 2:(sgi + 1) * h // 2] = V[f]
+                s.submit()
+                if s.pending() > lag:
+                    take()
+            while s.pending():
+                take()
+        finally:
+            s.close()
+        return units
+
+    a, b = run(0), run(2)
+    assert len(a) == len(b) == n * segs
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert x == y, "frame %d segment %d: pipelined session differs from lockstep (%d vs %d bytes)" % (i // segs, i % segs, len(y), len(x))
+    if D.available():      # and the streams are real: segment 0 decodes to 12 frames
+        got = D.decode(b"".join(b[i] for i in range(0, n * segs, segs)))
+        assert len(got) == n
