@@ -216,6 +216,17 @@ __device__ __forceinline__ void fast_pred_row(const T *edge, int r, int bd, int 
       const int pl = abs(b - l), pt = abs(b - t), ptl = abs(b - tl);
       out[c] = (pl <= pt && pl <= ptl) ? l : (pt <= ptl) ? t : tl;
     }
+  } else if constexpr (MODE == SMOOTH_V_PRED) {
+    const int below = left[B - 1], wh = sm_weight(B, r);
+#pragma unroll
+    for (int c = 0; c < B; c++) out[c] = (wh * above[c] + (256 - wh) * below + 128) >> 8;
+  } else if constexpr (MODE == SMOOTH_H_PRED) {
+    const int right = above[B - 1], l = left[r];
+#pragma unroll
+    for (int c = 0; c < B; c++) {
+      const int ww = sm_weight(B, c);
+      out[c] = (ww * l + (256 - ww) * right + 128) >> 8;
+    }
   } else {   // SMOOTH_PRED
     const int below = left[B - 1], right = above[B - 1], l = left[r], wh = sm_weight(B, r);
 #pragma unroll

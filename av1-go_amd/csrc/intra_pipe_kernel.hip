@@ -85,7 +85,7 @@ __device__ __forceinline__ int code_block(const TileCtx<Pix> &C, int lane, int b
   int s[B], bp[B];
   load_row<B>(src_row, s);
   STAMP(0);
-  // all edge variants of the block in two LDS phases, then 11 compile-time-specialised predictions, no hand-offs
+  // all edge variants of the block in two LDS phases, then 13 compile-time-specialised predictions, no hand-offs
   fast_build<B>(C.edge, lane, bd, n_top, n_topright, n_left, n_bottomleft, filter_type, fetch);
   STAMP(1);
   int best = 0x7fffffff, best_mode = 0;
@@ -110,7 +110,8 @@ __device__ __forceinline__ int code_block(const TileCtx<Pix> &C, int lane, int b
   eval(std::integral_constant<int, D135_PRED>{}); eval(std::integral_constant<int, D113_PRED>{});
   eval(std::integral_constant<int, D157_PRED>{}); eval(std::integral_constant<int, D203_PRED>{});
   eval(std::integral_constant<int, D67_PRED>{});  eval(std::integral_constant<int, SMOOTH_PRED>{});
-  eval(std::integral_constant<int, PAETH_PRED>{});
+  eval(std::integral_constant<int, PAETH_PRED>{}); eval(std::integral_constant<int, SMOOTH_V_PRED>{});
+  eval(std::integral_constant<int, SMOOTH_H_PRED>{});
   AV1MI_GROUP_SYNC();
   STAMP(2);
   int rec[B];

@@ -223,8 +223,8 @@ int av1mi_lr_frames_decide(av1mi_ctx *ctx, const void *d_cdef, const void *d_deb
  * to `ffmpeg -c:v:0 av1_vaapi` (transcode.go:120) for key frames.  One launch codes `nframes` frames that are
  * stacked in the plane buffers (frame f starts at row f*height of the luma planes, f*height/2 of the chroma planes).
  * Every 64x64 superblock is an independent tile; blocks are block_size x block_size (8 or 16; width and height must
- * be multiples of it), transform = block size, DCT_DCT, mode chosen per block by SAD among DC/V/H/6 diagonals/
- * SMOOTH/PAETH.  Outputs: reconstruction planes, int16 levels (block-contiguous, raster order of blocks, per plane),
+ * be multiples of it), transform = block size, DCT_DCT, mode chosen per block by SAD among all 13 intra modes (DC, V, H, 6
+ * diagonals, SMOOTH, PAETH, SMOOTH_V, SMOOTH_H; angle delta 0).  Outputs: reconstruction planes, int16 levels (block-contiguous, raster order of blocks, per plane),
  * one mode byte per block for luma and one for the chroma pair. */
 typedef struct av1mi_intra_job {
   int width, height, bit_depth, nframes, qindex, block_size;

@@ -59,7 +59,8 @@ int av1o_intra_predict(const void *ref, int ref_stride, int bd, int bw, int bh, 
                        int disable_edge_filter, int filter_type, int n_top_px, int n_topright_px, int n_left_px,
                        int n_bottomleft_px, uint16_t *pred);
 
-static const int intra_candidates[11] = { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 12 }; /* DC V H D45 D135 D113 D157 D203 D67 SMOOTH PAETH */
+/* all 13 intra modes, angle delta 0: DC V H D45 D135 D113 D157 D203 D67 SMOOTH PAETH SMOOTH_V SMOOTH_H (first minimum wins) */
+static const int intra_candidates[13] = { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 12, 10, 11 };
 /* Mode_To_Txfm (AV1 spec 5.11.47 compute_tx_type / libaom intra_mode_to_tx_type): the transform type an intra CHROMA block
  * takes from its prediction mode (it is not coded in the bitstream); luma types are coded explicitly and stay DCT_DCT here. */
 const uint8_t av1o_mode_to_txfm[14] = { DCT_DCT, ADST_DCT, DCT_ADST, DCT_DCT, ADST_ADST, ADST_DCT, DCT_ADST, DCT_ADST, ADST_DCT,
@@ -81,7 +82,7 @@ static int encode_block(int nplanes, const void *const *src, void *const *rec, i
   const int tx_size = bs == 4 ? TX_4X4 : bs == 8 ? TX_8X8 : bs == 16 ? TX_16X16 : bs == 32 ? TX_32X32 : TX_64X64;
   const int bps = bd == 8 ? 1 : 2;
   long best = -1; int best_mode = 0;
-  for (int ci = 0; ci < 11; ci++) {
+  for (int ci = 0; ci < 13; ci++) {
     const int mode = intra_candidates[ci];
     long sad = 0;
     for (int p = 0; p < nplanes; p++) {

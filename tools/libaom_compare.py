@@ -140,7 +140,7 @@ def main():
     ys = [aom[q][1] for q in sorted(aom)][::-1]
     at_equal_size = float(np.interp(np.log(ob), xs, ys)) if xs[0] <= np.log(ob) <= xs[-1] else None
     out = {"frame": "%dx%d %d-bit synthetic key frames (%d)" % (w, h, args.bd, args.frames), "qindex": args.qindex,
-           "ours": {"bytes_per_frame": ob, "psnr_y_db": op, "tools": "8x8 blocks, 11 intra modes by SAD, DCT only, no RDO, fixed filter policy"},
+           "ours": {"bytes_per_frame": ob, "psnr_y_db": op, "tools": "8x8 blocks, 13 intra modes by SAD, DCT only, no RDO, filter policy from q + restoration on/off by squared error"},
            "libaom": {"version": "3.13 (bundled libavif %s), all-intra, AOM_Q, speed %d" % ("1.4", args.speed),
                       "by_quantizer": {str(q): {"bytes_per_frame": v[0], "psnr_y_db": v[1], "seconds_per_frame": v[2]} for q, v in aom.items()},
                       "matching_quantizer": quantizer},
