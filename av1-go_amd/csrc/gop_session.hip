@@ -122,7 +122,10 @@ int setup(av1mi_gop *g) {
     for (int p = 0; p < 3; p++) {
       const size_t n = (p ? g->nc : g->ny);
       G_TRY(host_alloc(g, &s.h_src[p], n * g->bps)); G_TRY(dev_alloc(g, &s.d_src[p], n * g->bps));
-      G_TRY(host_alloc(g, &s.h_lev[p], n * 2)); G_TRY(dev_alloc(g, &s.d_lev[p], n * 2));
+      // the pinned mirror of the levels (as large as the source) is needed when the symbols go to the host; with the GPU coder
+      // only a batch the coder gives back needs it, and it is allocated then (pinning memory is a good part of the start-up time)
+      if (c.gpu_entropy != 1) G_TRY(host_alloc(g, &s.h_lev[p], n * 2));
+      G_TRY(dev_alloc(g, &s.d_lev[p], n * 2));
     }
     for (int k = 0; k < 2; k++) { G_TRY(host_alloc(g, &s.h_modes[k], g->nb)); G_TRY(dev_alloc(g, &s.d_modes[k], g->nb)); }
     G_TRY(host_alloc(g, &s.h_mv, g->nb * 4)); G_TRY(dev_alloc(g, &s.d_mv, g->nb * 4));
@@ -399,7 +402,10 @@ int av1mi_gop_collect(av1mi_gop *g, av1mi_gop_frame *out) {
       // lost: its symbols are still in the slot's device buffers (the next kernel that overwrites them is kSlots submits away),
       // so they are downloaded now and handed out like in host mode: tile_size stays NULL, the caller entropy-codes this batch.
       if (!s.symbols_down) {
-        for (int p = 0; p < 3; p++) G_HIP(hipMemcpyAsync(s.h_lev[p], s.d_lev[p], (p ? g->nc : g->ny) * 2, hipMemcpyDeviceToHost, g->down));
+        for (int p = 0; p < 3; p++) {
+          if (!s.h_lev[p]) G_TRY(host_alloc(g, &s.h_lev[p], (p ? g->nc : g->ny) * 2));
+          G_HIP(hipMemcpyAsync(s.h_lev[p], s.d_lev[p], (p ? g->nc : g->ny) * 2, hipMemcpyDeviceToHost, g->down));
+        }
         G_TRY(download_modes(g, s, g->down));
         G_HIP(hipStreamSynchronize(g->down));
         symbols(true);
