@@ -262,3 +262,44 @@ def test_three_batches_in_flight_give_the_bytes_of_lockstep(ctx, av1mi, mode):
     if D.available():      # and the streams are real: segment 0 decodes to 12 frames
         got = D.decode(b"".join(b[i] for i in range(0, n * segs, segs)))
         assert len(got) == n
+
+
+@pytest.mark.skipif(not D.available(), reason="no dav1d in this image")
+def test_random_small_configurations_decode_to_the_gpu_frames(ctx, av1mi):
+    """twenty random small configurations (sizes that are multiples of 8 but mostly not of 64, both bit depths, quantisers 20..235,
+    GOP lengths 1..5, 1..4 segments, three batches in flight): the GPU-coded stream of every segment decodes in dav1d, frame by
+    frame, to the planes the session reports as decoder output, and the host writer codes the same symbols to the same bytes"""
+    import av1stream
+    import synth
+    rng = np.random.default_rng(2024)
+    for case in range(20):
+        w, h = int(rng.integers(8, 41)) * 8, int(rng.integers(8, 31)) * 8
+        bd, q = int(rng.choice([8, 10])), int(rng.integers(20, 236))
+        gop, segs, nfr = int(rng.integers(1, 6)), int(rng.integers(1, 5)), int(rng.integers(2, 7))
+        Y, U, V = synth.frames(w, h, segs * nfr, bd, int(rng.integers(0, 50)))
+        s = av1mi.GopSession(ctx, w, h, bd, q, gop, segs, gpu_entropy=2)
+        streams, refs = [b""] * segs, []
+        try:
+            for t in range(nfr):
+                planes = s.input_planes()
+                for sgi in range(segs):
+                    f = sgi * nfr + t
+                    planes[0][sgi * h:(sgi + 1) * h] = Y[f]
+                    planes[1][sgi * h // 2:(sgi + 1) * h // 2] = U[f]
+                    planes[2][sgi * h // 2:(sgi + 1) * h // 2] = V[f]
+                s.submit()
+                fr = s.collect()
+                refs.append(s.download_reference())
+                assert "tile_size" in fr, (case, w, h, bd, q, "the GPU coder gave a batch back")
+                for sgi in range(segs):
+                    gpu = av1stream.session_frame_unit_gpu(w, h, bd, fr, sgi)
+                    assert gpu == av1stream.session_frame_unit(w, h, bd, fr, sgi, threads=2), (case, w, h, bd, q, gop, segs, t, sgi)
+                    streams[sgi] += gpu
+        finally:
+            s.close()
+        for sgi in range(segs):
+            got = D.decode(streams[sgi])
+            assert len(got) == nfr, (case, w, h, bd, q, gop, segs)
+            for t in range(nfr):
+                for i, hh in ((0, h), (1, h // 2), (2, h // 2)):
+                    assert (got[t][i] == refs[t][i][sgi * hh:(sgi + 1) * hh]).all(), (case, w, h, bd, q, gop, segs, t, sgi, i)
