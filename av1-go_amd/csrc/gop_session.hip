@@ -12,6 +12,7 @@
 // pipeline and the coder works on batch t, whose predecessor the host is still reading.  Four streams, one hardware queue each
 // (a fifth would share a queue with one of these and serialise behind it).
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <new>
 #include <vector>
@@ -117,7 +118,10 @@ int setup(av1mi_gop *g) {
   g->ny = (size_t)w * h * S; g->nc = g->ny / 4; g->nb = g->ny / 64;
   G_HIP(hipSetDevice(av1mi::ctx_device(g->ctx)));
   G_HIP(hipStreamCreateWithFlags(&g->up, hipStreamNonBlocking));
-  G_HIP(hipStreamCreateWithFlags(&g->down, hipStreamNonBlocking));
+  // the download stream only where symbols go to the host at submit time: HIP deals its (four) hardware queues to streams in the
+  // order they are created, and a fifth stream shares a queue with the first — measured: the coder's back stream and the main
+  // stream then ran one after the other.  The GPU-coder mode has exactly four: main, up, side, back.
+  if (c.gpu_entropy != 1) G_HIP(hipStreamCreateWithFlags(&g->down, hipStreamNonBlocking));
   for (Slot &s : g->slot) {
     for (int p = 0; p < 3; p++) {
       const size_t n = (p ? g->nc : g->ny);
@@ -345,6 +349,8 @@ int av1mi_gop_submit(av1mi_gop *g, int frame_type) {
     G_HIP(hipEventRecord(s.downloaded, g->down));
   }
   if (c.gpu_entropy) {
+    // (measured: tokenizer + chains on the MAIN stream instead — no contention with the block pipeline, three streams in all —
+    // is 2 % slower end to end than beside it)
     // the AV1 tile entropy coder beside the next batch's block pipeline: tokenizer + chains on the context's side stream (after
     // the filters: the restoration units a tile codes depend on the decision), the serial range coder on its back stream (so the
     // next batch's tokenizer does not wait for it)
@@ -402,6 +408,7 @@ int av1mi_gop_collect(av1mi_gop *g, av1mi_gop_frame *out) {
       // lost: its symbols are still in the slot's device buffers (the next kernel that overwrites them is kSlots submits away),
       // so they are downloaded now and handed out like in host mode: tile_size stays NULL, the caller entropy-codes this batch.
       if (!s.symbols_down) {
+        if (!g->down) G_HIP(hipStreamCreateWithFlags(&g->down, hipStreamNonBlocking));      // a rare path: its queue may be shared
         for (int p = 0; p < 3; p++) {
           if (!s.h_lev[p]) G_TRY(host_alloc(g, &s.h_lev[p], (p ? g->nc : g->ny) * 2));
           G_HIP(hipMemcpyAsync(s.h_lev[p], s.d_lev[p], (p ? g->nc : g->ny) * 2, hipMemcpyDeviceToHost, g->down));
