@@ -118,10 +118,13 @@ int setup(av1mi_gop *g) {
   g->ny = (size_t)w * h * S; g->nc = g->ny / 4; g->nb = g->ny / 64;
   G_HIP(hipSetDevice(av1mi::ctx_device(g->ctx)));
   G_HIP(hipStreamCreateWithFlags(&g->up, hipStreamNonBlocking));
-  // the download stream only where symbols go to the host at submit time: HIP deals its (four) hardware queues to streams in the
-  // order they are created, and a fifth stream shares a queue with the first — measured: the coder's back stream and the main
-  // stream then ran one after the other.  The GPU-coder mode has exactly four: main, up, side, back.
-  if (c.gpu_entropy != 1) G_HIP(hipStreamCreateWithFlags(&g->down, hipStreamNonBlocking));
+  // (created in every mode, used only where symbols go to the host at submit time or a batch falls back.  HIP deals its four
+  // default hardware queues to streams in creation order: main, up, down, side — and the coder's back stream, the fifth, shares
+  // the main stream's queue, i.e. the range coder of batch t and the block pipeline of batch t + 1 run one after the other.
+  // Measured A/B on one box: that is the FASTEST arrangement, 1 800 frames/s end to end at 4K against 1 500-1 600 with a queue
+  // per stream (without this stream, or with GPU_MAX_HW_QUEUES=8) and 1 500 with the coder on the main stream itself: the
+  // range coder is one long wave per CU, and beside it every kernel of the block pipeline runs at a fraction of its speed.)
+  G_HIP(hipStreamCreateWithFlags(&g->down, hipStreamNonBlocking));
   for (Slot &s : g->slot) {
     for (int p = 0; p < 3; p++) {
       const size_t n = (p ? g->nc : g->ny);
@@ -349,8 +352,6 @@ int av1mi_gop_submit(av1mi_gop *g, int frame_type) {
     G_HIP(hipEventRecord(s.downloaded, g->down));
   }
   if (c.gpu_entropy) {
-    // (measured: tokenizer + chains on the MAIN stream instead — no contention with the block pipeline, three streams in all —
-    // is 2 % slower end to end than beside it)
     // the AV1 tile entropy coder beside the next batch's block pipeline: tokenizer + chains on the context's side stream (after
     // the filters: the restoration units a tile codes depend on the decision), the serial range coder on its back stream (so the
     // next batch's tokenizer does not wait for it)
@@ -408,7 +409,6 @@ int av1mi_gop_collect(av1mi_gop *g, av1mi_gop_frame *out) {
       // lost: its symbols are still in the slot's device buffers (the next kernel that overwrites them is kSlots submits away),
       // so they are downloaded now and handed out like in host mode: tile_size stays NULL, the caller entropy-codes this batch.
       if (!s.symbols_down) {
-        if (!g->down) G_HIP(hipStreamCreateWithFlags(&g->down, hipStreamNonBlocking));      // a rare path: its queue may be shared
         for (int p = 0; p < 3; p++) {
           if (!s.h_lev[p]) G_TRY(host_alloc(g, &s.h_lev[p], (p ? g->nc : g->ny) * 2));
           G_HIP(hipMemcpyAsync(s.h_lev[p], s.d_lev[p], (p ? g->nc : g->ny) * 2, hipMemcpyDeviceToHost, g->down));

@@ -11,11 +11,6 @@
 using namespace av1mi_host;
 
 int main(int argc, char **argv) {
-  // The session runs four streams (block pipeline, upload, tokenizer + chains, range coder) that must overlap.  The HIP runtime
-  // shares FOUR hardware queues among all streams of a process by default, and a queue shared by two of these serialises them
-  // (measured: the range coder of batch t then holds back the block pipeline of batch t + 1).  Ask for eight before the runtime
-  // starts; an explicit setting in the environment wins.
-  setenv("GPU_MAX_HW_QUEUES", "8", 0);
   if (argc >= 2 && !strcmp(argv[1], "--gpu-usage")) {     // the AMD twin of internal/tui/gpu.go getGPUUsage
     printf("%.1f\n", GetGPUUsage(argc >= 3 ? atoi(argv[2]) : 0));
     return 0;

@@ -19,10 +19,6 @@ import time
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-# The GOP session's four streams must overlap; HIP shares four hardware queues among ALL streams a process ever made by default,
-# and this harness makes many (sessions of several legs): ask for eight before the runtime starts (same as av1mi_transcode's main;
-# an explicit setting wins).  The device-resident `value` runs on one stream and does not depend on it.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 sys.path.insert(0, os.path.join(ROOT, "av1-go_amd"))
 sys.path.insert(0, ROOT)
 
@@ -350,7 +346,6 @@ def e2e_leg(ctx, W, H, bd, qindex, first_frame, segs=4, gop=30, steps=2, warmup_
            "bytes_per_frame": coded["bytes"] / frames, "mbit_per_s_at_30fps": coded["bytes"] / frames * 8 * 30 / 1e6,
            "host_seconds": {"fill_pinned_input": coded["t_fill"], "wait_for_gpu": coded["t_wait"],
                             "assemble_obu" if gpu_entropy else "entropy_code": coded["t_code"]},
-           "hip_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
            "pcie_bytes_per_frame": {"up": W * H * 3 // 2 * (1 if bd == 8 else 2),
                                     "down": coded["bytes"] / frames if gpu_entropy else W * H * 3 + (W // 8) * (H // 8) * 5},
            "entropy_coding": "GPU (k_av1_*: AV1 tile syntax, one lane per tile, side stream)" if gpu_entropy else "host, %d threads" % threads,

@@ -7,8 +7,6 @@ import time
 
 import numpy as np
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # like bench.py and av1mi_transcode: the session's streams need queues of their own
-
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "av1-go_amd"))
 import av1mi   # noqa: E402
