@@ -260,7 +260,9 @@ __global__ __launch_bounds__(64) void k_av1_code(Av1EntLaunch L, int ntiles_all)
   request();
   if (pend) { take(); request(); }
   int i = 0, lit_left = 0;
-  uint32_t op = ring[0], op_next = ring[1];
+  // the word of this step and the next two in registers; the ring read of a step is issued before its arithmetic and used after
+  // it (read and moved back to back, every step waited a whole LDS latency)
+  uint32_t op = ring[0], op_next = ring[1], op_next2 = ring[2];
   for (;;) {
     // the checks every eight steps: a lane advances by at most eight words and eight stage entries in between
     if (!__any(lit_left > 0 || i < n)) break;
@@ -271,6 +273,7 @@ __global__ __launch_bounds__(64) void k_av1_code(Av1EntLaunch L, int ntiles_all)
 #pragma unroll
     for (int q = 0; q < 8; q++) {
       if (lit_left > 0 || i < n) {
+        const uint32_t fetched = ring[(i + 3) & (kRingOps - 1)];      // requested first, used last: the word an advance shifts in
         uint32_t tup = op;
         if (lit_left == 0 && (op >> 31)) lit_left = (int)((op >> 27) & 15);
         if (lit_left > 0) {         // one equiprobable bit: the tuples of (icdf 16384 | 0, symbol 1 of 2) and (32768 | 16384, symbol 0 of 2)
@@ -278,7 +281,7 @@ __global__ __launch_bounds__(64) void k_av1_code(Av1EntLaunch L, int ntiles_all)
           tup = (op >> lit_left) & 1 ? (1u << 19) | (256u << 9) : (2u << 19) | (512u << 9) | 256u;
         }
         c.encode_tuple(tup);
-        if (lit_left == 0) { i++; op = op_next; op_next = ring[(i + 1) & (kRingOps - 1)]; }
+        if (lit_left == 0) { i++; op = op_next; op_next = op_next2; op_next2 = fetched; }
       }
     }
   }
