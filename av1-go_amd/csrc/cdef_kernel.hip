@@ -89,11 +89,19 @@ __device__ __forceinline__ void cdef_quad_packed(const uint16_t *p, const int32_
     const v2s ww = { (short)w, (short)w };
     s0 += ww * c0; s1 += ww * c1;
   };
+  // secondary strength 0 (uniform in a superblock; the policy's value for inter frames at mid quantisers): its eight taps
+  // contribute nothing to the sum, and without them the result lies between the centre and a primary tap, so that they do not
+  // take part in the min / max clamp changes nothing either (libaom's cdef_filter_8_1 drops the clamp altogether)
+  if (sec) {
 #pragma unroll
-  for (int k = 0; k < 2; k++) {
-    taps(k, pri, pshift, k ? pt1 : pt0);
-    taps(2 + k, sec, sshift, k ? 1 : 2);
-    taps(4 + k, sec, sshift, k ? 1 : 2);
+    for (int k = 0; k < 2; k++) {
+      taps(k, pri, pshift, k ? pt1 : pt0);
+      taps(2 + k, sec, sshift, k ? 1 : 2);
+      taps(4 + k, sec, sshift, k ? 1 : 2);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 2; k++) taps(k, pri, pshift, k ? pt1 : pt0);
   }
   const v2s eight = { 8, 8 }, four = { 4, 4 }, fifteen = { 15, 15 };
   const v2s y0 = x0 + ((s0 + (s0 >> fifteen) + eight) >> four), y1 = x1 + ((s1 + (s1 >> fifteen) + eight) >> four);

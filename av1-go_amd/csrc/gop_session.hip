@@ -11,6 +11,7 @@
 // Source and symbol buffers exist kSlots = 3 times (slot = batch % 3): batch t + 2 uploads while batch t + 1 is in the block
 // pipeline and the coder works on batch t, whose predecessor the host is still reading.  Four streams, one hardware queue each
 // (a fifth would share a queue with one of these and serialise behind it).
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -34,11 +35,23 @@ void frame_params(int q, int bd, int frame_type, av1mi_frame_params *p) {
   const int lvl = lf_level_from_q(ac_q, bd, frame_type == 0);
   p->lf_level[0] = p->lf_level[1] = p->lf_level[2] = p->lf_level[3] = lvl;
   p->lf_sharpness = 0;
-  p->cdef_damping = 3 + (q8 > 100) + (q8 > 300);
-  int y = q8 < 700 ? (q8 * q8 * 3 + 32768) >> 16 : 15;     // one strength set per frame from the step
-  y = y > 15 ? 15 : y;
-  const int ypri = y + 2 > 15 ? 15 : (y + 2 < 1 ? 1 : y + 2), cpri = y < 1 ? 1 : y;
-  p->cdef_y = (uint8_t)(ypri << 2 | 1); p->cdef_uv = (uint8_t)(cpri << 2 | 1);
+  // CDEF strengths from the quantiser step: libaom's CDEF_PICK_FROM_Q fit (pickcdef.c av1_pick_cdef_from_qp: quadratic fits of the
+  // strengths its full search picks, separate for intra-only and inter frames; secondary codes 0..3 = strengths 0, 1, 2, 4).  At
+  // mid quantisers inter frames get secondary strength 0: two thirds of k_cdef's taps drop out (cdef_kernel.hip).
+  p->cdef_damping = 3 + (q >> 6);
+  {
+    const float x = (float)q8, x2 = x * x;
+    auto fit = [&](float a, float b, float c, int hi) { const int v = (int)lroundf(x2 * a + x * b + c); return v < 0 ? 0 : v > hi ? hi : v; };
+    int y1, y2, c1, c2;
+    if (frame_type == 0) {
+      y1 = fit(0.0000033731974f, 0.008070594f, 0.0187634f, 15); y2 = fit(0.0000029167343f, 0.0027798624f, 0.0079405f, 3);
+      c1 = fit(-0.0000130790995f, 0.012892405f, -0.00748388f, 15); c2 = fit(0.0000032651783f, 0.00035520183f, 0.00228092f, 3);
+    } else {
+      y1 = fit(-0.0000023593946f, 0.0068615186f, 0.02709886f, 15); y2 = fit(-0.00000057629734f, 0.0013993345f, 0.03831067f, 3);
+      c1 = fit(-0.0000007095069f, 0.0034628846f, 0.00887099f, 15); c2 = fit(0.00000023874085f, 0.00028223585f, 0.05576307f, 3);
+    }
+    p->cdef_y = (uint8_t)(y1 << 2 | y2); p->cdef_uv = (uint8_t)(c1 << 2 | c2);
+  }
   p->lr_unit_size = 64;
   static const int8_t wy[8] = { 1, 3, -7, 15, 3, -7, 15, 0 }, wc[8] = { 1, 0, -7, 15, 0, -7, 15, 0 };   // Wiener, libaom's mid-range taps
   memcpy(p->lr_unit_y, wy, 8); memcpy(p->lr_unit_uv, wc, 8);
@@ -172,11 +185,14 @@ int setup(av1mi_gop *g) {
     G_TRY(dev_alloc(g, &g->d_mi[t][0], mi.size() * 4)); G_TRY(av1mi_upload(g->ctx, g->d_mi[t][0], mi.data(), mi.size() * 4));
     G_TRY(dev_alloc(g, &g->d_mi[t][1], mic.size() * 4)); G_TRY(av1mi_upload(g->ctx, g->d_mi[t][1], mic.data(), mic.size() * 4));
   }
-  {
-    const av1mi_frame_params &P = g->params[0];     // CDEF strengths and restoration units do not depend on the frame type
+  for (int t = 0; t < 2; t++) {      // CDEF strengths: one set per frame type
+    const av1mi_frame_params &P = g->params[t];
     std::vector<uint8_t> sb((size_t)nsb * 4);
     for (int i = 0; i < nsb; i++) { sb[4 * i] = P.cdef_y >> 2; sb[4 * i + 1] = P.cdef_y & 3; sb[4 * i + 2] = P.cdef_uv >> 2; sb[4 * i + 3] = P.cdef_uv & 3; }
-    G_TRY(dev_alloc(g, &g->d_cdef_sb[0], sb.size())); G_TRY(av1mi_upload(g->ctx, g->d_cdef_sb[0], sb.data(), sb.size()));
+    G_TRY(dev_alloc(g, &g->d_cdef_sb[t], sb.size())); G_TRY(av1mi_upload(g->ctx, g->d_cdef_sb[t], sb.data(), sb.size()));
+  }
+  {
+    const av1mi_frame_params &P = g->params[0];     // the restoration units do not depend on the frame type
     std::vector<int8_t> lr((uy > uc ? uy : uc) * 8);
     for (size_t i = 0; i < uy; i++) memcpy(&lr[i * 8], P.lr_unit_y, 8);
     G_TRY(dev_alloc(g, &g->d_lr[0], uy * 8)); G_TRY(av1mi_upload(g->ctx, g->d_lr[0], lr.data(), uy * 8));
@@ -333,7 +349,7 @@ int av1mi_gop_submit(av1mi_gop *g, int frame_type) {
   cj.width = w; cj.height = h; cj.bit_depth = bd; cj.nframes = S; cj.damping = P.cdef_damping; cj.stride_y = w; cj.stride_uv = w / 2;
   cj.d_src_y = g->d_dbl[0]; cj.d_src_u = g->d_dbl[1]; cj.d_src_v = g->d_dbl[2];
   cj.d_dst_y = g->d_cdef[0]; cj.d_dst_u = g->d_cdef[1]; cj.d_dst_v = g->d_cdef[2];
-  cj.d_sb_strength = (const uint8_t *)g->d_cdef_sb[0]; cj.sb_frame_stride = 0;
+  cj.d_sb_strength = (const uint8_t *)g->d_cdef_sb[frame_type]; cj.sb_frame_stride = 0;
   // key frames are coded with skip = 0 everywhere (no block is exempt from CDEF); P frames: the kernel's skip flags, per frame
   // (the slot's next inter kernel is kSlots batches away and ordered behind this CDEF on the main stream, nothing else writes them)
   cj.d_skip8 = (const uint8_t *)(frame_type == 0 ? g->d_zero_skip : s.d_skip); cj.skip_frame_stride = frame_type == 0 ? 0 : (size_t)(w / 8) * (h / 8);

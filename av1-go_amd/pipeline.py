@@ -97,6 +97,7 @@ class IntraPipeline:
         self.mi_y, self.mi_c = k["mi_y"], k["mi_c"]
         self.d["mi_y"], self.d["mi_c"] = ctx.to_device(self.mi_y), ctx.to_device(self.mi_c)
         self.d["mi_y_p"], self.d["mi_c_p"] = ctx.to_device(self.pol[1]["mi_y"]), ctx.to_device(self.pol[1]["mi_c"])
+        self.d["cdef_sb_p"] = ctx.to_device(self.pol[1]["cdef_sb"])      # inter frames: their own CDEF strengths and damping
         self.samples = Y.size + U.size + V.size            # per step
         # CDEF: one strength set for every superblock, nothing skipped on key frames; LR: every unit Wiener with the default taps
         self.cdef_damping, self.cdef_sb = k["cdef_damping"], k["cdef_sb"]
@@ -228,8 +229,8 @@ class GopPipeline:
         c.deblock_frames(d["rec_y"], w, d["dbl_y"], w, w, h, self.bd, 0, mi_y, w // 4, 0, 0, f)
         c.deblock_frames(d["rec_u"], w // 2, d["dbl_u"], w // 2, w // 2, h // 2, self.bd, 1, mi_c, w // 8, 0, 0, f)
         c.deblock_frames(d["rec_v"], w // 2, d["dbl_v"], w // 2, w // 2, h // 2, self.bd, 1, mi_c, w // 8, 0, 0, f)
-        job = av1mi.CdefJob(w, h, self.bd, f, k.cdef_damping, w, w // 2, d["dbl_y"].ptr, d["dbl_u"].ptr, d["dbl_v"].ptr,
-                            d["cdef_y"].ptr, d["cdef_u"].ptr, d["cdef_v"].ptr, d["cdef_sb"].ptr, 0, skip_buf.ptr, skip_stride)
+        job = av1mi.CdefJob(w, h, self.bd, f, k.pol[0 if key else 1]["cdef_damping"], w, w // 2, d["dbl_y"].ptr, d["dbl_u"].ptr, d["dbl_v"].ptr,
+                            d["cdef_y"].ptr, d["cdef_u"].ptr, d["cdef_v"].ptr, d["cdef_sb" if key else "cdef_sb_p"].ptr, 0, skip_buf.ptr, skip_stride)
         c.cdef_frames(job)
         s, on, scr = self.d_src[t], self.d_lr_on[t], self.d_lr_scratch
         c.lr_frames_decide(d["cdef_y"], d["dbl_y"], self.d_ref[0], w, w, h, self.bd, 0, k.lr_unit, d["lr_y"], 0, f, s[0], scr[0], on, 0, 3)

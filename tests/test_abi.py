@@ -40,7 +40,9 @@ def test_policy_is_exported_and_frame_type_dependent(av1mi):
     """the filter-parameter policy lives in libav1mi.so only (round 1 kept two copies that disagreed on the P-frame level)"""
     k, p = av1mi.policy_frame_params(128, 8, 0), av1mi.policy_frame_params(128, 8, 1)
     assert list(k.lf_level) == [10] * 4 and list(p.lf_level) == [7] * 4      # libaom's key / inter fits for 8-bit
-    assert k.cdef_y == p.cdef_y and k.cdef_damping == p.cdef_damping and list(k.lr_unit_y) == [1, 3, -7, 15, 3, -7, 15, 0]
+    # CDEF: libaom's pick-from-q fits, one for intra-only and one for inter frames (weaker, no secondary strength at this q)
+    assert (k.cdef_y >> 2, k.cdef_y & 3) == (2, 1) and (p.cdef_y >> 2, p.cdef_y & 3) == (1, 0) and k.cdef_damping == p.cdef_damping == 5
+    assert list(k.lr_unit_y) == [1, 3, -7, 15, 3, -7, 15, 0]
     k10, p10 = av1mi.policy_frame_params(128, 10, 0), av1mi.policy_frame_params(128, 10, 1)
     assert list(k10.lf_level) == list(p10.lf_level)
 
