@@ -142,9 +142,12 @@ int RunBackend(const BackendJob &job, std::string *err) {
       auto exists = [&](int s, int t) { return g0 + s < ngops && (g0 + s) * G + t < y.nframes; };
       int T = 0;
       for (int t = 0; t < G; t++) if (exists(0, t)) T = t + 1;
-      auto code_oldest = [&](int t) -> bool {      // collect batch t and code it on the host cores
-        av1mi_gop_frame fr;
+      av1mi_gop_frame fr;
+      auto collect_oldest = [&]() -> bool {
         if (av1mi_gop_collect(gop, &fr) != AV1MI_OK) { *err = std::string("av1mi_gop_collect: ") + av1mi_last_error(ctx); return false; }
+        return true;
+      };
+      auto assemble = [&](int t) -> bool {         // the collected batch t -> temporal units (frame header + tile group, or the host coder)
         for (int s = 0; s < S; s++) {
           if (!exists(s, t)) continue;
           DescribeSessionFrame(fr, s, w, h, y.bd, &desc);
@@ -164,27 +167,36 @@ int RunBackend(const BackendJob &job, std::string *err) {
         }
         return true;
       };
-      for (int t = 0; t < T; t++) {
+      // The frames of batch t + 1 are read (one thread per segment) WHILE the host assembles batch t - lag: the session hands out
+      // the next input buffers as soon as the oldest batch has been collected.
+      struct Reads {
+        std::vector<std::thread> th; std::vector<char> ok;
+        bool join() { for (auto &x : th) if (x.joinable()) x.join(); th.clear(); for (char c : ok) if (!c) return false; return true; }
+        ~Reads() { for (auto &x : th) if (x.joinable()) x.join(); }
+      } reads;
+      auto start_reads = [&](int t) -> bool {
         void *py, *pu, *pv;
-        CHK(av1mi_gop_acquire_input(gop, &py, &pu, &pv));
-        // a shorter last GOP / fewer GOPs than segments: the slot keeps stale pixels, its output is dropped
-        std::vector<std::thread> readers;
-        std::vector<char> ok((size_t)S, 1);
+        if (av1mi_gop_acquire_input(gop, &py, &pu, &pv) != AV1MI_OK) { *err = std::string("av1mi_gop_acquire_input: ") + av1mi_last_error(ctx); return false; }
+        reads.ok.assign((size_t)S, 1);
         for (int s = 0; s < S; s++) {
-          if (!exists(s, t)) continue;
-          auto job_s = [&, s]() {
-            ok[(size_t)s] = y4m_read(&y, (g0 + s) * G + t, (unsigned char *)py + fy * s, (unsigned char *)pu + fc * s, (unsigned char *)pv + fc * s);
-          };
-          if (S > 1) readers.emplace_back(job_s); else job_s();
+          if (!exists(s, t)) continue;     // a shorter last GOP / fewer GOPs than segments: the slot keeps stale pixels, its output is dropped
+          reads.th.emplace_back([&, s, t, py, pu, pv]() {
+            reads.ok[(size_t)s] = y4m_read(&y, (g0 + s) * G + t, (unsigned char *)py + fy * s, (unsigned char *)pu + fc * s, (unsigned char *)pv + fc * s);
+          });
         }
-        for (auto &th : readers) th.join();
-        for (int s = 0; s < S; s++)
-          if (!ok[(size_t)s]) { *err = job.input + ": Invalid data found when processing input (truncated frame)"; code = 1; goto done; }
+        return true;
+      };
+      if (T > 0 && !start_reads(0)) { code = 2; goto done; }
+      for (int t = 0; t < T; t++) {
+        if (!reads.join()) { *err = job.input + ": Invalid data found when processing input (truncated frame)"; code = 1; goto done; }
         CHK(av1mi_gop_submit(gop, t == 0 ? 0 : 1));
-        if (t >= lag && !code_oldest(t - lag)) { code = 2; goto done; }    // the GPU works on the frames after it meanwhile
+        const bool have = t >= lag;
+        if (have && !collect_oldest()) { code = 2; goto done; }            // the GPU works on the frames after it meanwhile
+        if (t + 1 < T && !start_reads(t + 1)) { code = 2; goto done; }
+        if (have && !assemble(t - lag)) { code = 2; goto done; }
       }
       for (int t = std::max(0, T - lag); t < T; t++)
-        if (!code_oldest(t)) { code = 2; goto done; }
+        if (!collect_oldest() || !assemble(t)) { code = 2; goto done; }
       for (int s = 0; s < S; s++)
         for (size_t t = 0; t < units[(size_t)s].size(); t++)
           if (!sink.write(units[(size_t)s][t], t == 0, err)) { code = 1; goto done; }
