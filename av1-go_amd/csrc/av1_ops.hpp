@@ -369,7 +369,7 @@ AV1_HD void tok_partition_prefix(const FrameView &f, Sink &k, int sbr, int sbc, 
 
 // coeffs (5.11.39) of an N x N block (N = 8 luma, 4 chroma)
 // Default_Scan_4x4 / Default_Scan_8x8 for row-major blocks: diagonals, odd ones walked downwards from the top row
-struct ScanTables { uint8_t s4[16], s8[64]; };
+struct ScanTables { uint8_t s4[16], s8[64], i4[16], i8[64]; };      // scan order -> position, and position -> scan order
 AV1_HD void fill_scan_tables(ScanTables *t) {
   for (int N = 4; N <= 8; N += 4) {
     uint8_t *o = N == 4 ? t->s4 : t->s8;
@@ -379,6 +379,8 @@ AV1_HD void fill_scan_tables(ScanTables *t) {
         const int r = (d & 1) ? i : d - i, c = d - r;
         if (r < N && c < N) o[k++] = (uint8_t)(r * N + c);
       }
+    uint8_t *inv = N == 4 ? t->i4 : t->i8;
+    for (int i = 0; i < N * N; i++) inv[o[i]] = (uint8_t)i;
   }
 }
 // what a thread needs beside the frame to tokenize coefficients: its own scratch (LDS on the GPU: the magnitudes are read five
@@ -394,19 +396,18 @@ template <int N> AV1_HD void tok_coeffs(Sink &k, const TokScratch &ts, int plane
   // min(|level|, 15) | sign << 7 of the whole block, zero-padded to the right and below: every later read is from this copy
   // (the exact value of the rare levels above 14 is re-read from `lev`)
   uint8_t *mag = ts.mag;
-  for (int i = 0; i < kMagBytes / 4; i++) reinterpret_cast<u32a *>(mag)[i] = 0;
-  bool any = false;
+  const uint8_t *iscan = N == 4 ? ts.scan->i4 : ts.scan->i8;
+  for (int i = 0; i < (N + 2) * MS / 4; i++) reinterpret_cast<u32a *>(mag)[i] = 0;      // rows 0 .. N + 1: all a context template reaches
+  int eob = 0;      // 1 + the scan index of the last non-zero level, found while the block is copied (not by walking the scan backwards)
   for (int r = 0; r < nc / 8; r++) {
     struct alignas(16) L8 { int16_t v[8]; } q = *reinterpret_cast<const L8 *>(lev + 8 * r);
     for (int j = 0; j < 8; j++) {
       const int pos = 8 * r + j, v = q.v[j], a = iabs(v);
-      any |= v != 0;
+      if (v) eob = imax(eob, iscan[pos] + 1);
       mag[(pos >> LG) * MS + (pos & (N - 1))] = (uint8_t)((a > 15 ? 15 : a) | (v < 0 ? 128 : 0));
     }
   }
   auto at = [&](int pos) { return mag[(pos >> LG) * MS + (pos & (N - 1))]; };
-  int eob = 0;
-  if (any) for (int c = nc - 1; c >= 0; c--) if (at(scan[c])) { eob = c + 1; break; }
   const bool chroma = plane > 0;
   const int skip_slot = chroma ? S_TXB_SKIP_C + ((above_cul | above_dc) != 0) + ((left_cul | left_dc) != 0) : S_TXB_SKIP_Y;
   k.sym(skip_slot, eob == 0);
