@@ -52,11 +52,13 @@ __device__ __forceinline__ const void *ref_plane(const InterLaunch &L, int f, in
 // count and validity bound below is a constant.
 template <typename Pix, int RC>
 __global__ __launch_bounds__(256) void k_me_int(InterLaunch L) {
-  // window row stride in bytes: 35 dwords.  Consecutive lanes walk (dy pair, dx group): 5 consecutive dwords per dy pair, pairs
-  // two rows apart.  The window reads are ds_read2_b32 (32 banks per 32-lane group): with 28-dword rows two rows are 24 banks
-  // apart and pairs p and p + 4 land on the same banks (SQ_LDS_BANK_CONFLICT = 55 % of the LDS cycles); 2 x 35 = 6 mod 32 puts
-  // the six or seven pairs of a group on distinct banks.
-  constexpr int MAXR = 16, WS = 140;
+  // window row stride in bytes: 41 dwords.  The window reads are ds_read2_b32 / ds_read_b32 (32 banks per 32-lane group); a lane
+  // reads dword (by 8 + 3 dp + r) 41 + 2 bx + g (+ 0, 1, 2): 3 x 41 = 27 mod 32, so the six dy triples of a block start 5 banks
+  // apart (0, 27, 22, 17, 12, 7) and their five dx groups fill the gaps: 30 distinct banks.  That holds per BLOCK, so a block's
+  // 30 items are padded to 32 (one 32-lane group = one block; 16 x 32 items are the same 8 rounds as 16 x 30).  With 35-dword
+  // rows and 30 items per block every group straddled two blocks and two triples shared a bank: SQ_LDS_BANK_CONFLICT was 55 % of
+  // the LDS cycles.
+  constexpr int MAXR = 16, WS = 164;
   static_assert(WS >= 64 + 2 * MAXR + 4 && WS % 4 == 0, "window row must hold tile + range and be whole dwords");
   __shared__ __attribute__((aligned(16))) uint8_t win[(64 + 2 * MAXR) * WS];
   __shared__ __attribute__((aligned(16))) uint8_t srct[64 * 64];
@@ -109,7 +111,8 @@ __global__ __launch_bounds__(256) void k_me_int(InterLaunch L) {
   const int NG = (2 * R4) / 4 + 1;                 // groups of four dx starting at -R4
   constexpr int HD = 3;                            // vertical displacements per item
   const int NP = (NC + HD - 1) / HD;               // triples of vertical displacements (the last one may hold fewer)
-  const int per = NP * NG;                         // (dy triple, dx group) items per block
+  const int items = NP * NG;                       // (dy triple, dx group) items per block
+  const int per = RC == 8 ? 32 : items;            // lanes per block: padded to a 32-lane group when the count is known to be 30
   int16_t *mvs = L.mvs + (size_t)f * bw * bh * 2;
   // A lane scores THREE vertically adjacent displacements of four horizontal ones: they share six of their eight window
   // rows, so ten rows of three dwords and ONE copy of the source block's even rows are read for 24 QSADs (pairs: nine rows and a source
@@ -124,9 +127,9 @@ __global__ __launch_bounds__(256) void k_me_int(InterLaunch L) {
   for (int u0 = 0; u0 < 16 * per; u0 += 64) {
     const int u = u0 + lane;
     if (u < 16 * per) {
-      const int bi = (int)(((float)u + 0.5f) * inv_per), t = u - __mul24(bi, per), b = wave + 4 * bi;   // (plain products here became 64-bit multiply-adds)
+      const int bi = RC == 8 ? u >> 5 : (int)(((float)u + 0.5f) * inv_per), t = u - __mul24(bi, per), b = wave + 4 * bi;   // (plain products here became 64-bit multiply-adds)
       const int by = b >> 3, bx = b & 7;
-      if (sbx * 8 + bx < bw && sby * 8 + by < bh) {
+      if (t < items && sbx * 8 + bx < bw && sby * 8 + by < bh) {
         const int dp = (int)(((float)t + 0.5f) * inv_ng), g = t - __mul24(dp, NG);    // dy = 3 dp - R + {0, 1, 2}, dx0 = -R4 + 4 g
         const uint8_t *p = win + __mul24(by * 8 + HD * dp, WS) + bx * 8 + 4 * g;
         const uint8_t *s = srct + (by * 8) * 64 + bx * 8;
