@@ -82,7 +82,8 @@ class EntropyJob(C.Structure):
 
 class GopConfig(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("bit_depth", C.c_int), ("base_q_idx", C.c_int), ("gop_length", C.c_int),
-                ("segments", C.c_int), ("search_range", C.c_int), ("gpu_entropy", C.c_int)]
+                ("segments", C.c_int), ("search_range", C.c_int), ("gpu_entropy", C.c_int), ("visible_width", C.c_int),
+                ("visible_height", C.c_int)]
 
 
 class FrameParams(C.Structure):
@@ -115,9 +116,11 @@ def _view(ptr, shape, dtype):
 class GopSession:
     """av1mi_gop_* (include/av1mi.h): closed GOPs in lockstep, policy and PCIe plumbing inside the library."""
 
-    def __init__(self, ctx, width, height, bit_depth, base_q_idx, gop_length, segments=1, search_range=8, gpu_entropy=0):
+    def __init__(self, ctx, width, height, bit_depth, base_q_idx, gop_length, segments=1, search_range=8, gpu_entropy=0, visible=None):
+        """visible: the true (width, height) when width x height is it rounded up to 8 (the caller replicates the source edge)"""
         self.ctx, self.w, self.h, self.bd, self.segments = ctx, width, height, bit_depth, segments
-        self.cfg = GopConfig(width, height, bit_depth, base_q_idx, gop_length, segments, search_range, gpu_entropy)
+        vw, vh = visible if visible is not None else (0, 0)
+        self.cfg = GopConfig(width, height, bit_depth, base_q_idx, gop_length, segments, search_range, gpu_entropy, vw, vh)
         self.g = C.c_void_p()
         ctx.lib.av1mi_gop_open.argtypes = [C.c_void_p, C.POINTER(GopConfig), C.POINTER(C.c_void_p)]
         ctx._chk(ctx.lib.av1mi_gop_open(ctx.h, C.byref(self.cfg), C.byref(self.g)))
@@ -401,6 +404,9 @@ class Context:
                                                   C.c_void_p(d_orig.ptr), C.c_void_p(d_scratch.ptr), C.c_void_p(d_on.ptr + on_offset), int(on_stride)))
 
     # ---- fused intra-only segment pipeline
+    def extend_frames(self, d_plane, stride, w, h, visible_w, visible_h, bd, nframes):
+        self._chk(self.lib.av1mi_extend_frames(self.h, C.c_void_p(d_plane.ptr), stride, w, h, visible_w, visible_h, bd, nframes))
+
     def intra_encode(self, job):
         self._chk(self.lib.av1mi_intra_encode(self.h, C.byref(job)))
 

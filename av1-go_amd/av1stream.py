@@ -21,7 +21,8 @@ class ObuFrame(C.Structure):
                 ("reduced_tx_set", C.c_int32), ("disable_cdf_update", C.c_int32), ("tile_cols_log2", C.c_int32),
                 ("tile_rows_log2", C.c_int32), ("y_mode", C.c_void_p), ("angle_y", C.c_void_p), ("uv_mode", C.c_void_p),
                 ("angle_uv", C.c_void_p), ("cfl_alpha", C.c_void_p), ("skip", C.c_void_p), ("tx_type", C.c_void_p),
-                ("is_inter", C.c_void_p), ("mv", C.c_void_p), ("lev_y", C.c_void_p), ("lev_u", C.c_void_p), ("lev_v", C.c_void_p)]
+                ("is_inter", C.c_void_p), ("mv", C.c_void_p), ("lev_y", C.c_void_p), ("lev_u", C.c_void_p), ("lev_v", C.c_void_p),
+                ("visible_width", C.c_int32), ("visible_height", C.c_int32)]
 
 
 def lib():
@@ -45,11 +46,14 @@ _PTR_FIELDS = {"cdef_idx": np.uint8, "y_mode": np.uint8, "angle_y": np.int8, "uv
 def temporal_unit(width, height, bit_depth, base_q_idx, frame_type=0, with_sequence_header=True, threads=1, lf_level=(0, 0, 0, 0),
                   lf_sharpness=0, cdef_damping=3, cdef_bits=0, cdef_y=(0,), cdef_uv=(0,), lr_type=(0, 0, 0), lr_unit_shift=0, lr_uv_shift=0,
                   lr_units=(None, None, None), reduced_tx_set=0, disable_cdf_update=0, tile_cols_log2=-1, tile_rows_log2=-1, opstream=False,
-                  **arrays):
+                  visible=None, **arrays):
     """arrays: y_mode, angle_y, uv_mode, angle_uv, cfl_alpha, skip, tx_type, is_inter, mv, lev_y, lev_u, lev_v, cdef_idx (numpy, raster
-    order over 8x8 blocks; see av1_bitstream.hpp).  Returns bytes."""
+    order over 8x8 blocks; see av1_bitstream.hpp).  visible: (width, height) a decoder outputs when the coded size is the source's rounded up to 8.
+    Returns bytes."""
     f = ObuFrame()
     f.width, f.height, f.bit_depth, f.frame_type, f.base_q_idx = width, height, bit_depth, frame_type, base_q_idx
+    if visible is not None:
+        f.visible_width, f.visible_height = int(visible[0]), int(visible[1])
     for i in range(4):
         f.lf_level[i] = int(lf_level[i])
     f.lf_sharpness, f.cdef_damping, f.cdef_bits = lf_sharpness, cdef_damping, cdef_bits
@@ -92,6 +96,8 @@ def assemble_temporal_unit(width, height, bit_depth, base_q_idx, payloads, sizes
     """temporal unit around tile payloads coded on the GPU (av1mi_obu_assemble_temporal_unit); hdr = header_from_params(...)"""
     f = ObuFrame()
     f.width, f.height, f.bit_depth, f.base_q_idx = width, height, bit_depth, base_q_idx
+    if hdr.get("visible") is not None:
+        f.visible_width, f.visible_height = int(hdr["visible"][0]), int(hdr["visible"][1])
     f.frame_type = hdr.get("frame_type", 0)
     for i in range(4):
         f.lf_level[i] = int(hdr.get("lf_level", (0,) * 4)[i])
@@ -121,10 +127,10 @@ def assemble_temporal_unit(width, height, bit_depth, base_q_idx, payloads, sizes
     return out[:n].tobytes()
 
 
-def session_frame_unit_gpu(width, height, bit_depth, frame, seg, with_sequence_header=None):
+def session_frame_unit_gpu(width, height, bit_depth, frame, seg, with_sequence_header=None, visible=None):
     """the temporal unit of segment `seg` of a collected batch whose tiles were entropy-coded on the GPU (gpu_entropy != 0)"""
     p = frame["params"]
-    hdr = header_from_params(p, width, height, frame["lr_on"][seg])
+    hdr = header_from_params(p, width, height, frame["lr_on"][seg], visible)
     nt = frame["tiles_per_frame"]
     sizes = frame["tile_size"][seg * nt:(seg + 1) * nt]
     start = int(frame["tile_size"][:seg * nt].sum(dtype=np.uint64))
@@ -133,24 +139,27 @@ def session_frame_unit_gpu(width, height, bit_depth, frame, seg, with_sequence_h
     return assemble_temporal_unit(width, height, bit_depth, p.base_q_idx, pay, sizes, with_sequence_header=sh, **hdr)
 
 
-def header_from_params(p, width, height, lr_on=None):
+def header_from_params(p, width, height, lr_on=None, visible=None):
     """keyword arguments of temporal_unit() for a frame whose filter parameters are an av1mi_frame_params (GOP session policy);
-    lr_on: the encoder's restoration ON / OFF decision per plane (the session's frame["lr_on"][segment]; None = the policy's types)"""
+    lr_on: the encoder's restoration ON / OFF decision per plane (the session's frame["lr_on"][segment]; None = the policy's types);
+    visible: the true (width, height) when the coded size is rounded up to 8 (the restoration units tile the TRUE frame)"""
     ur = lambda n: max(1, (n + p.lr_unit_size // 2) // p.lr_unit_size)
-    uy = np.tile(np.array(list(p.lr_unit_y), np.int8), (ur(height), ur(width), 1))
-    uc = np.tile(np.array(list(p.lr_unit_uv), np.int8), (ur(height // 2), ur(width // 2), 1))
+    vw, vh = visible if visible is not None else (width, height)
+    uy = np.tile(np.array(list(p.lr_unit_y), np.int8), (ur(vh), ur(vw), 1))
+    uc = np.tile(np.array(list(p.lr_unit_uv), np.int8), (ur((vh + 1) // 2), ur((vw + 1) // 2), 1))
     shift = {64: 0, 128: 1, 256: 2}[p.lr_unit_size]
     types = [int(p.lr_unit_y[0]), int(p.lr_unit_uv[0]), int(p.lr_unit_uv[0])]
     if lr_on is not None:
         types = [t if int(k) else 0 for t, k in zip(types, lr_on)]
     return dict(frame_type=p.frame_type, lf_level=tuple(p.lf_level), lf_sharpness=p.lf_sharpness, cdef_damping=p.cdef_damping,
-                cdef_y=(p.cdef_y,), cdef_uv=(p.cdef_uv,), lr_type=tuple(types), lr_unit_shift=shift, lr_uv_shift=0, lr_units=(uy, uc, uc))
+                cdef_y=(p.cdef_y,), cdef_uv=(p.cdef_uv,), lr_type=tuple(types), lr_unit_shift=shift, lr_uv_shift=0, lr_units=(uy, uc, uc),
+                **({} if visible is None else {"visible": (int(vw), int(vh))}))
 
 
-def session_frame_unit(width, height, bit_depth, frame, seg, with_sequence_header=None, threads=1):
+def session_frame_unit(width, height, bit_depth, frame, seg, with_sequence_header=None, threads=1, visible=None):
     """the temporal unit of segment `seg` of a collected GOP-session batch (av1mi.GopSession.collect())"""
     p = frame["params"]
-    hdr = header_from_params(p, width, height, frame["lr_on"][seg])
+    hdr = header_from_params(p, width, height, frame["lr_on"][seg], visible)
     if p.frame_type == 0:
         sym = dict(y_mode=frame["y_mode"][seg], uv_mode=frame["uv_mode"][seg])
     else:

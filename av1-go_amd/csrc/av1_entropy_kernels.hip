@@ -409,7 +409,8 @@ int av1mi::av1_entropy_submit(av1mi_ctx *ctx, const av1mi_av1_entropy_job *j, hi
   L.fv.lev_y = j->d_lev_y; L.fv.lev_u = j->d_lev_u; L.fv.lev_v = j->d_lev_v;
   for (int p = 0; p < 3; p++) {
     L.fv.lr_on[p] = j->lr_on[p] != 0;
-    const int ph = p ? j->height / 2 : j->height, pw = p ? j->width / 2 : j->width;
+    const int vh = j->visible_height ? j->visible_height : j->height, vw = j->visible_width ? j->visible_width : j->width;   // the units tile the TRUE frame
+    const int ph = p ? (vh + 1) / 2 : vh, pw = p ? (vw + 1) / 2 : vw;
     L.fv.lr_rows[p] = (ph + 32) / 64 > 1 ? (ph + 32) / 64 : 1; L.fv.lr_cols[p] = (pw + 32) / 64 > 1 ? (pw + 32) / 64 : 1;
   }
   memcpy(L.fv.lr_unit[0], j->lr_unit_y, 8); memcpy(L.fv.lr_unit[1], j->lr_unit_uv, 8);

@@ -460,6 +460,17 @@ int av1mi_lr_frames_decide(av1mi_ctx *ctx, const void *d_cdef, const void *d_deb
   return AV1MI_OK;
 }
 
+int av1mi_extend_frames(av1mi_ctx *ctx, void *d_plane, int stride, int w, int h, int visible_w, int visible_h, int bd, int nframes) {
+  BIND(ctx);
+  if (!d_plane) return fail(ctx, AV1MI_E_INVAL, "null device pointer");
+  if (bd != 8 && bd != 10) return fail(ctx, AV1MI_E_INVAL, "bit depth %d not supported (8 or 10)", bd);
+  if (w <= 0 || h <= 0 || stride < w || visible_w <= 0 || visible_h <= 0 || visible_w > w || visible_h > h)
+    return fail(ctx, AV1MI_E_INVAL, "bad plane geometry %dx%d (visible %dx%d) stride %d", w, h, visible_w, visible_h, stride);
+  if (nframes < 0 || nframes > 65535) return fail(ctx, AV1MI_E_INVAL, "nframes %d out of range", nframes);
+  HIP_TRY(ctx, av1mi::launch_extend(d_plane, stride, w, h, visible_w, visible_h, bd, nframes, ctx->stream));
+  return AV1MI_OK;
+}
+
 int av1mi_intra_encode(av1mi_ctx *ctx, const av1mi_intra_job *j) {
   BIND(ctx);
   if (!j) return fail(ctx, AV1MI_E_INVAL, "null job");

@@ -90,6 +90,7 @@ struct av1mi_gop {
   void *d_mi[2][2] = {};                       // [key / inter][luma / chroma] deblocking mode-info maps (one frame, shared by the batch)
   void *d_cdef_sb[2] = {}, *d_lr[2] = {}, *d_zero_skip = nullptr;
   void *d_lr_scratch[3] = {};                  // the restoration decision's partial sums, per plane
+  int vw = 0, vh = 0;                          // the true frame size (== the coded size unless cfg.visible_* say otherwise)
   int last = 0;                                // slot of the most recent batch (its d_lr_on selects the next batch's references)
   av1mi_frame_params params[2];                // key, inter
   size_t ent_cap = 0; int tiles = 0;           // GPU entropy coding: payload capacity of a batch, tiles per frame
@@ -129,6 +130,7 @@ int setup(av1mi_gop *g) {
   const int w = c.width, h = c.height, S = c.segments;
   g->bps = c.bit_depth == 8 ? 1 : 2;
   g->ny = (size_t)w * h * S; g->nc = g->ny / 4; g->nb = g->ny / 64;
+  g->vw = c.visible_width ? c.visible_width : w; g->vh = c.visible_height ? c.visible_height : h;
   G_HIP(hipSetDevice(av1mi::ctx_device(g->ctx)));
   G_HIP(hipStreamCreateWithFlags(&g->up, hipStreamNonBlocking));
   // (created in every mode, used only where symbols go to the host at submit time or a batch falls back.  HIP deals its four
@@ -182,6 +184,10 @@ int setup(av1mi_gop *g) {
     // deblocking mode-info words (av1mi_deblock_plane): 8x8 luma / 4x4 chroma transforms, every block edge a prediction edge
     std::vector<uint32_t> mi(fy / 16, 3u | (3u << 4) | ((uint32_t)P.lf_level[0] << 8) | ((uint32_t)P.lf_level[1] << 16) | (3u << 25));
     std::vector<uint32_t> mic(fc / 16, 2u | (2u << 4) | ((uint32_t)P.lf_level[2] << 8) | ((uint32_t)P.lf_level[2] << 16) | (3u << 25));
+    // units that start at or beyond the true size (spec 7.14.2 onScreen; a chroma unit is two luma units wide) are never filtered:
+    // "skipped inter block, no block edge"
+    for (int r = 0; r < h / 4; r++) for (int cc = 0; cc < w / 4; cc++) if (4 * r >= g->vh || 4 * cc >= g->vw) mi[(size_t)r * (w / 4) + cc] = 3u | (3u << 4) | (1u << 24);
+    for (int r = 0; r < h / 8; r++) for (int cc = 0; cc < w / 8; cc++) if (8 * r >= g->vh || 8 * cc >= g->vw) mic[(size_t)r * (w / 8) + cc] = 2u | (2u << 4) | (1u << 24);
     G_TRY(dev_alloc(g, &g->d_mi[t][0], mi.size() * 4)); G_TRY(av1mi_upload(g->ctx, g->d_mi[t][0], mi.data(), mi.size() * 4));
     G_TRY(dev_alloc(g, &g->d_mi[t][1], mic.size() * 4)); G_TRY(av1mi_upload(g->ctx, g->d_mi[t][1], mic.data(), mic.size() * 4));
   }
@@ -219,6 +225,10 @@ int av1mi_gop_open(av1mi_ctx *ctx, const av1mi_gop_config *cfg, av1mi_gop **out)
   if (!cfg) return av1mi::ctx_fail(ctx, AV1MI_E_INVAL, "null config");
   if (cfg->width <= 0 || cfg->height <= 0 || (cfg->width & 7) || (cfg->height & 7) || cfg->width > 16384 || cfg->height > 16384)
     return av1mi::ctx_fail(ctx, AV1MI_E_INVAL, "frame %dx%d must be a multiple of 8", cfg->width, cfg->height);
+  if (cfg->visible_width < 0 || cfg->visible_height < 0 || (cfg->visible_width && (cfg->visible_width > cfg->width || cfg->width - cfg->visible_width >= 8)) ||
+      (cfg->visible_height && (cfg->visible_height > cfg->height || cfg->height - cfg->visible_height >= 8)))
+    return av1mi::ctx_fail(ctx, AV1MI_E_INVAL, "visible size %dx%d must lie within 7 samples below the coded size %dx%d", cfg->visible_width, cfg->visible_height,
+                           cfg->width, cfg->height);
   if (cfg->bit_depth != 8 && cfg->bit_depth != 10) return av1mi::ctx_fail(ctx, AV1MI_E_INVAL, "bit depth %d not supported (8 or 10)", cfg->bit_depth);
   if (cfg->base_q_idx < 1 || cfg->base_q_idx > 255 || cfg->gop_length < 1 || cfg->segments < 1 || cfg->segments > 4096 || cfg->search_range < 0 ||
       cfg->search_range > 15 || cfg->gpu_entropy < 0 || cfg->gpu_entropy > 2)
@@ -354,6 +364,15 @@ int av1mi_gop_submit(av1mi_gop *g, int frame_type) {
   // (the slot's next inter kernel is kSlots batches away and ordered behind this CDEF on the main stream, nothing else writes them)
   cj.d_skip8 = (const uint8_t *)(frame_type == 0 ? g->d_zero_skip : s.d_skip); cj.skip_frame_stride = frame_type == 0 ? 0 : (size_t)(w / 8) * (h / 8);
   G_TRY(av1mi_cdef_frames(g->ctx, &cj));
+  // a true size that is not a multiple of 8: the decoder's restoration clamps at the true last column / row (CDEF above read the
+  // planes as they were: it works on the coded size in a decoder too)
+  const bool padded = g->vw != w || g->vh != h;
+  if (padded)
+    for (int p = 0; p < 3; p++) {
+      const int pw = p ? w / 2 : w, ph = p ? h / 2 : h, pvw = p ? (g->vw + 1) / 2 : g->vw, pvh = p ? (g->vh + 1) / 2 : g->vh;
+      G_TRY(av1mi_extend_frames(g->ctx, g->d_dbl[p], pw, pw, ph, pvw, pvh, bd, S));
+      G_TRY(av1mi_extend_frames(g->ctx, g->d_cdef[p], pw, pw, ph, pvw, pvh, bd, S));
+    }
   // loop restoration of every frame, and the decision per segment and plane whether it stays ON (it must lower the squared error
   // against the source): d_ref always receives the restored planes, the next batch's kernels choose between d_ref and d_cdef
   for (int p = 0; p < 3; p++) {
@@ -361,6 +380,9 @@ int av1mi_gop_submit(av1mi_gop *g, int frame_type) {
     G_TRY(av1mi_lr_frames_decide(g->ctx, g->d_cdef[p], g->d_dbl[p], g->d_ref[p], pw, pw, ph, bd, p > 0, P.lr_unit_size, (const int8_t *)g->d_lr[p > 0], 0, S,
                                  s.d_src[p], g->d_lr_scratch[p], (uint8_t *)s.d_lr_on + p, 3));
   }
+  if (padded)      // ... and so do its motion-compensation reads of this frame
+    for (int p = 0; p < 3; p++)
+      G_TRY(av1mi_extend_frames(g->ctx, g->d_ref[p], p ? w / 2 : w, p ? w / 2 : w, p ? h / 2 : h, p ? (g->vw + 1) / 2 : g->vw, p ? (g->vh + 1) / 2 : g->vh, bd, S));
   G_HIP(hipEventRecord(s.filters_done, main));
   if (s.symbols_down) {
     G_HIP(hipStreamWaitEvent(g->down, s.filters_done, 0));
@@ -382,6 +404,7 @@ int av1mi_gop_submit(av1mi_gop *g, int frame_type) {
     ej.d_mvs = (const int16_t *)s.d_mv; ej.d_skip = (const uint8_t *)s.d_skip;
     ej.lr_on[0] = P.lr_unit_y[0] == 1; ej.lr_on[1] = ej.lr_on[2] = P.lr_unit_uv[0] == 1;
     ej.d_lr_on = (const uint8_t *)s.d_lr_on;
+    ej.visible_width = g->vw; ej.visible_height = g->vh;
     memcpy(ej.lr_unit_y, P.lr_unit_y, 8); memcpy(ej.lr_unit_uv, P.lr_unit_uv, 8);
     ej.d_out = (uint8_t *)s.h_ent_out; ej.out_cap = g->ent_cap; ej.d_tile_size = (uint32_t *)s.d_tile_size; ej.d_total = (uint64_t *)s.d_total;
     G_TRY(av1mi::av1_entropy_submit(g->ctx, &ej, side, back));

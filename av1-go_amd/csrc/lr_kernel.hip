@@ -350,6 +350,33 @@ __global__ __launch_bounds__(64) void k_lr_decide(const unsigned long long *sse,
   on[(size_t)f * on_stride] = a < b;
 }
 
+// A frame whose true size (vw x vh) is not a multiple of 8 is coded at the size rounded up (w x h, at most 7 more columns / rows).
+// A decoder clamps motion-compensation and restoration reads at the TRUE last column / row (spec 7.11.3.4 lastX / lastY, 7.17
+// PlaneEndX / PlaneEndY); the kernels clamp at the coded size.  Replicating the true edge into the padding makes both read the
+// same values.  One thread per padded sample: first the columns right of vw for the rows above vh, then whole rows below vh
+// (which copy row vh - 1 with ITS columns already clamped).
+template <typename Pix> __global__ __launch_bounds__(256) void k_extend(Pix *plane, int stride, int w, int h, int vw, int vh, int nframes) {
+  const int pw = w - vw, ph = h - vh;                 // padding columns / rows
+  const long per = (long)pw * vh + (long)ph * w;      // padded samples of a frame
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= per * nframes) return;
+  const int f = (int)(i / per);
+  const long k = i - (long)f * per;
+  Pix *p = plane + (size_t)f * h * stride;
+  int x, y;
+  if (k < (long)pw * vh) { y = (int)(k / pw); x = vw + (int)(k - (long)y * pw); }
+  else { const long r = k - (long)pw * vh; y = vh + (int)(r / w); x = (int)(r - (long)(y - vh) * w); }
+  p[(size_t)y * stride + x] = p[(size_t)min(y, vh - 1) * stride + min(x, vw - 1)];
+}
+hipError_t launch_extend(void *plane, int stride, int w, int h, int vw, int vh, int bd, int nframes, hipStream_t s) {
+  const long n = ((long)(w - vw) * vh + (long)(h - vh) * w) * nframes;
+  if (n <= 0) return hipSuccess;
+  const dim3 grid((unsigned)((n + 255) / 256));
+  if (bd == 8) hipLaunchKernelGGL(k_extend<uint8_t>, grid, dim3(256), 0, s, (uint8_t *)plane, stride, w, h, vw, vh, nframes);
+  else hipLaunchKernelGGL(k_extend<uint16_t>, grid, dim3(256), 0, s, (uint16_t *)plane, stride, w, h, vw, vh, nframes);
+  return hipGetLastError();
+}
+
 int lr_stripes(int h, int ss) { return (h + (8 >> ss) + (64 >> ss) - 1) / (64 >> ss); }
 hipError_t launch_lr_decide(const unsigned long long *sse, int nframes, int stripes, uint8_t *on, int on_stride, hipStream_t s) {
   hipLaunchKernelGGL(k_lr_decide, dim3((unsigned)((nframes + 63) / 64)), dim3(64), 0, s, sse, nframes, stripes, on, on_stride);

@@ -286,6 +286,9 @@ bool check(const av1mi_obu_frame &f, std::string *err, bool need_symbols = true)
   auto bad = [&](const char *m) { if (err) *err = m; return false; };
   if (f.width <= 0 || f.height <= 0 || (f.width & 7) || (f.height & 7) || f.width > 4096 || f.height > 4096)
     return bad("frame size must be a multiple of 8 and at most 4096x4096 (64 superblock tiles per dimension)");
+  if (f.visible_width < 0 || f.visible_height < 0 || (f.visible_width && (f.visible_width > f.width || f.width - f.visible_width >= 8)) ||
+      (f.visible_height && (f.visible_height > f.height || f.height - f.visible_height >= 8)))
+    return bad("visible size must lie within 7 samples below the coded size");
   if (f.bit_depth != 8 && f.bit_depth != 10) return bad("bit depth must be 8 or 10");
   if (f.frame_type != 0 && f.frame_type != 1) return bad("frame_type must be 0 (key) or 1 (inter)");
   if (f.base_q_idx < 1 || f.base_q_idx > 255) return bad("base_q_idx must be 1..255 (0 is the lossless mode, not coded)");
@@ -325,7 +328,8 @@ FrameInfo frame_info(const av1mi_obu_frame &f) {
   fi.qcat = f.base_q_idx <= 20 ? 0 : f.base_q_idx <= 60 ? 1 : f.base_q_idx <= 120 ? 2 : 3;   // init_coeff_cdfs index (7.20)
   for (int p = 0; p < 3; p++) {
     fi.lr_size[p] = (64 << f.lr_unit_shift) >> (p ? f.lr_uv_shift : 0);
-    const int ph = p ? (f.height + 1) >> 1 : f.height, pw = p ? (f.width + 1) >> 1 : f.width;
+    const int vh = visible_height(f), vw = visible_width(f);      // the restoration units tile the TRUE frame (spec 5.9.20 unitRows / unitCols)
+    const int ph = p ? (vh + 1) >> 1 : vh, pw = p ? (vw + 1) >> 1 : vw;
     fi.lr_rows[p] = std::max((ph + (fi.lr_size[p] >> 1)) / fi.lr_size[p], 1);   // count_units_in_frame (5.11.57)
     fi.lr_cols[p] = std::max((pw + (fi.lr_size[p] >> 1)) / fi.lr_size[p], 1);
   }
@@ -1031,7 +1035,7 @@ bool temporal_unit(const av1mi_obu_frame &f, bool with_sequence_header, int thre
   if (!frame_obu(f, threads, &fr, err)) return false;
   *out = temporal_delimiter_obu();
   if (with_sequence_header) {
-    SequenceParams sp; sp.width = f.width; sp.height = f.height; sp.bit_depth = f.bit_depth;
+    const SequenceParams sp = sequence_params(f);
     const std::vector<uint8_t> sh = sequence_header_obu(sp);
     out->insert(out->end(), sh.begin(), sh.end());
   }

@@ -32,6 +32,13 @@ struct SequenceParams {
   bool operator==(const SequenceParams &o) const { return width == o.width && height == o.height && bit_depth == o.bit_depth; }
 };
 
+// the size a decoder outputs (av1mi_obu_frame.visible_*: 0 = the coded size) and the sequence header that announces it
+inline int visible_width(const av1mi_obu_frame &f) { return f.visible_width ? f.visible_width : f.width; }
+inline int visible_height(const av1mi_obu_frame &f) { return f.visible_height ? f.visible_height : f.height; }
+inline SequenceParams sequence_params(const av1mi_obu_frame &f) {
+  SequenceParams sp; sp.width = visible_width(f); sp.height = visible_height(f); sp.bit_depth = f.bit_depth;
+  return sp;
+}
 // OBU_TEMPORAL_DELIMITER (spec 5.6)
 std::vector<uint8_t> temporal_delimiter_obu();
 // OBU_SEQUENCE_HEADER (spec 5.5)

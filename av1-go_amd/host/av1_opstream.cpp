@@ -36,7 +36,7 @@ bool opstream_tiles(const av1mi_obu_frame &f, std::vector<std::vector<uint8_t>> 
   if (!v.key && !v.skip) { zskip.assign((size_t)v.w8 * v.h8, 0); v.skip = zskip.data(); }
   for (int p = 0; p < 3; p++) {
     v.lr_on[p] = f.lr_type[p] == 1;
-    const int ph = p ? f.height / 2 : f.height, pw = p ? f.width / 2 : f.width;
+    const int ph = p ? (visible_height(f) + 1) >> 1 : visible_height(f), pw = p ? (visible_width(f) + 1) >> 1 : visible_width(f);
     v.lr_rows[p] = std::max((ph + 32) / 64, 1); v.lr_cols[p] = std::max((pw + 32) / 64, 1);
   }
   // the op-stream coder takes ONE unit record per plane class (what the session's policy produces): check and copy it

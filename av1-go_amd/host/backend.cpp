@@ -48,19 +48,20 @@ bool y4m_open(const std::string &path, Y4m *y, std::string *err) {
   if (cs.rfind("420p10", 0) == 0) y->bd = 10;
   else if (cs.rfind("420", 0) == 0 && cs.find("p1") == std::string::npos) y->bd = 8;
   else { *err = "Invalid argument: unsupported Y4M colourspace " + cs + " (4:2:0 8/10-bit only)"; return false; }
-  if (y->w <= 0 || y->h <= 0 || (y->w & 7) || (y->h & 7)) { *err = "Invalid argument: frame size must be a multiple of 8"; return false; }
+  if (y->w < 8 || y->h < 8) { *err = "Invalid argument: frame size below 8x8"; return false; }
   if (y->w > 4096 || y->h > 4096) { *err = "Invalid argument: frames above 4096x4096 need more than 64 tile rows / columns"; return false; }
   if (y->fps_n <= 0 || y->fps_d <= 0) { y->fps_n = 30; y->fps_d = 1; }
-  y->frame_bytes = (size_t)y->w * y->h * (y->bd == 8 ? 1 : 2) * 3 / 2;
+  // Y4M 4:2:0 planes of a w x h picture: w * h luma and two ceil(w / 2) * ceil(h / 2) chroma planes
+  y->frame_bytes = ((size_t)y->w * y->h + 2 * (size_t)((y->w + 1) / 2) * ((y->h + 1) / 2)) * (y->bd == 8 ? 1 : 2);
   struct stat st;
   if (fstat(fileno(y->f), &st)) { *err = path + ": cannot stat"; return false; }
   y->nframes = (long)((st.st_size - y->hdr_len) / (off_t)(6 + y->frame_bytes));   // "FRAME\n" + planes
   return true;
 }
-// frame `idx` into the three plane pointers; false on a malformed or truncated frame
-// frame idx -> the three planes; pread, so the segments of a batch are read by threads of their own (a single thread copies
-// ~5 GB/s out of the page cache: 215 frames/s at 4K 10-bit, one eighth of what the GPU takes)
-bool y4m_read(const Y4m *y, long idx, unsigned char *Y, unsigned char *U, unsigned char *V) {
+// frame idx -> the three planes of the CODED size cw x ch (the true size rounded up to 8: the last column / row replicated into
+// the padding); pread, so the segments of a batch are read by threads of their own (a single thread copies ~5 GB/s out of the
+// page cache: 215 frames/s at 4K 10-bit, one eighth of what the GPU takes).  false on a malformed or truncated frame.
+bool y4m_read(const Y4m *y, long idx, int cw, int ch, unsigned char *Y, unsigned char *U, unsigned char *V) {
   const int fd = fileno(y->f);
   off_t off = (off_t)y->hdr_len + (off_t)idx * (off_t)(6 + y->frame_bytes);
   auto rd = [&](void *dst, size_t n) {
@@ -74,21 +75,35 @@ bool y4m_read(const Y4m *y, long idx, unsigned char *Y, unsigned char *U, unsign
   };
   char tag[6];
   if (!rd(tag, 6) || memcmp(tag, "FRAME\n", 6)) return false;
-  const size_t ny = y->frame_bytes * 2 / 3, nc = ny / 4;
-  return rd(Y, ny) && rd(U, nc) && rd(V, nc);
+  const size_t bps = y->bd == 8 ? 1 : 2;
+  // one plane: pw x ph samples in the file -> dw x dh in memory
+  auto plane = [&](unsigned char *dst, int pw, int ph, int dw, int dh) {
+    if (pw == dw) { if (!rd(dst, (size_t)pw * ph * bps)) return false; }
+    else
+      for (int r = 0; r < ph; r++) {
+        unsigned char *row = dst + (size_t)r * dw * bps;
+        if (!rd(row, (size_t)pw * bps)) return false;
+        for (int c = pw; c < dw; c++) memcpy(row + (size_t)c * bps, row + (size_t)(pw - 1) * bps, bps);
+      }
+    for (int r = ph; r < dh; r++) memcpy(dst + (size_t)r * dw * bps, dst + (size_t)(ph - 1) * dw * bps, (size_t)dw * bps);
+    return true;
+  };
+  return plane(Y, y->w, y->h, cw, ch) && plane(U, (y->w + 1) / 2, (y->h + 1) / 2, cw / 2, ch / 2) && plane(V, (y->w + 1) / 2, (y->h + 1) / 2, cw / 2, ch / 2);
 }
 
 }  // namespace
 
-void DescribeSessionFrame(const av1mi_gop_frame &fr, int seg, int width, int height, int bit_depth, SessionFrameDesc *d) {
+void DescribeSessionFrame(const av1mi_gop_frame &fr, int seg, int width, int height, int bit_depth, SessionFrameDesc *d, int visible_width, int visible_height) {
   const av1mi_frame_params &p = fr.params;
   av1mi_obu_frame &f = d->f;
   memset(&f, 0, sizeof(f));
   f.width = width; f.height = height; f.bit_depth = bit_depth; f.frame_type = p.frame_type; f.base_q_idx = p.base_q_idx;
+  f.visible_width = visible_width; f.visible_height = visible_height;
   for (int i = 0; i < 4; i++) f.lf_level[i] = p.lf_level[i];
   f.lf_sharpness = p.lf_sharpness; f.cdef_damping = p.cdef_damping; f.cdef_bits = 0; f.cdef_y[0] = p.cdef_y; f.cdef_uv[0] = p.cdef_uv;
   auto units = [&](int n) { const int u = (n + p.lr_unit_size / 2) / p.lr_unit_size; return u > 1 ? u : 1; };
-  const size_t uy = (size_t)units(height) * units(width), uc = (size_t)units(height / 2) * units(width / 2);
+  const int vw = visible_width ? visible_width : width, vh = visible_height ? visible_height : height;      // the units tile the TRUE frame
+  const size_t uy = (size_t)units(vh) * units(vw), uc = (size_t)units((vh + 1) / 2) * units((vw + 1) / 2);
   d->lr_y.resize(uy * 8); d->lr_uv.resize(uc * 8);
   for (size_t i = 0; i < uy; i++) memcpy(&d->lr_y[i * 8], p.lr_unit_y, 8);
   for (size_t i = 0; i < uc; i++) memcpy(&d->lr_uv[i * 8], p.lr_unit_uv, 8);
@@ -121,17 +136,19 @@ int RunBackend(const BackendJob &job, std::string *err) {
   if (!y4m_open(job.input, &y, err)) { code = 1; goto done; }
   if (y.nframes <= 0) { *err = job.input + ": Invalid data found when processing input (no frames)"; code = 1; goto done; }
   {
-    const int G = job.gop, w = y.w, h = y.h;
+    const int G = job.gop, w = (y.w + 7) & ~7, h = (y.h + 7) & ~7;       // the coded size; y.w x y.h is what a decoder outputs
     const long ngops = (y.nframes + G - 1) / G;
     const int S = (int)std::min<long>(std::max(job.segments, 1), ngops);
     const int threads = job.threads > 0 ? job.threads : (int)std::max(1u, std::thread::hardware_concurrency());
     const size_t bps = y.bd == 8 ? 1 : 2, fy = (size_t)w * h * bps, fc = fy / 4;
     av1mi_gop_config cfg;
+    memset(&cfg, 0, sizeof(cfg));
+    if (w != y.w || h != y.h) { cfg.visible_width = y.w; cfg.visible_height = y.h; }
     cfg.width = w; cfg.height = h; cfg.bit_depth = y.bd; cfg.base_q_idx = job.quality < 1 ? 1 : job.quality; cfg.gop_length = G; cfg.segments = S;
     cfg.search_range = 8;
     cfg.gpu_entropy = job.gpu_entropy ? 1 : 0;
     CHK(av1mi_gop_open(ctx, &cfg, &gop));
-    av1::SequenceParams sp; sp.width = w; sp.height = h; sp.bit_depth = y.bd;
+    av1::SequenceParams sp; sp.width = y.w; sp.height = y.h; sp.bit_depth = y.bd;
     if (!sink.open(job.output, sp, y.fps_n, y.fps_d, err)) { code = 1; goto done; }
     std::vector<std::vector<std::vector<uint8_t>>> units((size_t)S);   // [segment][frame] temporal units of the batch in flight
     SessionFrameDesc desc;
@@ -150,7 +167,7 @@ int RunBackend(const BackendJob &job, std::string *err) {
       auto assemble = [&](int t) -> bool {         // the collected batch t -> temporal units (frame header + tile group, or the host coder)
         for (int s = 0; s < S; s++) {
           if (!exists(s, t)) continue;
-          DescribeSessionFrame(fr, s, w, h, y.bd, &desc);
+          DescribeSessionFrame(fr, s, w, h, y.bd, &desc, cfg.visible_width, cfg.visible_height);
           std::vector<uint8_t> tu;
           std::string werr;
           if (fr.tile_size) {      // tiles coded on the GPU: frame header + tile group around them
@@ -181,7 +198,7 @@ int RunBackend(const BackendJob &job, std::string *err) {
         for (int s = 0; s < S; s++) {
           if (!exists(s, t)) continue;     // a shorter last GOP / fewer GOPs than segments: the slot keeps stale pixels, its output is dropped
           reads.th.emplace_back([&, s, t, py, pu, pv]() {
-            reads.ok[(size_t)s] = y4m_read(&y, (g0 + s) * G + t, (unsigned char *)py + fy * s, (unsigned char *)pu + fc * s, (unsigned char *)pv + fc * s);
+            reads.ok[(size_t)s] = y4m_read(&y, (g0 + s) * G + t, w, h, (unsigned char *)py + fy * s, (unsigned char *)pu + fc * s, (unsigned char *)pv + fc * s);
           });
         }
         return true;

@@ -11,5 +11,7 @@ namespace av1mi_host {
 // < 0 = could not run (no HIP device / library unusable).  *err carries the text.
 int RunBackend(const BackendJob &job, std::string *err);
 // the bitstream writer's frame description for segment `seg` of a collected session batch (pointers into the batch)
-void DescribeSessionFrame(const av1mi_gop_frame &fr, int seg, int width, int height, int bit_depth, SessionFrameDesc *d);
+// visible_*: the true frame size when width x height is it rounded up to 8 (0 = the coded size)
+void DescribeSessionFrame(const av1mi_gop_frame &fr, int seg, int width, int height, int bit_depth, SessionFrameDesc *d, int visible_width = 0,
+                          int visible_height = 0);
 }

@@ -115,7 +115,7 @@ long long av1mi_obu_assemble_temporal_unit(const av1mi_obu_frame *f, const uint8
   }
   std::vector<uint8_t> b = av1::temporal_delimiter_obu();
   if (with_sequence_header) {
-    av1::SequenceParams sp; sp.width = f->width; sp.height = f->height; sp.bit_depth = f->bit_depth;
+    const av1::SequenceParams sp = av1::sequence_params(*f);
     const std::vector<uint8_t> sh = av1::sequence_header_obu(sp);
     b.insert(b.end(), sh.begin(), sh.end());
   }
@@ -135,7 +135,7 @@ long long av1mi_host_opstream_temporal_unit(const av1mi_obu_frame *f, int with_s
   if (!av1::frame_obu_from_tiles(*f, cat.data(), sizes.data(), (int)sizes.size(), &fr, &e)) return fail(-1);
   std::vector<uint8_t> b = av1::temporal_delimiter_obu();
   if (with_sequence_header) {
-    av1::SequenceParams sp; sp.width = f->width; sp.height = f->height; sp.bit_depth = f->bit_depth;
+    const av1::SequenceParams sp = av1::sequence_params(*f);
     const std::vector<uint8_t> sh = av1::sequence_header_obu(sp);
     b.insert(b.end(), sh.begin(), sh.end());
   }

@@ -23,20 +23,33 @@ def frame_policy(qindex, bd, frame_type):
     return av1mi.policy_frame_params(qindex, bd, frame_type)
 
 
-def policy_arrays(qindex, bd, frame_type, width, height, block_size=8):
-    """host-side arrays of a frame's filter parameters in the layouts the stage entry points take"""
+def policy_arrays(qindex, bd, frame_type, width, height, block_size=8, visible=None):
+    """host-side arrays of a frame's filter parameters in the layouts the stage entry points take.  visible: the true
+    (width, height) when the coded size is rounded up to 8: deblocking units that start beyond it are marked "not filtered" (spec
+    7.14.2 onScreen) and the restoration units tile the true frame."""
     p = frame_policy(qindex, bd, frame_type)
     l2y, l2c = int(np.log2(block_size)), int(np.log2(block_size // 2))
     nsb = ((height + 63) // 64) * ((width + 63) // 64)
     ur = lambda n: max(1, (n + p.lr_unit_size // 2) // p.lr_unit_size)
-    return dict(params=p,
-                mi_y=np.full((height // 4, width // 4), lf_mi_word(l2y, l2y, p.lf_level[0], p.lf_level[1]), np.uint32),
-                mi_c=np.full((height // 8, width // 8), lf_mi_word(l2c, l2c, p.lf_level[2], p.lf_level[2]), np.uint32),
+    vw, vh = visible if visible is not None else (width, height)
+    mi_y = np.full((height // 4, width // 4), lf_mi_word(l2y, l2y, p.lf_level[0], p.lf_level[1]), np.uint32)
+    mi_c = np.full((height // 8, width // 8), lf_mi_word(l2c, l2c, p.lf_level[2], p.lf_level[2]), np.uint32)
+    off_y, off_c = lf_mi_word(l2y, l2y, 0, 0, 1, 0, 0), lf_mi_word(l2c, l2c, 0, 0, 1, 0, 0)     # skip && inter, no block edge: never filtered
+    mi_y[(vh + 3) // 4:, :] = off_y; mi_y[:, (vw + 3) // 4:] = off_y                              # luma unit (r, c) starts at (4 r, 4 c)
+    mi_c[(vh + 7) // 8:, :] = off_c; mi_c[:, (vw + 7) // 8:] = off_c                              # chroma unit (r, c) = luma (8 r, 8 c)
+    return dict(params=p, mi_y=mi_y, mi_c=mi_c,
                 cdef_damping=p.cdef_damping,
                 cdef_sb=np.tile(np.array([p.cdef_y >> 2, p.cdef_y & 3, p.cdef_uv >> 2, p.cdef_uv & 3], np.uint8), (nsb, 1)),
                 lr_unit=p.lr_unit_size,
                 lr_units_y=np.tile(np.array(list(p.lr_unit_y), np.int8), (ur(height), ur(width), 1)),
                 lr_units_c=np.tile(np.array(list(p.lr_unit_uv), np.int8), (ur(height // 2), ur(width // 2), 1)))
+
+
+def extend_visible(plane, vw, vh):
+    """the true last column / row of a plane replicated into the padding of the coded size (in place; plane: [..., h, w])"""
+    plane[..., :, vw:] = plane[..., :, vw - 1:vw]
+    plane[..., vh:, :] = plane[..., vh - 1:vh, :]
+    return plane
 
 
 class IntraPipeline:

@@ -214,6 +214,9 @@ int av1mi_lr_frames(av1mi_ctx *ctx, const void *d_cdef, const void *d_deblocked,
  * samples — sum of squared differences, strictly smaller — else 0: the plane the next frame predicts from is then d_cdef's, and
  * the frame header signals lr_type NONE for it.  d_out always receives the restored samples.  d_scratch: device memory of
  * av1mi_lr_decide_scratch_bytes(h, subsampled, nframes) bytes, 8-byte aligned. */
+/* In place: the column visible_w - 1 of every row replicated into columns [visible_w, w), then row visible_h - 1 into rows
+ * [visible_h, h), for nframes stacked frames of one plane (see av1mi_gop_config.visible_width for when an encoder loop needs it). */
+int av1mi_extend_frames(av1mi_ctx *ctx, void *d_plane, int stride, int w, int h, int visible_w, int visible_h, int bd, int nframes);
 size_t av1mi_lr_decide_scratch_bytes(int h, int subsampled, int nframes);
 int av1mi_lr_frames_decide(av1mi_ctx *ctx, const void *d_cdef, const void *d_deblocked, void *d_out, int stride, int w, int h, int bd, int subsampled,
                            int unit_size, const int8_t *d_units, size_t unit_frame_stride, int nframes, const void *d_orig, void *d_scratch, uint8_t *d_on,
@@ -310,6 +313,8 @@ typedef struct av1mi_av1_entropy_job {
   uint32_t *d_tile_size;
   uint64_t *d_total;                           /* 2 entries, 8-byte aligned */
   const uint8_t *d_lr_on;                      /* optional: [frame * 3 + plane] 0 switches lr_on[plane] off for that frame */
+  int visible_width, visible_height;           /* the true frame size when width / height are it rounded up to 8 (the restoration units
+                                                  a tile codes tile the TRUE frame); 0 = width / height */
 } av1mi_av1_entropy_job;
 int av1mi_av1_entropy_encode(av1mi_ctx *ctx, const av1mi_av1_entropy_job *job);
 /* the same on another HIP stream of the caller's (hipStream_t passed as void *; NULL = the context's stream) */
@@ -342,6 +347,14 @@ typedef struct av1mi_gop_config {
   int gpu_entropy;       /* 0: the symbols are downloaded, the host entropy-codes them (north_star's split);
                             1: the AV1 tile entropy coder runs on the GPU (side stream), only tile payloads are downloaded;
                             2: both (tests compare the two) */
+  /* Sources whose size is not a multiple of 8: width / height above are the CODED size (the true size rounded up to 8; the caller
+   * replicates the source's last column / row into the padding of the input planes) and these the TRUE size that goes into the
+   * sequence header (av1mi_obu_frame.visible_*); coded - visible < 8; 0 = the coded size.  The session then does what makes a
+   * decoder — which works at the coded size except where the spec says FrameWidth / FrameHeight — reconstruct the same pictures:
+   * deblocking units that start beyond the true size are not filtered (spec 7.14.2 onScreen), the true last column / row of the
+   * deblocked, CDEF and restored planes is replicated into the padding (what the decoder's clamps at lastX / lastY, 7.11.3.4, and
+   * PlaneEndX / PlaneEndY, 7.17, read), the restoration units of the tile syntax are counted on the true size. */
+  int visible_width, visible_height;
 } av1mi_gop_config;
 
 /* Frame-header parameters chosen by the session's policy for one frame (non-normative encoder choices; the bitstream carries

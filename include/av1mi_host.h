@@ -53,6 +53,11 @@ typedef struct av1mi_obu_frame {
   const int16_t *mv;           /* inter blocks: (x, y) in 1/8 luma samples, multiples of 2 (quarter-sample precision) */
   const int16_t *lev_y;        /* 64 levels per block, row-major (row = vertical frequency) */
   const int16_t *lev_u, *lev_v;/* 16 levels per block */
+  /* The size the decoder outputs, when the source is not a multiple of 8: width / height above are then the CODED size (the
+   * true size rounded up to 8, the source edge replicated into the padding) and these the true one, written to the sequence
+   * header; coded - visible < 8.  0 = same as width / height.  What the encoder loop must do for such a frame so that a decoder
+   * reconstructs the same pictures: av1mi.h, av1mi_gop_config.visible_width. */
+  int32_t visible_width, visible_height;
 } av1mi_obu_frame;
 
 /* One temporal unit: temporal delimiter [+ sequence header] + OBU_FRAME.  threads > 1 codes the tiles on that many host

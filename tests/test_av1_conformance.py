@@ -15,20 +15,29 @@ import dav1d_ref as D
 pytestmark = pytest.mark.skipif(not D.available(), reason="no dav1d in this image (pillow.libs/libavif)")
 
 
-def _filters(O, P, r, bd, q, frame_type, w, h, skip8, src=None):
+def _filters(O, P, r, bd, q, frame_type, w, h, skip8, src=None, visible=None):
     """deblock -> CDEF -> loop restoration of the oracle with the library's policy numbers; with the source planes `src` also the
     encoder's restoration ON / OFF decision per plane (the last stage is then what the next frame predicts from, and the header
-    carries lr_type NONE for the planes switched off); returns (header kwargs, stages)"""
+    carries lr_type NONE for the planes switched off); returns (header kwargs, stages).  visible: the true (width, height) of a
+    frame coded at w x h = that size rounded up to 8 (DESIGN.md "Frame sizes"): off-screen deblocking units are not filtered, and the
+    true last column / row is replicated into the padding of every plane something clamps at the true size in a decoder."""
     import av1stream
-    a = P.policy_arrays(q, bd, frame_type, w, h)
+    a = P.policy_arrays(q, bd, frame_type, w, h, visible=visible)
     dbl = [O.deblock_plane(r["rec_y"], bd, 0, a["mi_y"]), O.deblock_plane(r["rec_u"], bd, 1, a["mi_c"]), O.deblock_plane(r["rec_v"], bd, 1, a["mi_c"])]
-    cdef = O.cdef_frame(dbl[0], dbl[1], dbl[2], bd, a["cdef_damping"], a["cdef_sb"], skip8)
+    cdef = list(O.cdef_frame(dbl[0], dbl[1], dbl[2], bd, a["cdef_damping"], a["cdef_sb"], skip8))
+    vis = None
+    if visible is not None:
+        vis = [(visible[0], visible[1])] + [((visible[0] + 1) // 2, (visible[1] + 1) // 2)] * 2
+        dbl = [P.extend_visible(x.copy(), *v) for x, v in zip(dbl, vis)]       # after CDEF has read the unextended planes
+        cdef = [P.extend_visible(x.copy(), *v) for x, v in zip(cdef, vis)]
     out = [O.lr_plane(cdef[0], dbl[0], bd, 0, a["lr_unit"], a["lr_units_y"]), O.lr_plane(cdef[1], dbl[1], bd, 1, a["lr_unit"], a["lr_units_c"]),
            O.lr_plane(cdef[2], dbl[2], bd, 1, a["lr_unit"], a["lr_units_c"])]
     on = None
     if src is not None:
         out, on = O.lr_select(src, cdef, out, bd)
-    hdr = av1stream.header_from_params(a["params"], w, h, on)
+    if vis is not None:
+        out = [P.extend_visible(np.array(x), *v) for x, v in zip(out, vis)]
+    hdr = av1stream.header_from_params(a["params"], w, h, on, visible)
     hdr.pop("frame_type")
     return hdr, [dbl, list(cdef), out]
 
@@ -266,3 +275,58 @@ def test_random_filter_parameters(O, w, h, bd, q, seed):
         for i in range(3):
             assert (got[i] == ref[i]).all(), "%s plane %d (levels %s sharpness %d, cdef sets %d damping %d, lr %s units %s)" % (
                 name, i, lv, sharp, nset, damping, lrt, usz)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Frame sizes that are not multiples of 8: coded at the size rounded up (source edge replicated), announced at the true size.
+def _pad(a, h, w):
+    return np.pad(a, ((0, h - a.shape[0]), (0, w - a.shape[1])), mode="edge")
+
+
+def _crop(planes, vw, vh):
+    return [planes[0][:vh, :vw], planes[1][:(vh + 1) // 2, :(vw + 1) // 2], planes[2][:(vh + 1) // 2, :(vw + 1) // 2]]
+
+
+def visible_gop(O, P, vw, vh, bd, q, nframes, first=3):
+    """the oracle's closed-GOP chain of a vw x vh source; returns (stream, per frame [stages of the key frame | reference planes])"""
+    import av1stream
+    import synth
+    w, h = (vw + 7) // 8 * 8, (vh + 7) // 8 * 8
+    Yc, Uc, Vc = synth.frames(w + 8, h + 8, nframes, bd, first)       # any content: cut the true size out of a larger frame
+    stream, refs, ref, key_stages = b"", [], None, None
+    for t in range(nframes):
+        src = (_pad(Yc[t][:vh, :vw], h, w), _pad(Uc[t][:(vh + 1) // 2, :(vw + 1) // 2], h // 2, w // 2), _pad(Vc[t][:(vh + 1) // 2, :(vw + 1) // 2], h // 2, w // 2))
+        if t == 0:
+            r = O.intra_encode_frame(src[0], src[1], src[2], bd, 8, q)
+            hdr, st = _filters(O, P, r, bd, q, 0, w, h, np.zeros((h // 8, w // 8), np.uint8), src, (vw, vh))
+            key_stages = [[r["rec_y"], r["rec_u"], r["rec_v"]]] + st
+            stream += av1stream.temporal_unit(w, h, bd, q, y_mode=r["modes_y"], uv_mode=r["modes_uv"], lev_y=r["lev_y"], lev_u=r["lev_u"],
+                                              lev_v=r["lev_v"], **hdr)
+        else:
+            r = O.inter_encode_frame(src, ref, bd, q, 8)
+            hdr, st = _filters(O, P, r, bd, q, 1, w, h, r["skip"].reshape(h // 8, w // 8), src, (vw, vh))
+            stream += av1stream.temporal_unit(w, h, bd, q, frame_type=1, with_sequence_header=False, mv=r["mvs"], skip=r["skip"],
+                                              lev_y=r["lev_y"], lev_u=r["lev_u"], lev_v=r["lev_v"], **hdr)
+        ref = st[2]
+        refs.append(ref)
+    return stream, refs, key_stages
+
+
+@pytest.mark.parametrize("vw,vh,bd,q,n", [(100, 76, 8, 220, 3), (61, 45, 8, 100, 3), (130, 70, 10, 60, 3), (199, 133, 8, 180, 2), (66, 129, 10, 140, 3), (132, 68, 10, 230, 3)])
+def test_sizes_that_are_not_multiples_of_8(O, vw, vh, bd, q, n):
+    """dav1d outputs the TRUE size; every stage of the key frame and every reference frame of the GOP equals the oracle's planes
+    cropped to it — in particular the P frames, whose vectors point into the replicated border"""
+    import pipeline as P
+    stream, refs, ks = visible_gop(O, P, vw, vh, bd, q, n)
+    got = D.decode(stream)
+    assert len(got) == n
+    for t in range(n):
+        want = _crop(refs[t], vw, vh)
+        for i in range(3):
+            assert got[t][i].shape == want[i].shape, (got[t][i].shape, want[i].shape)
+            assert (got[t][i] == want[i]).all(), "frame %d plane %d differs from dav1d" % (t, i)
+    for name, flt, ref in (("reconstruction", 0, ks[0]), ("deblocked", D.INLOOP_DEBLOCK, ks[1]), ("cdef", D.INLOOP_DEBLOCK | D.INLOOP_CDEF, ks[2])):
+        g0 = D.decode(stream, inloop_filters=flt)[0]
+        want = _crop(ref, vw, vh)
+        for i in range(3):
+            assert (g0[i] == want[i]).all(), "key frame %s plane %d differs from dav1d" % (name, i)

@@ -303,3 +303,58 @@ def test_random_small_configurations_decode_to_the_gpu_frames(ctx, av1mi):
             for t in range(nfr):
                 for i, hh in ((0, h), (1, h // 2), (2, h // 2)):
                     assert (got[t][i] == refs[t][i][sgi * hh:(sgi + 1) * hh]).all(), (case, w, h, bd, q, gop, segs, t, sgi, i)
+
+
+@pytest.mark.skipif(not D.available(), reason="no dav1d in this image")
+@pytest.mark.parametrize("vw,vh,bd,q,gop,segs", [(100, 76, 8, 220, 3, 2), (61, 45, 8, 100, 3, 1), (130, 70, 10, 60, 3, 2), (132, 68, 10, 230, 2, 3),
+                                                  (854, 480, 8, 128, 3, 2), (1366, 768, 10, 110, 2, 1)])
+def test_sizes_that_are_not_multiples_of_8(ctx, av1mi, O, vw, vh, bd, q, gop, segs):
+    """A vw x vh source coded at the size rounded up to 8 (include/av1mi.h av1mi_gop_config.visible_width): the stream announces
+    the true size, the host writer and the GPU tile coder give the same bytes, dav1d outputs vw x vh frames that equal the
+    session's reference frames cropped — P frames predicted across the replicated border included — and, for the small cases,
+    the oracle's chain (tests/test_av1_conformance.py visible_gop, itself pinned to dav1d on the CPU)."""
+    import av1stream
+    import pipeline as P
+    import synth
+    import test_av1_conformance as T
+    w, h = (vw + 7) // 8 * 8, (vh + 7) // 8 * 8
+    cvw, cvh = (vw + 1) // 2, (vh + 1) // 2
+    s = av1mi.GopSession(ctx, w, h, bd, q, gop, segs, gpu_entropy=2, visible=(vw, vh))
+    try:
+        streams, refs = [b""] * segs, []
+        for t in range(gop):
+            planes = s.input_planes()
+            for sgi in range(segs):
+                Yc, Uc, Vc = synth.frames(w + 8, h + 8, gop, bd, 3 + 5 * sgi)
+                planes[0][sgi * h:(sgi + 1) * h] = T._pad(Yc[t][:vh, :vw], h, w)
+                planes[1][sgi * h // 2:(sgi + 1) * h // 2] = T._pad(Uc[t][:cvh, :cvw], h // 2, w // 2)
+                planes[2][sgi * h // 2:(sgi + 1) * h // 2] = T._pad(Vc[t][:cvh, :cvw], h // 2, w // 2)
+            s.submit()
+            fr = s.collect()
+            refs.append(s.download_reference())
+            for sgi in range(segs):
+                host = av1stream.session_frame_unit(w, h, bd, fr, sgi, threads=8, visible=(vw, vh))
+                gpu = av1stream.session_frame_unit_gpu(w, h, bd, fr, sgi, visible=(vw, vh))
+                assert gpu == host, "frame %d segment %d: GPU-coded temporal unit differs from the host writer's" % (t, sgi)
+                streams[sgi] += gpu
+        for sgi in range(segs):
+            got = D.decode(streams[sgi])
+            assert len(got) == gop
+            for t in range(gop):
+                for i, (hh, ch, cw) in enumerate(((h, vh, vw), (h // 2, cvh, cvw), (h // 2, cvh, cvw))):
+                    assert got[t][i].shape == (ch, cw)
+                    assert (got[t][i] == refs[t][i][sgi * hh:sgi * hh + ch, :cw]).all(), "segment %d frame %d plane %d: dav1d differs from the GPU" % (sgi, t, i)
+        if w * h <= 200 * 200:       # the oracle's chain of segment 0 (first frame 3): same stream, same reference frames
+            stream, orefs, _ = T.visible_gop(O, P, vw, vh, bd, q, gop)
+            assert stream == streams[0]
+            for t in range(gop):
+                for i, hh in ((0, h), (1, h // 2), (2, h // 2)):
+                    assert (orefs[t][i] == refs[t][i][:hh]).all(), "frame %d plane %d: the GPU's reference differs from the oracle's (padding included)" % (t, i)
+    finally:
+        s.close()
+
+
+def test_visible_size_must_be_within_the_last_block(ctx, av1mi):
+    for vis in ((90, 80), (104, 72), (105, 80), (104, 81)):
+        with pytest.raises(av1mi.Av1miError):
+            av1mi.GopSession(ctx, 104, 80, 8, 100, 2, 1, visible=vis)

@@ -207,6 +207,47 @@ def test_run_transcode_and_process_job_on_gpu(host, tmp_path, O):
     assert status.value == b"success" and src3.read_bytes()[:4] == b"\x1a\x45\xdf\xa3"
 
 
+@pytest.mark.gpu
+def test_run_transcode_of_a_source_whose_size_is_not_a_multiple_of_8(host, tmp_path, O):
+    """854x480-style sources: the backend pads to the coded size while reading, the file announces the true size, dav1d outputs it,
+    and the frames equal the oracle's chain of the same source (tests/test_av1_conformance.py visible_gop) — host coder and GPU coder"""
+    import dav1d_ref as D
+    if not D.available():
+        pytest.skip("no dav1d in this image")
+    sys_path_synth()
+    import pipeline as P
+    import synth
+    import test_av1_conformance as T
+    for vw, vh, bd, q, n in ((109, 75, 8, 140, 3), (70, 61, 10, 90, 3)):
+        w, h = (vw + 7) // 8 * 8, (vh + 7) // 8 * 8
+        Yc, Uc, Vc = synth.frames(w + 8, h + 8, n, bd, 3)
+        src = tmp_path / ("odd%d.y4m" % bd)
+        with open(str(src), "wb") as f:
+            f.write(("YUV4MPEG2 W%d H%d F30:1 Ip A1:1 C%s\n" % (vw, vh, "420jpeg" if bd == 8 else "420p10")).encode())
+            for i in range(n):
+                f.write(b"FRAME\n")
+                for pl in (Yc[i][:vh, :vw], Uc[i][:(vh + 1) // 2, :(vw + 1) // 2], Vc[i][:(vh + 1) // 2, :(vw + 1) // 2]):
+                    f.write(np.ascontiguousarray(pl).astype("<u2" if bd == 10 else np.uint8).tobytes())
+        stream, refs, _ = T.visible_gop(O, P, vw, vh, bd, q, n)
+        buf = C.create_string_buffer(1024)
+        for gpu_entropy in ("0", "1"):
+            out = tmp_path / ("odd%d_%s.obu" % (bd, gpu_entropy))
+            args = "\n".join(["-i", str(src), "-global_quality:v:0", str(q), "-g", str(n), "-av1mi_gpu_entropy", gpu_entropy, str(out)])
+            assert host.av1mi_host_run_transcode(args.encode(), buf, 1024) == 0 and buf.value == b"", buf.value
+            obu = out.read_bytes()
+            assert obu == stream, "the file differs from the oracle chain's stream"
+            got = D.decode(obu)
+            assert len(got) == n and got[0][0].shape == (vh, vw) and got[0][1].shape == ((vh + 1) // 2, (vw + 1) // 2)
+            for t in range(n):
+                for i, a in enumerate(T._crop(refs[t], vw, vh)):
+                    assert (got[t][i] == a).all()
+        mkv = tmp_path / ("odd%d.mkv" % bd)
+        args = "\n".join(["-i", str(src), "-global_quality:v:0", str(q), "-g", str(n), str(mkv)])
+        assert host.av1mi_host_run_transcode(args.encode(), buf, 1024) == 0
+        data = mkv.read_bytes()
+        assert b"\xb0" + bytes([0x81, vw]) in data and b"\xba" + bytes([0x81, vh]) in data      # PixelWidth / PixelHeight = the true size
+
+
 def sys_path_synth():
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(HOST), ".."))
