@@ -517,26 +517,59 @@ __global__ __launch_bounds__(256) void k_inter_pipe(InterLaunch L) {
   // block lies in is decided as well this way as with the 8-tap filter (coded bytes and PSNR unchanged); the
   // quarter-sample round below scores every position, its centre included, with the real filter.
   {
-    int R[3][10];                                  // window rows lane + 3 .. lane + 5, columns 3 .. 12 = block rows -1 .. +1, columns -1 .. +8
-    constexpr int PER = 4 / (int)sizeof(ES);
+    // packed 16-bit arithmetic (v_pk_add_u16 / v_pk_lshrrev_b16: two samples per lane-op; sums of four 10-bit samples fit):
+    // P[j][k][i] = the sample pair at columns 3 + k + 2 i, 4 + k + 2 i of window row lane + 3 + j (block row -1 .. +1, columns
+    // -1 + k ..), straight from the window's dwords — the sample-by-sample form unpacked 30 samples, averaged in 32 bits and packed
+    // every candidate again for the SAD
+    typedef unsigned short v2u __attribute__((ext_vector_type(2)));
+    v2u P[3][3][4];
 #pragma unroll
-    for (int j = 0; j < 3; j++) row_samples<10, ES>(wy + (lane + 3 + j) * YWS + (3 & ~(PER - 1)), 3 & (PER - 1), R[j]);
+    for (int j = 0; j < 3; j++) {
+      const uint32_t *r32 = reinterpret_cast<const uint32_t *>(wy + (lane + 3 + j) * YWS);
+      uint32_t w[3][4];
+      if constexpr (sizeof(ES) == 2) {
+        uint32_t D[6];                               // columns 2 .. 13
+#pragma unroll
+        for (int i = 0; i < 6; i++) D[i] = r32[1 + i];
+#pragma unroll
+        for (int i = 0; i < 4; i++) { w[0][i] = __builtin_amdgcn_alignbit(D[i + 1], D[i], 16); w[1][i] = D[i + 1]; w[2][i] = __builtin_amdgcn_alignbit(D[i + 2], D[i + 1], 16); }
+      } else {
+        const uint32_t B0 = r32[0], B1 = r32[1], B2 = r32[2], B3 = r32[3];     // columns 0 .. 15, one byte each
+        w[0][0] = __builtin_amdgcn_perm(B1, B0, 0x0c040c03u); w[0][1] = __builtin_amdgcn_perm(0u, B1, 0x0c020c01u);
+        w[0][2] = __builtin_amdgcn_perm(B2, B1, 0x0c040c03u); w[0][3] = __builtin_amdgcn_perm(0u, B2, 0x0c020c01u);
+        w[1][0] = __builtin_amdgcn_perm(0u, B1, 0x0c010c00u); w[1][1] = __builtin_amdgcn_perm(0u, B1, 0x0c030c02u);
+        w[1][2] = __builtin_amdgcn_perm(0u, B2, 0x0c010c00u); w[1][3] = __builtin_amdgcn_perm(0u, B2, 0x0c030c02u);
+        w[2][0] = w[0][1]; w[2][1] = w[0][2]; w[2][2] = w[0][3]; w[2][3] = __builtin_amdgcn_perm(B3, B2, 0x0c040c03u);
+      }
+#pragma unroll
+      for (int k = 0; k < 3; k++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) P[j][k][i] = __builtin_bit_cast(v2u, w[k][i]);
+    }
+    v2u H[3][2][4];                                // horizontal pair sums: columns (k, k + 1) of row j
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+#pragma unroll
+      for (int k = 0; k < 2; k++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) H[j][k][i] = P[j][k][i] + P[j][k + 1][i];
+    const v2u one = { 1, 1 }, two = { 2, 2 };
     unsigned bestkey = (unsigned)best << 4;        // (SAD, rank): rank 0 = the centre (keeps ties), k + 1 = the neighbour visited k-th
 #pragma unroll
     for (int iy = 0; iy < 3; iy++) {
 #pragma unroll
       for (int ix = 0; ix < 3; ix++) {
         if (ix == 1 && iy == 1) continue;
-        const int r0 = iy == 0 ? 0 : 1, r1 = iy == 2 ? 2 : 1, c0 = ix == 0 ? 0 : 1, c1 = ix == 2 ? 2 : 1;   // the 1, 2 or 4 samples averaged
-        int o[8];
-#pragma unroll
-        for (int c = 0; c < 8; c++) {
-          if (r0 == r1) o[c] = (R[r0][c + c0] + R[r0][c + c1] + 1) >> 1;
-          else if (c0 == c1) o[c] = (R[r0][c + c0] + R[r1][c + c0] + 1) >> 1;
-          else o[c] = (R[r0][c + c0] + R[r0][c + c1] + R[r1][c + c0] + R[r1][c + c1] + 2) >> 2;
-        }
+        const int r0 = iy == 0 ? 0 : 1, r1 = iy == 2 ? 2 : 1, k = ix == 0 ? 0 : 1;   // the 1, 2 or 4 samples averaged
         uint32_t ow[4];
-        pack4(o, ow);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          v2u o;
+          if (iy == 1) o = (H[1][k][i] + one) >> one;
+          else if (ix == 1) o = (P[r0][1][i] + P[r1][1][i] + one) >> one;
+          else o = (H[r0][k][i] + H[r1][k][i] + two) >> two;
+          ow[i] = __builtin_bit_cast(uint32_t, o);
+        }
         bestkey = min(bestkey, ((unsigned)sad_of(ow) << 4) | (unsigned)(iy * 3 + ix + 1));
       }
     }
