@@ -80,6 +80,17 @@ class EntropyJob(C.Structure):
                 ("d_out", C.c_void_p), ("out_cap", C.c_size_t), ("d_frame_off", C.c_void_p)]
 
 
+class LrDecideJob(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("bit_depth", C.c_int), ("nframes", C.c_int), ("unit_size", C.c_int),
+                ("stride_y", C.c_int), ("stride_uv", C.c_int),
+                ("d_cdef_y", C.c_void_p), ("d_cdef_u", C.c_void_p), ("d_cdef_v", C.c_void_p),
+                ("d_dbl_y", C.c_void_p), ("d_dbl_u", C.c_void_p), ("d_dbl_v", C.c_void_p),
+                ("d_out_y", C.c_void_p), ("d_out_u", C.c_void_p), ("d_out_v", C.c_void_p),
+                ("d_orig_y", C.c_void_p), ("d_orig_u", C.c_void_p), ("d_orig_v", C.c_void_p),
+                ("d_units_y", C.c_void_p), ("d_units_uv", C.c_void_p), ("unit_frame_stride_y", C.c_size_t), ("unit_frame_stride_uv", C.c_size_t),
+                ("d_scratch", C.c_void_p), ("d_on", C.c_void_p)]
+
+
 class GopConfig(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("bit_depth", C.c_int), ("base_q_idx", C.c_int), ("gop_length", C.c_int),
                 ("segments", C.c_int), ("search_range", C.c_int), ("gpu_entropy", C.c_int), ("visible_width", C.c_int),
@@ -402,6 +413,14 @@ class Context:
         self._chk(self.lib.av1mi_lr_frames_decide(self.h, C.c_void_p(d_cdef.ptr), C.c_void_p(d_dbl.ptr), C.c_void_p(d_out.ptr), stride, w, h, bd,
                                                   int(ss), unit_size, C.c_void_p(d_units.ptr), C.c_size_t(unit_frame_stride), nframes,
                                                   C.c_void_p(d_orig.ptr), C.c_void_p(d_scratch.ptr), C.c_void_p(d_on.ptr + on_offset), int(on_stride)))
+
+    def lr_yuv_decide_scratch_bytes(self, h, nframes):
+        self.lib.av1mi_lr_yuv_decide_scratch_bytes.restype = C.c_size_t
+        return int(self.lib.av1mi_lr_yuv_decide_scratch_bytes(int(h), int(nframes)))
+
+    def lr_yuv_decide(self, job):
+        """the three planes' restoration + ON / OFF decisions in one call (include/av1mi.h av1mi_lr_yuv_decide)"""
+        self._chk(self.lib.av1mi_lr_yuv_decide(self.h, C.byref(job)))
 
     # ---- fused intra-only segment pipeline
     def extend_frames(self, d_plane, stride, w, h, visible_w, visible_h, bd, nframes):

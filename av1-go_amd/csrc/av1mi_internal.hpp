@@ -101,6 +101,8 @@ struct LrLaunch {
 };
 hipError_t launch_lr(const LrLaunch &L, hipStream_t s);
 int lr_stripes(int h, int ss);
+hipError_t launch_zero16(void *p, size_t bytes, hipStream_t s);
+hipError_t launch_lr_decide3(const unsigned long long *sse, int nframes, int stripes_y, int stripes_c, uint8_t *on, hipStream_t s);
 hipError_t launch_extend(void *plane, int stride, int w, int h, int vw, int vh, int bd, int nframes, hipStream_t s);
 hipError_t launch_lr_decide(const unsigned long long *sse, int nframes, int stripes, uint8_t *on, int on_stride, hipStream_t s);
 

@@ -460,6 +460,39 @@ int av1mi_lr_frames_decide(av1mi_ctx *ctx, const void *d_cdef, const void *d_deb
   return AV1MI_OK;
 }
 
+size_t av1mi_lr_yuv_decide_scratch_bytes(int h, int nframes) {
+  return av1mi_lr_decide_scratch_bytes(h, 0, nframes) + 2 * av1mi_lr_decide_scratch_bytes(h / 2, 1, nframes);
+}
+int av1mi_lr_yuv_decide(av1mi_ctx *ctx, const av1mi_lr_decide_job *j) {
+  BIND(ctx);
+  if (!j) return fail(ctx, AV1MI_E_INVAL, "null job");
+  const void *ptrs[] = { j->d_cdef_y, j->d_cdef_u, j->d_cdef_v, j->d_dbl_y, j->d_dbl_u, j->d_dbl_v, j->d_out_y, j->d_out_u, j->d_out_v,
+                         j->d_orig_y, j->d_orig_u, j->d_orig_v, j->d_units_y, j->d_units_uv, j->d_scratch, j->d_on };
+  for (const void *p : ptrs) if (!p) return fail(ctx, AV1MI_E_INVAL, "null device pointer");
+  if ((uintptr_t)j->d_scratch & 15) return fail(ctx, AV1MI_E_INVAL, "misaligned scratch");
+  if (j->bit_depth != 8 && j->bit_depth != 10) return fail(ctx, AV1MI_E_INVAL, "bit depth %d not supported (8 or 10)", j->bit_depth);
+  if (j->width <= 0 || j->height <= 0 || (j->width & 1) || (j->height & 1) || j->stride_y < j->width || j->stride_uv < j->width / 2)
+    return fail(ctx, AV1MI_E_INVAL, "bad frame geometry %dx%d strides %d/%d", j->width, j->height, j->stride_y, j->stride_uv);
+  if (!(j->unit_size == 64 || j->unit_size == 128 || j->unit_size == 256)) return fail(ctx, AV1MI_E_INVAL, "restoration unit size %d not allowed", j->unit_size);
+  if (j->nframes < 0 || j->nframes > 65535) return fail(ctx, AV1MI_E_INVAL, "nframes %d out of range", j->nframes);
+  if (j->nframes == 0) return AV1MI_OK;
+  const int n = j->nframes, sy = av1mi::lr_stripes(j->height, 0), sc = av1mi::lr_stripes(j->height / 2, 1);
+  unsigned long long *sse = (unsigned long long *)j->d_scratch;
+  HIP_TRY(ctx, av1mi::launch_zero16(sse, av1mi_lr_yuv_decide_scratch_bytes(j->height, n), ctx->stream));
+  const void *cdef[3] = { j->d_cdef_y, j->d_cdef_u, j->d_cdef_v }, *dbl[3] = { j->d_dbl_y, j->d_dbl_u, j->d_dbl_v }, *orig[3] = { j->d_orig_y, j->d_orig_u, j->d_orig_v };
+  void *out[3] = { j->d_out_y, j->d_out_u, j->d_out_v };
+  for (int p = 0; p < 3; p++) {
+    if (out[p] == cdef[p] || out[p] == dbl[p]) return fail(ctx, AV1MI_E_INVAL, "aliased device pointer");
+    av1mi::LrLaunch L = { cdef[p], dbl[p], out[p], p ? j->stride_uv : j->stride_y, p ? j->width / 2 : j->width, p ? j->height / 2 : j->height, j->bit_depth, p ? 1 : 0,
+                          j->unit_size, n, p ? j->d_units_uv : j->d_units_y, p ? j->unit_frame_stride_uv : j->unit_frame_stride_y, orig[p],
+                          sse + 2 * ((size_t)(p ? n * sy + (p - 1) * n * sc : 0)), p ? sc : sy };
+    ProfScope ps(ctx, AV1MI_K_LR);
+    HIP_TRY(ctx, av1mi::launch_lr(L, ctx->stream));
+  }
+  HIP_TRY(ctx, av1mi::launch_lr_decide3(sse, n, sy, sc, j->d_on, ctx->stream));
+  return AV1MI_OK;
+}
+
 int av1mi_extend_frames(av1mi_ctx *ctx, void *d_plane, int stride, int w, int h, int visible_w, int visible_h, int bd, int nframes) {
   BIND(ctx);
   if (!d_plane) return fail(ctx, AV1MI_E_INVAL, "null device pointer");
@@ -577,11 +610,10 @@ int av1mi_entropy_encode(av1mi_ctx *ctx, const av1mi_entropy_job *j) {
 int av1mi_entropy_encode_async(av1mi_ctx *ctx, const av1mi_entropy_job *j, int slot) {
   BIND(ctx);
   if (slot < 0 || slot >= 8) return fail(ctx, AV1MI_E_INVAL, "slot %d out of range (0..7)", slot);
-  if (!ctx->side) {
-    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
-    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->fork, hipEventDisableTiming));
-    for (hipEvent_t &ev : ctx->slot_done) HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-  }
+  // (the side stream may exist already — a GOP session of this context creates it for the AV1 coder — without these events)
+  if (!ctx->side) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+  if (!ctx->fork) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->fork, hipEventDisableTiming));
+  for (hipEvent_t &ev : ctx->slot_done) if (!ev) HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
   HIP_TRY(ctx, hipEventRecord(ctx->fork, ctx->stream));            // everything queued so far produced the job's inputs
   HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->fork, 0));
   if (int rc = entropy_run(ctx, j, ctx->side)) return rc;
@@ -591,7 +623,7 @@ int av1mi_entropy_encode_async(av1mi_ctx *ctx, const av1mi_entropy_job *j, int s
 int av1mi_entropy_wait(av1mi_ctx *ctx, int slot) {
   BIND(ctx);
   if (slot < 0 || slot >= 8) return fail(ctx, AV1MI_E_INVAL, "slot %d out of range (0..7)", slot);
-  if (ctx->side) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->slot_done[slot], 0));   // never recorded = no wait
+  if (ctx->slot_done[slot]) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->slot_done[slot], 0));   // never created or never recorded = no wait
   return AV1MI_OK;
 }
 

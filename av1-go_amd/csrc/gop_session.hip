@@ -89,7 +89,7 @@ struct av1mi_gop {
   void *d_rec[3] = {}, *d_dbl[3] = {}, *d_cdef[3] = {}, *d_ref[3] = {};
   void *d_mi[2][2] = {};                       // [key / inter][luma / chroma] deblocking mode-info maps (one frame, shared by the batch)
   void *d_cdef_sb[2] = {}, *d_lr[2] = {}, *d_zero_skip = nullptr;
-  void *d_lr_scratch[3] = {};                  // the restoration decision's partial sums, per plane
+  void *d_lr_scratch = nullptr;                // the restoration decision's partial sums (three planes)
   int vw = 0, vh = 0;                          // the true frame size (== the coded size unless cfg.visible_* say otherwise)
   int last = 0;                                // slot of the most recent batch (its d_lr_on selects the next batch's references)
   av1mi_frame_params params[2];                // key, inter
@@ -170,7 +170,7 @@ int setup(av1mi_gop *g) {
     const size_t n = (p ? g->nc : g->ny) * g->bps;
     G_TRY(dev_alloc(g, &g->d_rec[p], n)); G_TRY(dev_alloc(g, &g->d_dbl[p], n)); G_TRY(dev_alloc(g, &g->d_cdef[p], n)); G_TRY(dev_alloc(g, &g->d_ref[p], n));
   }
-  for (int p = 0; p < 3; p++) G_TRY(dev_alloc(g, &g->d_lr_scratch[p], av1mi_lr_decide_scratch_bytes(p ? h / 2 : h, p > 0, S)));
+  G_TRY(dev_alloc(g, &g->d_lr_scratch, av1mi_lr_yuv_decide_scratch_bytes(h, S)));
   G_TRY(dev_alloc(g, &g->d_zero_skip, g->nb));
   G_TRY(av1mi_memset(g->ctx, g->d_zero_skip, 0, g->nb));
   // constant side information: one map per frame type, shared by every frame of a batch (frame stride 0)
@@ -375,10 +375,17 @@ int av1mi_gop_submit(av1mi_gop *g, int frame_type) {
     }
   // loop restoration of every frame, and the decision per segment and plane whether it stays ON (it must lower the squared error
   // against the source): d_ref always receives the restored planes, the next batch's kernels choose between d_ref and d_cdef
-  for (int p = 0; p < 3; p++) {
-    const int pw = p ? w / 2 : w, ph = p ? h / 2 : h;
-    G_TRY(av1mi_lr_frames_decide(g->ctx, g->d_cdef[p], g->d_dbl[p], g->d_ref[p], pw, pw, ph, bd, p > 0, P.lr_unit_size, (const int8_t *)g->d_lr[p > 0], 0, S,
-                                 s.d_src[p], g->d_lr_scratch[p], (uint8_t *)s.d_lr_on + p, 3));
+  {
+    av1mi_lr_decide_job lj;
+    memset(&lj, 0, sizeof(lj));
+    lj.width = w; lj.height = h; lj.bit_depth = bd; lj.nframes = S; lj.unit_size = P.lr_unit_size; lj.stride_y = w; lj.stride_uv = w / 2;
+    lj.d_cdef_y = g->d_cdef[0]; lj.d_cdef_u = g->d_cdef[1]; lj.d_cdef_v = g->d_cdef[2];
+    lj.d_dbl_y = g->d_dbl[0]; lj.d_dbl_u = g->d_dbl[1]; lj.d_dbl_v = g->d_dbl[2];
+    lj.d_out_y = g->d_ref[0]; lj.d_out_u = g->d_ref[1]; lj.d_out_v = g->d_ref[2];
+    lj.d_orig_y = s.d_src[0]; lj.d_orig_u = s.d_src[1]; lj.d_orig_v = s.d_src[2];
+    lj.d_units_y = (const int8_t *)g->d_lr[0]; lj.d_units_uv = (const int8_t *)g->d_lr[1];
+    lj.d_scratch = g->d_lr_scratch; lj.d_on = (uint8_t *)s.d_lr_on;
+    G_TRY(av1mi_lr_yuv_decide(g->ctx, &lj));
   }
   if (padded)      // ... and so do its motion-compensation reads of this frame
     for (int p = 0; p < 3; p++)

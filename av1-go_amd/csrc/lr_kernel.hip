@@ -377,6 +377,31 @@ hipError_t launch_extend(void *plane, int stride, int w, int h, int vw, int vh, 
   return hipGetLastError();
 }
 
+// the three planes of 4:2:0 frames at once: thread = (frame, plane); plane p's sums start at sse + off[p] pairs
+__global__ __launch_bounds__(64) void k_lr_decide3(const unsigned long long *sse, int nframes, int stripes_y, int stripes_c, uint8_t *on) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= nframes * 3) return;
+  const int f = i / 3, p = i - 3 * f;
+  const int stripes = p ? stripes_c : stripes_y;
+  const unsigned long long *q = sse + 2 * ((size_t)(p ? nframes * stripes_y + (p - 1) * nframes * stripes_c : 0) + (size_t)f * stripes);
+  unsigned long long a = 0, b = 0;
+  for (int s = 0; s < stripes; s++) { a += q[2 * s]; b += q[2 * s + 1]; }
+  on[i] = a < b;
+}
+__global__ __launch_bounds__(256) void k_zero16(uint4 *p, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = make_uint4(0, 0, 0, 0);
+}
+hipError_t launch_zero16(void *p, size_t bytes, hipStream_t s) {      // bytes: a multiple of 16
+  const size_t n = bytes / 16;
+  if (n) hipLaunchKernelGGL(k_zero16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (uint4 *)p, n);
+  return hipGetLastError();
+}
+hipError_t launch_lr_decide3(const unsigned long long *sse, int nframes, int stripes_y, int stripes_c, uint8_t *on, hipStream_t s) {
+  hipLaunchKernelGGL(k_lr_decide3, dim3((unsigned)((nframes * 3 + 63) / 64)), dim3(64), 0, s, sse, nframes, stripes_y, stripes_c, on);
+  return hipGetLastError();
+}
+
 int lr_stripes(int h, int ss) { return (h + (8 >> ss) + (64 >> ss) - 1) / (64 >> ss); }
 hipError_t launch_lr_decide(const unsigned long long *sse, int nframes, int stripes, uint8_t *on, int on_stride, hipStream_t s) {
   hipLaunchKernelGGL(k_lr_decide, dim3((unsigned)((nframes + 63) / 64)), dim3(64), 0, s, sse, nframes, stripes, on, on_stride);

@@ -222,7 +222,7 @@ class GopPipeline:
         # restoration ON / OFF per (segment, plane) of every frame index, decided on the GPU against the source (the session's policy:
         # av1mi_lr_frames_decide); frame t + 1 predicts from d_ref where ON and from the CDEF output where OFF
         self.d_lr_on = [ctx.to_device(np.ones(segments * 3 + 4, np.uint8)) for _ in range(gop)]      # (+ 4: read as aligned dwords)
-        self.d_lr_scratch = [ctx.alloc(ctx.lr_decide_scratch_bytes(height >> (p > 0), p > 0, segments)) for p in range(3)]
+        self.d_lr_scratch = ctx.alloc(ctx.lr_yuv_decide_scratch_bytes(height, segments))
         self.zero_skip = ctx.to_device(np.zeros(segments * nb, np.uint8))
         self.samples = sum(a.size for a in self.src[0]) * gop
         self.bps = k.bps
@@ -245,10 +245,10 @@ class GopPipeline:
         job = av1mi.CdefJob(w, h, self.bd, f, k.pol[0 if key else 1]["cdef_damping"], w, w // 2, d["dbl_y"].ptr, d["dbl_u"].ptr, d["dbl_v"].ptr,
                             d["cdef_y"].ptr, d["cdef_u"].ptr, d["cdef_v"].ptr, d["cdef_sb" if key else "cdef_sb_p"].ptr, 0, skip_buf.ptr, skip_stride)
         c.cdef_frames(job)
-        s, on, scr = self.d_src[t], self.d_lr_on[t], self.d_lr_scratch
-        c.lr_frames_decide(d["cdef_y"], d["dbl_y"], self.d_ref[0], w, w, h, self.bd, 0, k.lr_unit, d["lr_y"], 0, f, s[0], scr[0], on, 0, 3)
-        c.lr_frames_decide(d["cdef_u"], d["dbl_u"], self.d_ref[1], w // 2, w // 2, h // 2, self.bd, 1, k.lr_unit, d["lr_c"], 0, f, s[1], scr[1], on, 1, 3)
-        c.lr_frames_decide(d["cdef_v"], d["dbl_v"], self.d_ref[2], w // 2, w // 2, h // 2, self.bd, 1, k.lr_unit, d["lr_c"], 0, f, s[2], scr[2], on, 2, 3)
+        s, on = self.d_src[t], self.d_lr_on[t]
+        c.lr_yuv_decide(av1mi.LrDecideJob(w, h, self.bd, f, k.lr_unit, w, w // 2, d["cdef_y"].ptr, d["cdef_u"].ptr, d["cdef_v"].ptr,
+                                          d["dbl_y"].ptr, d["dbl_u"].ptr, d["dbl_v"].ptr, self.d_ref[0].ptr, self.d_ref[1].ptr, self.d_ref[2].ptr,
+                                          s[0].ptr, s[1].ptr, s[2].ptr, d["lr_y"].ptr, d["lr_c"].ptr, 0, 0, self.d_lr_scratch.ptr, on.ptr))
 
     def lr_on(self, t):
         """[segments, 3] restoration ON / OFF flags of the t-th frames after the last step"""
@@ -315,6 +315,6 @@ class GopPipeline:
         for t in self.d_src:
             for b in t:
                 b.free()
-        for b in [self.d_mvs, self.d_skip, self.zero_skip] + self.d_ref + self.d_lr_on + self.d_lr_scratch + self.ent_out + self.ent_off + (list(self.sym[1].values()) if len(self.sym) > 1 else []):
+        for b in [self.d_mvs, self.d_skip, self.zero_skip] + self.d_ref + self.d_lr_on + [self.d_lr_scratch] + self.ent_out + self.ent_off + (list(self.sym[1].values()) if len(self.sym) > 1 else []):
             b.free()
         self.key.close()

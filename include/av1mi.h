@@ -214,6 +214,22 @@ int av1mi_lr_frames(av1mi_ctx *ctx, const void *d_cdef, const void *d_deblocked,
  * samples — sum of squared differences, strictly smaller — else 0: the plane the next frame predicts from is then d_cdef's, and
  * the frame header signals lr_type NONE for it.  d_out always receives the restored samples.  d_scratch: device memory of
  * av1mi_lr_decide_scratch_bytes(h, subsampled, nframes) bytes, 8-byte aligned. */
+/* The same for the three planes of 4:2:0 frames in one call (what the GOP session uses): one zeroing launch, the three
+ * restorations, ONE decision launch — five launches instead of nine.  d_on[f * 3 + plane].  d_scratch: 16-byte aligned,
+ * av1mi_lr_yuv_decide_scratch_bytes(height, nframes) bytes.  unit_size applies to the samples of each plane (luma and chroma). */
+typedef struct av1mi_lr_decide_job {
+  int width, height, bit_depth, nframes, unit_size;
+  int stride_y, stride_uv;
+  const void *d_cdef_y, *d_cdef_u, *d_cdef_v;
+  const void *d_dbl_y, *d_dbl_u, *d_dbl_v;       /* the deblocked planes (rows beside the stripes) */
+  void *d_out_y, *d_out_u, *d_out_v;
+  const void *d_orig_y, *d_orig_u, *d_orig_v;    /* the source */
+  const int8_t *d_units_y, *d_units_uv; size_t unit_frame_stride_y, unit_frame_stride_uv;
+  void *d_scratch; uint8_t *d_on;
+} av1mi_lr_decide_job;
+size_t av1mi_lr_yuv_decide_scratch_bytes(int height, int nframes);
+int av1mi_lr_yuv_decide(av1mi_ctx *ctx, const av1mi_lr_decide_job *job);
+
 /* In place: the column visible_w - 1 of every row replicated into columns [visible_w, w), then row visible_h - 1 into rows
  * [visible_h, h), for nframes stacked frames of one plane (see av1mi_gop_config.visible_width for when an encoder loop needs it). */
 int av1mi_extend_frames(av1mi_ctx *ctx, void *d_plane, int stride, int w, int h, int visible_w, int visible_h, int bd, int nframes);

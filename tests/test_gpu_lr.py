@@ -98,3 +98,36 @@ def test_lr_on_off_decision_equals_the_oracle(ctx, O, bd, ss):
         exp = [O.lr_select((src[f],), (cdef[f],), (lr[f],), bd, ss)[1][0] for f in range(nf)]
         assert on[:, 1].tolist() == exp and (on[:, 0] == 7).all() and (on[:, 2] == 7).all(), ((h, w), unit, on.tolist(), exp)
         assert exp[1] == 0 and (exp[2] == 1 or (lr[2] == cdef[2]).mean() > 0.2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,bd", [(200, 136, 8), (136, 72, 10)])
+def test_three_plane_decide_equals_three_single_plane_calls(ctx, av1mi, O, w, h, bd):
+    """av1mi_lr_yuv_decide (one zeroing launch, three restorations, one decision launch: what the GOP session uses) against
+    av1mi_lr_frames_decide per plane: the same restored planes and the same ON / OFF flags"""
+    rng = np.random.default_rng(w * 7 + bd)
+    nf, unit = 3, 64
+    dims = [(h, w), (h // 2, w // 2), (h // 2, w // 2)]
+    cdef = [np.stack([make_image(rng, hh, ww, bd) for _ in range(nf)]) for hh, ww in dims]
+    dbl = [c.copy() for c in cdef]
+    mx = (1 << bd) - 1
+    src = [np.clip(c.astype(int) + rng.integers(-2, 3, c.shape), 0, mx).astype(c.dtype) for c in cdef]
+    uy, uc = _random_units(rng, O, unit, h, w), _random_units(rng, O, unit, h // 2, w // 2)
+    d = {k: [ctx.to_device(a) for a in v] for k, v in (("cdef", cdef), ("dbl", dbl), ("src", src))}
+    d_uy, d_uc = ctx.to_device(uy), ctx.to_device(uc)
+    out1 = [ctx.alloc(c.nbytes) for c in cdef]
+    out3 = [ctx.alloc(c.nbytes) for c in cdef]
+    on1, on3 = ctx.to_device(np.full(3 * nf + 1, 9, np.uint8)), ctx.to_device(np.full(3 * nf + 1, 9, np.uint8))
+    for p in range(3):
+        scr = ctx.alloc(ctx.lr_decide_scratch_bytes(dims[p][0], p > 0, nf))
+        ctx.lr_frames_decide(d["cdef"][p], d["dbl"][p], out1[p], dims[p][1], dims[p][1], dims[p][0], bd, p > 0, unit, d_uc if p else d_uy, 0, nf,
+                             d["src"][p], scr, on1, on_offset=p, on_stride=3)
+        ctx.sync()
+        scr.free()
+    scr = ctx.to_device(np.full(ctx.lr_yuv_decide_scratch_bytes(h, nf), 0xA5, np.uint8))      # the call zeroes it itself
+    ctx.lr_yuv_decide(av1mi.LrDecideJob(w, h, bd, nf, unit, w, w // 2, *[b.ptr for b in d["cdef"] + d["dbl"] + out3 + d["src"]], d_uy.ptr, d_uc.ptr, 0, 0,
+                                        scr.ptr, on3.ptr))
+    a, b = on1.download((3 * nf + 1,), np.uint8), on3.download((3 * nf + 1,), np.uint8)
+    assert a.tolist() == b.tolist() and a[-1] == 9 and set(a[:-1].tolist()) <= {0, 1}
+    for p in range(3):
+        assert (out1[p].download(cdef[p].shape, cdef[p].dtype) == out3[p].download(cdef[p].shape, cdef[p].dtype)).all()

@@ -108,10 +108,12 @@ def test_pipeline_with_gpu_entropy_stage(ctx, O):
     pipe.close()
 
 
-def test_async_entropy_stage_matches_sync(ctx, O):
-    """side-stream coder with double-buffered levels: every step's records equal the oracle's, whichever slot they used"""
+def test_async_entropy_stage_matches_sync(ctx, av1mi, O):
+    """side-stream coder with double-buffered levels: every step's records equal the oracle's, whichever slot they used — also
+    on a context whose side stream a GOP session has created before (the events of this path are then still to be made)"""
     import pipeline
     w, h, bd, q = 256, 136, 8, 150
+    av1mi.GopSession(ctx, 64, 64, 8, 100, 2, 1, gpu_entropy=1).close()
     pipe = pipeline.IntraPipeline(ctx, w, h, bd, 2, q, first_frame=0, entropy_tile=32, entropy_async=True)
     Y, U, V = pipe.src
     ref = []
