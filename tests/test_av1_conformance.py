@@ -287,12 +287,13 @@ def _crop(planes, vw, vh):
     return [planes[0][:vh, :vw], planes[1][:(vh + 1) // 2, :(vw + 1) // 2], planes[2][:(vh + 1) // 2, :(vw + 1) // 2]]
 
 
-def visible_gop(O, P, vw, vh, bd, q, nframes, first=3):
-    """the oracle's closed-GOP chain of a vw x vh source; returns (stream, per frame [stages of the key frame | reference planes])"""
+def visible_gop(O, P, vw, vh, bd, q, nframes, first=3, frames=None):
+    """the oracle's closed-GOP chain of a vw x vh source (frames: (Y, U, V) stacks to cut it from; default synthetic ones);
+    returns (stream, the reference planes per frame, the key frame's stages)"""
     import av1stream
     import synth
     w, h = (vw + 7) // 8 * 8, (vh + 7) // 8 * 8
-    Yc, Uc, Vc = synth.frames(w + 8, h + 8, nframes, bd, first)       # any content: cut the true size out of a larger frame
+    Yc, Uc, Vc = frames if frames is not None else synth.frames(w + 8, h + 8, nframes, bd, first)       # any content: cut the true size out of a larger frame
     stream, refs, ref, key_stages = b"", [], None, None
     for t in range(nframes):
         src = (_pad(Yc[t][:vh, :vw], h, w), _pad(Uc[t][:(vh + 1) // 2, :(vw + 1) // 2], h // 2, w // 2), _pad(Vc[t][:(vh + 1) // 2, :(vw + 1) // 2], h // 2, w // 2))

@@ -218,7 +218,7 @@ def test_run_transcode_of_a_source_whose_size_is_not_a_multiple_of_8(host, tmp_p
     import pipeline as P
     import synth
     import test_av1_conformance as T
-    for vw, vh, bd, q, n in ((109, 75, 8, 140, 3), (70, 61, 10, 90, 3)):
+    for vw, vh, bd, q, n, gop in ((109, 75, 8, 140, 3, 3), (70, 61, 10, 90, 7, 3)):      # the second: three GOPs, two segments in lockstep
         w, h = (vw + 7) // 8 * 8, (vh + 7) // 8 * 8
         Yc, Uc, Vc = synth.frames(w + 8, h + 8, n, bd, 3)
         src = tmp_path / ("odd%d.y4m" % bd)
@@ -228,11 +228,15 @@ def test_run_transcode_of_a_source_whose_size_is_not_a_multiple_of_8(host, tmp_p
                 f.write(b"FRAME\n")
                 for pl in (Yc[i][:vh, :vw], Uc[i][:(vh + 1) // 2, :(vw + 1) // 2], Vc[i][:(vh + 1) // 2, :(vw + 1) // 2]):
                     f.write(np.ascontiguousarray(pl).astype("<u2" if bd == 10 else np.uint8).tobytes())
-        stream, refs, _ = T.visible_gop(O, P, vw, vh, bd, q, n)
+        stream, refs = b"", []
+        for g0 in range(0, n, gop):
+            st, rf, _ = T.visible_gop(O, P, vw, vh, bd, q, min(gop, n - g0), frames=(Yc[g0:], Uc[g0:], Vc[g0:]))
+            stream += st
+            refs += rf
         buf = C.create_string_buffer(1024)
         for gpu_entropy in ("0", "1"):
             out = tmp_path / ("odd%d_%s.obu" % (bd, gpu_entropy))
-            args = "\n".join(["-i", str(src), "-global_quality:v:0", str(q), "-g", str(n), "-av1mi_gpu_entropy", gpu_entropy, str(out)])
+            args = "\n".join(["-i", str(src), "-global_quality:v:0", str(q), "-g", str(gop), "-av1mi_segments", "2", "-av1mi_gpu_entropy", gpu_entropy, str(out)])
             assert host.av1mi_host_run_transcode(args.encode(), buf, 1024) == 0 and buf.value == b"", buf.value
             obu = out.read_bytes()
             assert obu == stream, "the file differs from the oracle chain's stream"
@@ -242,7 +246,7 @@ def test_run_transcode_of_a_source_whose_size_is_not_a_multiple_of_8(host, tmp_p
                 for i, a in enumerate(T._crop(refs[t], vw, vh)):
                     assert (got[t][i] == a).all()
         mkv = tmp_path / ("odd%d.mkv" % bd)
-        args = "\n".join(["-i", str(src), "-global_quality:v:0", str(q), "-g", str(n), str(mkv)])
+        args = "\n".join(["-i", str(src), "-global_quality:v:0", str(q), "-g", str(gop), str(mkv)])
         assert host.av1mi_host_run_transcode(args.encode(), buf, 1024) == 0
         data = mkv.read_bytes()
         assert b"\xb0" + bytes([0x81, vw]) in data and b"\xba" + bytes([0x81, vh]) in data      # PixelWidth / PixelHeight = the true size
