@@ -98,6 +98,9 @@ struct LrLaunch {
   // the on/off decision (orig != nullptr): the source plane, and per (frame, stripe) two 64-bit sums: squared error of the restored
   // samples, of the CDEF samples (zeroed by the caller; sse_stripes = lr_stripes(h, ss))
   const void *orig; unsigned long long *sse; int sse_stripes;
+  // two-pass form of the decision (pass 0 = everything in one launch): pass 1 restores only the tiles the sums run over, pass 2 the
+  // others, and only in the frames whose flag keep[f * keep_stride] (written by the decision between the two) is set
+  int pass; const uint8_t *keep; int keep_stride;
 };
 hipError_t launch_lr(const LrLaunch &L, hipStream_t s);
 int lr_stripes(int h, int ss);

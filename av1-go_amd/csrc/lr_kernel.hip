@@ -61,6 +61,8 @@ __global__ __launch_bounds__(256) void k_lr(LrLaunch L) {
   // over the whole picture (every tile when the plane has fewer than 32) — so the decision costs an eighth of a source read.
   const int ntx64 = (L.w + 63) >> 6, nst = (L.h + off + SH - 1) / SH;
   const bool sampled = ntx64 * nst < 32 || (((X0 >> 6) + stripe) & 7) == 0;
+  if (L.pass == 1 && !sampled) return;                                   // (uniform per workgroup, before any barrier)
+  if (L.pass == 2 && (sampled || !L.keep[(size_t)f * L.keep_stride])) return;
   const Pix *orig = L.orig && sampled ? reinterpret_cast<const Pix *>(L.orig) + (size_t)f * L.h * L.stride : nullptr;
   unsigned e_lr = 0, e_cd = 0;
   auto lr_acc = [&](int o, int cd, int sv) { const int a = o - sv, b = cd - sv; e_lr += (unsigned)(a * a); e_cd += (unsigned)(b * b); };

@@ -214,8 +214,10 @@ int av1mi_lr_frames(av1mi_ctx *ctx, const void *d_cdef, const void *d_deblocked,
  * samples — sum of squared differences, strictly smaller — else 0: the plane the next frame predicts from is then d_cdef's, and
  * the frame header signals lr_type NONE for it.  d_out always receives the restored samples.  d_scratch: device memory of
  * av1mi_lr_decide_scratch_bytes(h, subsampled, nframes) bytes, 8-byte aligned. */
-/* The same for the three planes of 4:2:0 frames in one call (what the GOP session uses): one zeroing launch, the three
- * restorations, ONE decision launch — five launches instead of nine.  d_on[f * 3 + plane].  d_scratch: 16-byte aligned,
+/* The same decision for the three planes of 4:2:0 frames in one call (what the GOP session uses), in two passes: the tiles the
+ * decision's sums run over are restored first (an eighth of a large plane), the decision follows, and the other tiles are restored
+ * only in the frames that keep their restoration.  So d_out_* hold the restored plane where d_on[f * 3 + plane] == 1; where it is
+ * 0 — the next frame predicts from d_cdef_* there — only the sampled tiles were written.  d_scratch: 16-byte aligned,
  * av1mi_lr_yuv_decide_scratch_bytes(height, nframes) bytes.  unit_size applies to the samples of each plane (luma and chroma). */
 typedef struct av1mi_lr_decide_job {
   int width, height, bit_depth, nframes, unit_size;

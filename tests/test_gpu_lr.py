@@ -101,9 +101,9 @@ def test_lr_on_off_decision_equals_the_oracle(ctx, O, bd, ss):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("w,h,bd", [(200, 136, 8), (136, 72, 10)])
+@pytest.mark.parametrize("w,h,bd", [(200, 136, 8), (136, 72, 10), (576, 328, 10)])      # the last: luma has 54 tiles, sampled sparsely
 def test_three_plane_decide_equals_three_single_plane_calls(ctx, av1mi, O, w, h, bd):
-    """av1mi_lr_yuv_decide (one zeroing launch, three restorations, one decision launch: what the GOP session uses) against
+    """av1mi_lr_yuv_decide (sampled tiles, decision, the rest of the frames that stay ON: what the GOP session uses) against
     av1mi_lr_frames_decide per plane: the same restored planes and the same ON / OFF flags"""
     rng = np.random.default_rng(w * 7 + bd)
     nf, unit = 3, 64
@@ -113,6 +113,8 @@ def test_three_plane_decide_equals_three_single_plane_calls(ctx, av1mi, O, w, h,
     mx = (1 << bd) - 1
     src = [np.clip(c.astype(int) + rng.integers(-2, 3, c.shape), 0, mx).astype(c.dtype) for c in cdef]
     uy, uc = _random_units(rng, O, unit, h, w), _random_units(rng, O, unit, h // 2, w // 2)
+    for p in range(3):       # frame 1: the source IS the restored plane, so restoration stays on there (unless no unit filters)
+        src[p][1] = O.lr_plane(cdef[p][1], dbl[p][1], bd, int(p > 0), unit, uc if p else uy)
     d = {k: [ctx.to_device(a) for a in v] for k, v in (("cdef", cdef), ("dbl", dbl), ("src", src))}
     d_uy, d_uc = ctx.to_device(uy), ctx.to_device(uc)
     out1 = [ctx.alloc(c.nbytes) for c in cdef]
@@ -128,6 +130,8 @@ def test_three_plane_decide_equals_three_single_plane_calls(ctx, av1mi, O, w, h,
     ctx.lr_yuv_decide(av1mi.LrDecideJob(w, h, bd, nf, unit, w, w // 2, *[b.ptr for b in d["cdef"] + d["dbl"] + out3 + d["src"]], d_uy.ptr, d_uc.ptr, 0, 0,
                                         scr.ptr, on3.ptr))
     a, b = on1.download((3 * nf + 1,), np.uint8), on3.download((3 * nf + 1,), np.uint8)
-    assert a.tolist() == b.tolist() and a[-1] == 9 and set(a[:-1].tolist()) <= {0, 1}
-    for p in range(3):
-        assert (out1[p].download(cdef[p].shape, cdef[p].dtype) == out3[p].download(cdef[p].shape, cdef[p].dtype)).all()
+    assert a.tolist() == b.tolist() and a[-1] == 9 and set(a[:-1].tolist()) <= {0, 1} and a[3] == 1 and a[0] == 0
+    for p in range(3):       # the restored planes where restoration stays ON (elsewhere the two-pass form writes the sampled tiles only)
+        x, y = out1[p].download(cdef[p].shape, cdef[p].dtype), out3[p].download(cdef[p].shape, cdef[p].dtype)
+        for f in range(nf):
+            assert not a[3 * f + p] or (x[f] == y[f]).all()

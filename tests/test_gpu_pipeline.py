@@ -65,7 +65,8 @@ def test_closed_gop_chain_matches_oracle(ctx, O, w, h, bd, q, segs, gop, rng_):
     gp = pipeline.GopPipeline(ctx, w, h, bd, segments=segs, gop=gop, qindex=q, first_frame=1, search_range=rng_)
     got = []
     dl = lambda bufs, shapes: [b.download(s.shape, s.dtype) for b, s in zip(bufs, shapes)]
-    gp.step(on_frame=lambda t: got.append(dl(gp.d_ref, gp.src[t])))
+    cd = [gp.key.d["cdef_" + p] for p in "yuv"]
+    gp.step(on_frame=lambda t: got.append((dl(gp.d_ref, gp.src[t]), dl(cd, gp.src[t]))))
     lr_on = [gp.lr_on(t) for t in range(gop)]
     k = gp.key
     for s in range(segs):
@@ -83,11 +84,13 @@ def test_closed_gop_chain_matches_oracle(ctx, O, w, h, bd, q, segs, gop, rng_):
             cdef = O.cdef_frame(dbl[0], dbl[1], dbl[2], bd, damping, cdef_sb, skip8)
             lr = [O.lr_plane(cdef[0], dbl[0], bd, 0, lr_unit, lr_y), O.lr_plane(cdef[1], dbl[1], bd, 1, lr_unit, lr_c),
                   O.lr_plane(cdef[2], dbl[2], bd, 1, lr_unit, lr_c)]
-            for i in range(3):
-                assert (got[t][i][s] == lr[i]).all(), (s, t, i)
-            # the restoration ON / OFF decision against the source: frame t + 1 predicts from the restored or the CDEF plane
+            # the restoration ON / OFF decision against the source: frame t + 1 predicts from the restored or the CDEF plane, and the
+            # restored plane is complete exactly where it is kept (av1mi_lr_yuv_decide restores the other planes' sampled tiles only)
             ref, on = O.lr_select(src, cdef, lr, bd)
             assert lr_on[t][s].tolist() == on, (s, t, lr_on[t][s].tolist(), on)
+            for i in range(3):
+                assert (got[t][1][i][s] == cdef[i]).all(), (s, t, i)
+                assert not on[i] or (got[t][0][i][s] == lr[i]).all(), (s, t, i)
     gp.close()
 
 
