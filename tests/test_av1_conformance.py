@@ -313,7 +313,7 @@ def visible_gop(O, P, vw, vh, bd, q, nframes, first=3, frames=None):
     return stream, refs, key_stages
 
 
-@pytest.mark.parametrize("vw,vh,bd,q,n", [(100, 76, 8, 220, 3), (61, 45, 8, 100, 3), (130, 70, 10, 60, 3), (199, 133, 8, 180, 2), (66, 129, 10, 140, 3), (132, 68, 10, 230, 3)])
+@pytest.mark.parametrize("vw,vh,bd,q,n", [(100, 76, 8, 220, 3), (61, 45, 8, 100, 3), (130, 70, 10, 60, 3), (199, 133, 8, 180, 2), (66, 129, 10, 140, 3), (132, 68, 10, 230, 3), (17, 9, 8, 120, 2), (9, 23, 10, 160, 2)])
 def test_sizes_that_are_not_multiples_of_8(O, vw, vh, bd, q, n):
     """dav1d outputs the TRUE size; every stage of the key frame and every reference frame of the GOP equals the oracle's planes
     cropped to it — in particular the P frames, whose vectors point into the replicated border"""

@@ -307,7 +307,7 @@ def test_random_small_configurations_decode_to_the_gpu_frames(ctx, av1mi):
 
 @pytest.mark.skipif(not D.available(), reason="no dav1d in this image")
 @pytest.mark.parametrize("vw,vh,bd,q,gop,segs", [(100, 76, 8, 220, 3, 2), (61, 45, 8, 100, 3, 1), (130, 70, 10, 60, 3, 2), (132, 68, 10, 230, 2, 3),
-                                                  (854, 480, 8, 128, 3, 2), (1366, 768, 10, 110, 2, 1)])
+                                                  (854, 480, 8, 128, 3, 2), (1366, 768, 10, 110, 2, 1), (17, 9, 8, 120, 2, 2), (9, 23, 10, 160, 2, 1)])
 def test_sizes_that_are_not_multiples_of_8(ctx, av1mi, O, vw, vh, bd, q, gop, segs):
     """A vw x vh source coded at the size rounded up to 8 (include/av1mi.h av1mi_gop_config.visible_width): the stream announces
     the true size, the host writer and the GPU tile coder give the same bytes, dav1d outputs vw x vh frames that equal the
