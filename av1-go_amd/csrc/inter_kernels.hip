@@ -463,9 +463,14 @@ __global__ __launch_bounds__(256) void k_inter_pipe(InterLaunch L) {
   const int grp = threadIdx.x >> 3, lane = threadIdx.x & 7;
   const int bw = L.w / 8, bh = L.h / 8;
   // workgroups in XCD-aware order: vertically adjacent block rows (their windows overlap by 8 of 16 rows) share an L2
-  const long long blk_all = (long long)xcd_swizzle(blockIdx.x, gridDim.x) * GPW + grp;
-  if (blk_all >= (long long)L.nframes * bw * bh) return;
-  const int f = (int)(blk_all / (bw * bh)), blk = (int)(blk_all % (bw * bh)), by = blk / bw, bx = blk % bw;
+  // frame = a whole number of workgroups (launch_inter_pipe): the frame index is a 32-bit division of the workgroup id — scalar
+  // code — and the block row a reciprocal multiplication with a one-step correction.  (As blk_all / (bw * bh) in 64 bits and two
+  // more integer divisions per lane this line was 117 vector instructions, 5 % of the kernel.)
+  const unsigned wpf = (unsigned)(bw * bh + GPW - 1) / GPW, wg = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int f = (int)(wg / wpf), blk = (int)(wg - (unsigned)f * wpf) * GPW + grp;
+  if (blk >= bw * bh) return;
+  int by = (int)((float)blk * __builtin_amdgcn_rcpf((float)bw)), bx = blk - by * bw;       // blk < 2^22: the estimate is within 1
+  if (bx < 0) { by--; bx += bw; } else if (bx >= bw) { by++; bx -= bw; }
   const int x = bx * 8, y = by * 8;
   unsigned char *reg = regb + grp * REG_BYTES;
   ES *wy = reinterpret_cast<ES *>(reg);
@@ -664,8 +669,8 @@ hipError_t launch_me_int(const InterLaunch &L, hipStream_t s) {
 }
 hipError_t launch_inter_pipe(const InterLaunch &L, hipStream_t s) {
   if (L.nframes <= 0) return hipSuccess;
-  const long long blocks = (long long)L.nframes * (L.w / 8) * (L.h / 8);
-  const dim3 g2((unsigned)((blocks + 31) / 32));
+  const long long wpf = ((long long)(L.w / 8) * (L.h / 8) + 31) / 32;       // workgroups per frame (32 blocks each)
+  const dim3 g2((unsigned)(wpf * L.nframes));
   if (L.bd == 8) hipLaunchKernelGGL(k_inter_pipe<uint8_t>, g2, dim3(256), 0, s, L);
   else hipLaunchKernelGGL(k_inter_pipe<uint16_t>, g2, dim3(256), 0, s, L);
   return hipGetLastError();
