@@ -634,12 +634,15 @@ __global__ __launch_bounds__(256) void k_inter_pipe(InterLaunch L) {
     ES *wc = wy + pl * CW * CWS;
     int16_t *imc = reinterpret_cast<int16_t *>(reg + CWIN_BYTES) + pl * (11 * 4 + 4);
     AV1MI_GROUP_SYNC();                               // the luma transpose buffer has been read: the region is free
+    // the 4-tap family reads window rows 3 .. 9 only (mc_row<4, ES, 2, 6>: taps 2 .. 5 of rows -1 .. +5 around the block)
 #pragma unroll
-    for (int it = 0; it < 3; it++) {
-      const int r = cl + it * 4;
-      const int fy = min(max(cy0 + ciy - 4 + r, 0), chh - 1);
-      const Pix *row = ref_c + row_off(fy, L.stride_uv);
-      stage_window_row<CW, Pix>(row, cx0 + cix - 4, cw, wc + r * CWS);
+    for (int it = 0; it < 2; it++) {
+      const int r = 3 + cl + it * 4;
+      if (r <= 9) {
+        const int fy = min(max(cy0 + ciy - 4 + r, 0), chh - 1);
+        const Pix *row = ref_c + row_off(fy, L.stride_uv);
+        stage_window_row<CW, Pix>(row, cx0 + cix - 4, cw, wc + r * CWS);
+      }
     }
     int sc[4], pc[4], rc[4];
     load_row<4>(src_c + row_off(cy0 + cl, L.stride_uv) + cx0, sc);
