@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void k_me_int(InterLaunch L) {
   static_assert(WS >= 64 + 2 * MAXR + 4 && WS % 4 == 0, "window row must hold tile + range and be whole dwords");
   __shared__ __attribute__((aligned(16))) uint8_t win[(64 + 2 * MAXR) * WS];
   __shared__ __attribute__((aligned(16))) uint8_t srct[64 * 64];
-  __shared__ uint32_t s_best[64];                    // per 8x8 block: min of (SAD, rank)
+  __shared__ uint32_t s_best[64];                    // per 8x8 block: min of SAD << 16 | rank
   constexpr int sh = sizeof(Pix) == 1 ? 0 : 2;
   const int tid = threadIdx.x, R = RC ? RC : L.range, R4 = (R + 3) & ~3, NC = 2 * R + 1;
   const int WDX = 64 + 2 * R4 + 4, WDY = 64 + 2 * R + 2;    // window columns start at x - R4 (4-aligned), rows at y - R; two more rows for the unused part of the last dy triple
@@ -124,14 +124,38 @@ __global__ __launch_bounds__(256) void k_me_int(InterLaunch L) {
   // 0.5 / per to an integer, far outside float rounding, so the truncation is the exact quotient (an integer division by a
   // run-time divisor is ~25 instructions, and there are two per item)
   const float inv_per = 1.0f / (float)per, inv_ng = 1.0f / (float)NG;
+  // what an item (dy triple dp, dx group g) contributes whatever the block: its window offset, the ranks of its 12 displacements
+  // (~0 = outside +-R) and whether it holds the zero vector.  With 32 items per block a lane has the SAME item in every round, so
+  // all of it is computed once, before the loop (the compiler does not hoist it out of the rounds' conditional bodies by itself).
+  struct Item { int off; unsigned rk[HD][4]; unsigned not_zero_item; };
+  auto make_item = [&](int t) {
+    Item it;
+    const int dp = (int)(((float)t + 0.5f) * inv_ng), g = t - __mul24(dp, NG);    // dy = 3 dp - R + {0, 1, 2}, dx0 = -R4 + 4 g
+    it.off = __mul24(HD * dp, WS) + 4 * g;
+    // rank: (0,0) ranks first (0), the others in raster order (1 + (dy + R) NC + dx + R < 1024); dx_i = 4 g - R4 + i is in range for
+    // i in [imin, imax]; row h of the triple exists when 3 dp + h < NC
+    const int imin = R4 - R - 4 * g, imax = R4 + R - 4 * g;
+    const unsigned rank0 = (unsigned)(__mul24(HD * dp, NC) + 4 * g - R4 + R + 1);
+#pragma unroll
+    for (int h = 0; h < HD; h++)
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+        it.rk[h][i] = (rank0 + h * NC + i) | (unsigned)(((i - imin) | (imax - i)) >> 31) | (unsigned)((NC - 1 - h - HD * dp) >> 31);
+    it.not_zero_item = (dp == R / HD && g == (R4 >> 2)) ? 0u : 0xFFFFFFFFu;     // dy index R = row R % 3 of triple R / 3, dx index R4 = sample 0 of group R4 >> 2
+    return it;
+  };
+  Item fixed = {};
+  if constexpr (RC == 8) fixed = make_item(lane & 31);
   for (int u0 = 0; u0 < 16 * per; u0 += 64) {
     const int u = u0 + lane;
     if (u < 16 * per) {
-      const int bi = RC == 8 ? u >> 5 : (int)(((float)u + 0.5f) * inv_per), t = u - __mul24(bi, per), b = wave + 4 * bi;   // (plain products here became 64-bit multiply-adds)
+      // (with 32 items per block the item of a lane — its dy triple, dx group, ranks and validity masks — is the same in every round:
+      // written so that the compiler sees it and keeps them in registers across the unrolled rounds)
+      const int bi = RC == 8 ? (u0 >> 5) + (lane >> 5) : (int)(((float)u + 0.5f) * inv_per), t = RC == 8 ? (lane & 31) : u - __mul24(bi, per), b = wave + 4 * bi;   // (plain products here became 64-bit multiply-adds)
       const int by = b >> 3, bx = b & 7;
       if (t < items && sbx * 8 + bx < bw && sby * 8 + by < bh) {
-        const int dp = (int)(((float)t + 0.5f) * inv_ng), g = t - __mul24(dp, NG);    // dy = 3 dp - R + {0, 1, 2}, dx0 = -R4 + 4 g
-        const uint8_t *p = win + __mul24(by * 8 + HD * dp, WS) + bx * 8 + 4 * g;
+        const Item it = RC == 8 ? fixed : make_item(t);
+        const uint8_t *p = win + __mul24(by * 8, WS) + bx * 8 + it.off;
         const uint8_t *s = srct + (by * 8) * 64 + bx * 8;
         // the SAD runs over the block's EVEN rows (policy; the oracle's block_sad8): half the QSADs, the same vectors on the test clips
         uint2 sr[4];
@@ -150,30 +174,23 @@ __global__ __launch_bounds__(256) void k_me_int(InterLaunch L) {
               acc[h] = __builtin_amdgcn_qsad_pk_u16_u8(w12, sr[(r - h) >> 1].y, acc[h]);
             }
         }
-        // key = SAD << 10 | rank: (0,0) ranks first (0), the others in raster order (1 + (dy + R) NC + dx + R < 1024); ties keep
-        // the lower rank.  Branch-free: a displacement outside +-R gets rank ~0, which turns its key into ~0 under the OR.
-        // dx_i = 4 g - R4 + i is in range for i in [imin, imax]; row h of the triple exists when 3 dp + h < NC.
-        const int imin = R4 - R - 4 * g, imax = R4 + R - 4 * g;
-        const unsigned rank0 = (unsigned)(__mul24(HD * dp, NC) + 4 * g - R4 + R + 1);
-        unsigned inv_h[HD];
-#pragma unroll
-        for (int h = 0; h < HD; h++) inv_h[h] = (unsigned)((NC - 1 - h - HD * dp) >> 31);
+        // key = SAD << 16 | rank; ties keep the lower rank; a displacement outside +-R has rank ~0, which turns its key into ~0 under
+        // the OR.  With the SAD in the upper half a candidate's key is ONE instruction from the packed QSAD result:
+        // (word << 16) | rank or (word & 0xFFFF0000) | rank.
         unsigned best = 0xFFFFFFFFu;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-          const unsigned inv = (unsigned)(((i - imin) | (imax - i)) >> 31);
+        for (int h = 0; h < HD; h++) {
+          const uint32_t lo = (uint32_t)acc[h], hi = (uint32_t)(acc[h] >> 32);
 #pragma unroll
-          for (int h = 0; h < HD; h++) {
-            const unsigned sd = (unsigned)(acc[h] >> (16 * i)) & 0xFFFFu;
-            best = min(best, (sd << 10) | (rank0 + h * NC + i) | inv | inv_h[h]);
+          for (int i = 0; i < 4; i++) {
+            const uint32_t word = i < 2 ? lo : hi;
+            best = min(best, ((i & 1) ? (word & 0xFFFF0000u) : (word << 16)) | it.rk[h][i]);
           }
         }
-        // the zero vector: dy index R = row R % 3 of triple R / 3, dx index R4 = sample 0 of group R4 >> 2
         {
-          const int hz = R % HD;
-          const unsigned sz = (unsigned)(hz == 0 ? acc[0] : hz == 1 ? acc[1] : acc[2]) & 0xFFFFu;
-          const unsigned not_zero_item = (dp == R / HD && g == (R4 >> 2)) ? 0u : 0xFFFFFFFFu;
-          best = min(best, (sz << 10) | not_zero_item);
+          const int hz = R % HD;      // the zero vector
+          const unsigned sz = (unsigned)(hz == 0 ? acc[0] : hz == 1 ? acc[1] : acc[2]) << 16;
+          best = min(best, sz | it.not_zero_item);
         }
         atomicMin(&s_best[b], best);
       }
@@ -184,7 +201,7 @@ __global__ __launch_bounds__(256) void k_me_int(InterLaunch L) {
     const int by = tid >> 3, bx = tid & 7;
     const int fbx = sbx * 8 + bx, fby = sby * 8 + by;
     if (fbx < bw && fby < bh) {
-      const int rank = s_best[tid] & 1023;
+      const int rank = s_best[tid] & 0xFFFF;
       const int dy = rank ? (rank - 1) / NC - R : 0, dx = rank ? (rank - 1) % NC - R : 0;
       mvs[((size_t)fby * bw + fbx) * 2] = (int16_t)(dx * 8);
       mvs[((size_t)fby * bw + fbx) * 2 + 1] = (int16_t)(dy * 8);
