@@ -116,7 +116,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) void
     for (int w = 0; w < kBlocksPerTile / 4; w++) {
       const uint32_t u = sl < nslots ? reinterpret_cast<const uint32_t *>(S.p1.cnt)[sl * (kBlocksPerTile / 4) + w] : 0u;
       c[q][w] = u;
-      sum += (int)((u & 0xFF) + ((u >> 8) & 0xFF) + ((u >> 16) & 0xFF) + (u >> 24));
+      sum = (int)__builtin_amdgcn_sad_u8(u, 0u, (unsigned)sum);      // the four counts of the dword in one instruction
     }
     if (sl < S_MAX) S.total[sl] = (uint16_t)sum;
   }
