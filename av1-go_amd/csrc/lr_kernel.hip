@@ -44,6 +44,13 @@ __global__ __launch_bounds__(256) void k_lr(LrLaunch L) {
   const int sstart = stripe * SH - off, send = sstart + SH - 1;
   const int y0 = max(sstart, 0), y1 = min(send, L.h - 1);    // rows this workgroup writes
   if (y0 > y1 || X0 >= L.w) return;
+  // The decision's sums run over an EIGHTH of the plane — the 64-column x stripe tiles with (column + stripe) % 8 == 0, a diagonal
+  // pattern over the whole picture (every tile when the plane has fewer than 32) — so the decision costs an eighth of a source read.
+  // Two-pass form: the workgroups that have nothing to do leave before they load anything (uniform per workgroup, before any barrier).
+  const int ntx64 = (L.w + 63) >> 6, nst = (L.h + off + SH - 1) / SH;
+  const bool sampled = ntx64 * nst < 32 || (((X0 >> 6) + stripe) & 7) == 0;
+  if (L.pass == 1 && !sampled) return;
+  if (L.pass == 2 && (sampled || !L.keep[(size_t)f * L.keep_stride])) return;
   const int bw = min(tw, L.w - X0), bh = y1 - y0 + 1;
   const Pix *cdef = reinterpret_cast<const Pix *>(L.cdef) + (size_t)f * L.h * L.stride;
   const Pix *dbl = reinterpret_cast<const Pix *>(L.dbl) + (size_t)f * L.h * L.stride;
@@ -57,12 +64,6 @@ __global__ __launch_bounds__(256) void k_lr(LrLaunch L) {
   const int type = U[0];
   // the on/off decision's two sums (L.orig != nullptr): squared error of the restored samples and of the CDEF samples this workgroup
   // covers, against the source; per lane in 32 bits (16 samples x 2^20), per wave and stripe into 64-bit words (lr_finish)
-  // The sums run over an EIGHTH of the plane — the 64-column x stripe tiles with (column + stripe) % 8 == 0, a diagonal pattern
-  // over the whole picture (every tile when the plane has fewer than 32) — so the decision costs an eighth of a source read.
-  const int ntx64 = (L.w + 63) >> 6, nst = (L.h + off + SH - 1) / SH;
-  const bool sampled = ntx64 * nst < 32 || (((X0 >> 6) + stripe) & 7) == 0;
-  if (L.pass == 1 && !sampled) return;                                   // (uniform per workgroup, before any barrier)
-  if (L.pass == 2 && (sampled || !L.keep[(size_t)f * L.keep_stride])) return;
   const Pix *orig = L.orig && sampled ? reinterpret_cast<const Pix *>(L.orig) + (size_t)f * L.h * L.stride : nullptr;
   unsigned e_lr = 0, e_cd = 0;
   auto lr_acc = [&](int o, int cd, int sv) { const int a = o - sv, b = cd - sv; e_lr += (unsigned)(a * a); e_cd += (unsigned)(b * b); };
