@@ -63,10 +63,13 @@ __global__ __launch_bounds__(256) void k_av1_info(Av1EntLaunch L) {
   L.info[nb * f + b] = o;
 }
 
+// the records are replayed in two passes over half of the slots each: the 16-bit positions [slots][64 blocks] of ALL slots were 25 KB
+// of LDS = 6 workgroups per CU; 12.5 KB fit beside nothing larger (counts + magnitudes: 19 KB) = 8, what the registers allow
+constexpr int kReplaySlots = (S_MAX + 1) / 2;
 struct TokLds {
   union {
     struct { uint8_t cnt[S_MAX * kBlocksPerTile]; alignas(16) uint8_t mag[kBlocksPerTile * kMagBytes]; } p1;    // while tokenizing
-    uint16_t pos[S_MAX * kBlocksPerTile];                                                                      // while replaying
+    uint16_t pos[kReplaySlots * kBlocksPerTile];                                                               // while replaying: half of the slots at a time
   };
   uint16_t total[S_MAX], base[S_MAX];
   ScanTables scan;
@@ -139,23 +142,34 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) void
     const int sl = zi + 64 * q;
     if (sl >= S_MAX) continue;
     const bool on = sl < nslots;
-    int run = on ? S.base[sl] : 0;
     L.slot_total[(size_t)t * S_MAX + sl] = on ? S.total[sl] : (uint16_t)0;
-    L.slot_base[(size_t)t * S_MAX + sl] = (uint16_t)run;
-    if (!on) continue;
-#pragma unroll
-    for (int w = 0; w < kBlocksPerTile / 4; w++) {
-      const uint32_t u = c[q][w];
-      const int p0 = run, p1 = p0 + (int)(u & 0xFF), p2 = p1 + (int)((u >> 8) & 0xFF), p3 = p2 + (int)((u >> 16) & 0xFF);
-      run = p3 + (int)(u >> 24);
-      uint32_t *d = reinterpret_cast<uint32_t *>(S.pos + sl * kBlocksPerTile + 4 * w);
-      d[0] = (uint32_t)p0 | ((uint32_t)p1 << 16); d[1] = (uint32_t)p2 | ((uint32_t)p3 << 16);
-    }
+    L.slot_base[(size_t)t * S_MAX + sl] = on ? S.base[sl] : (uint16_t)0;
   }
-  __syncthreads();
-  __threadfence_block();
   // replay: the thread's own records (it wrote them itself), literals into the list, adaptive symbols into their slot's entries
-  replay_block(rec, k.nrec, S.pos, zi, first, L.ops + (size_t)t * L.ops_cap, L.grouped + (size_t)t * L.grouped_cap);
+  op_t *list = L.ops + (size_t)t * L.ops_cap;
+  uint32_t *grouped = L.grouped + (size_t)t * L.grouped_cap;
+#pragma unroll
+  for (int half = 0; half < 2; half++) {
+    const int lo = half * kReplaySlots, hi = lo + kReplaySlots;
+    if (half) __syncthreads();                      // the first half's positions have been used up
+#pragma unroll
+    for (int q = 0; q < kOwn; q++) {
+      const int sl = zi + 64 * q;
+      if (sl < lo || sl >= hi || sl >= nslots) continue;
+      int run = S.base[sl];
+#pragma unroll
+      for (int w = 0; w < kBlocksPerTile / 4; w++) {
+        const uint32_t u = c[q][w];
+        const int p0 = run, p1 = p0 + (int)(u & 0xFF), p2 = p1 + (int)((u >> 8) & 0xFF), p3 = p2 + (int)((u >> 16) & 0xFF);
+        run = p3 + (int)(u >> 24);
+        uint32_t *d = reinterpret_cast<uint32_t *>(S.pos + (sl - lo) * kBlocksPerTile + 4 * w);
+        d[0] = (uint32_t)p0 | ((uint32_t)p1 << 16); d[1] = (uint32_t)p2 | ((uint32_t)p3 << 16);
+      }
+    }
+    __syncthreads();
+    __threadfence_block();
+    replay_block(rec, k.nrec, S.pos, zi, first, list, grouped, lo, hi, half == 0);
+  }
 }
 
 // CHAINS: workgroup = one CDF slot of 64 consecutive tiles, one lane per tile.  The slot is the same for the whole wave (no

@@ -153,15 +153,23 @@ AV1_HD int group_positions(const uint8_t *cnt_slot, uint16_t *pos_slot, int base
   for (int b = 0; b < kBlocksPerTile; b++) { const int c = cnt_slot[b]; pos_slot[b] = (uint16_t)run; run += c; }
   return run - base;
 }
-// the block's records -> list words (from index `first`) and grouped entries; pos = [S_MAX][64] running positions
-AV1_HD void replay_block(const uint16_t *rec, int nrec, uint16_t *pos, int zi, int first, op_t *list, uint32_t *grouped) {
+// the block's records -> list words (from index `first`) and grouped entries; pos = [slots][64] running positions.  The GPU replays
+// in two passes over half of the slots each (half the positions in LDS): a pass takes the symbols of slots [slot_lo, slot_hi), whose
+// positions start at pos row 0, and the literals when `literals` is set
+AV1_HD void replay_block(const uint16_t *rec, int nrec, uint16_t *pos, int zi, int first, op_t *list, uint32_t *grouped, int slot_lo = 0,
+                         int slot_hi = 1 << 16, bool literals = true) {
   int n = first;
   for (int i0 = 0; i0 < nrec; i0 += 8) {
-    struct alignas(16) R8 { uint16_t v[8]; } q = *reinterpret_cast<const R8 *>(rec + i0);
-    for (int j = 0; j < 8 && i0 + j < nrec; j++, n++) {
-      const unsigned r = q.v[j];
-      if (r & 0x8000u) list[n] = op_lit((int)((r >> 11) & 15), r & 0x7FFu);
-      else { uint16_t &p = pos[(r >> 4) * kBlocksPerTile + zi]; grouped[p] = ((uint32_t)n << 4) | (r & 15u); p++; }
+    struct alignas(16) R8 { uint32_t w[4]; } q = *reinterpret_cast<const R8 *>(rec + i0);
+    AV1_UNROLL      // (fully unrolled the eight records are register halves; indexed at run time the array lived in scratch memory)
+    for (int j = 0; j < 8; j++, n++) {
+      if (i0 + j >= nrec) break;
+      const unsigned r = (q.w[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
+      if (r & 0x8000u) { if (literals) list[n] = op_lit((int)((r >> 11) & 15), r & 0x7FFu); }
+      else {
+        const int sl = (int)(r >> 4);
+        if (sl >= slot_lo && sl < slot_hi) { uint16_t &p = pos[(sl - slot_lo) * kBlocksPerTile + zi]; grouped[p] = ((uint32_t)n << 4) | (r & 15u); p++; }
+      }
     }
   }
 }
@@ -385,7 +393,7 @@ AV1_HD void fill_scan_tables(ScanTables *t) {
 }
 // what a thread needs beside the frame to tokenize coefficients: its own scratch (LDS on the GPU: the magnitudes are read five
 // at a time per coefficient) and the scan tables
-enum { kMagStride = 12, kMagBytes = 148 };      // (8 + 4)^2 = 144, + 4: an odd number of dwords per thread
+enum { kMagStride = 10, kMagBytes = 100 };      // (8 + 2)^2: the context templates reach two columns / rows beyond a level; 25 dwords (odd) per thread
 struct TokScratch { uint8_t *mag; const ScanTables *scan; };
 
 // coeffs() (5.11.39) of one transform block: `lev` = its N x N levels, row-major (16-byte aligned)
