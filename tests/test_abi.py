@@ -95,3 +95,20 @@ def test_device_copy_and_memset(ctx):
     assert rc < 0 and b"null" in ctx.lib.av1mi_last_error(ctx.h)
     d_a.free()
     d_b.free()
+
+
+def test_off_screen_deblocking_units_are_marked_unfiltered():
+    """policy_arrays(visible=...): 4x4 units that start at or beyond the true size carry "skipped inter block, no block edge" (spec
+    7.14.2 onScreen; a chroma unit is 8 luma samples wide), the others the frame's levels — what the session builds in C++"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "av1-go_amd"))
+    import pipeline as P
+    a = P.policy_arrays(120, 8, 1, 104, 80, visible=(98, 75))
+    y, c = a["mi_y"], a["mi_c"]
+    on_y, on_c = y[0, 0], c[0, 0]
+    assert (on_y >> 24) == 6 and (on_c >> 24) == 6              # both edges are block edges, not skipped
+    assert (y[:19, :25] == on_y).all() and (y[19:, :] >> 24 == 1).all() and (y[:, 25:] >> 24 == 1).all()      # 4 * 19 = 76 >= 75, 4 * 25 = 100 >= 98
+    assert (c[:10, :13] == on_c).all() and (c[10:, :] >> 24 == 1).all() and (c[:, 13:] >> 24 == 1).all()      # 8 * 10 = 80 >= 75, 8 * 13 = 104 >= 98
+    b = P.policy_arrays(120, 8, 1, 104, 80)
+    assert (b["mi_y"] == on_y).all() and (b["mi_c"] == on_c).all()

@@ -135,3 +135,20 @@ def test_three_plane_decide_equals_three_single_plane_calls(ctx, av1mi, O, w, h,
         x, y = out1[p].download(cdef[p].shape, cdef[p].dtype), out3[p].download(cdef[p].shape, cdef[p].dtype)
         for f in range(nf):
             assert not a[3 * f + p] or (x[f] == y[f]).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bd", [8, 10])
+def test_extend_frames_replicates_the_true_edge(ctx, bd):
+    """av1mi_extend_frames == numpy edge replication (pipeline.extend_visible), stacked frames, every padding width 0 .. 7"""
+    import pipeline as P
+    rng = np.random.default_rng(bd)
+    dt = np.uint8 if bd == 8 else np.uint16
+    for (w, h, vw, vh) in ((64, 48, 64, 48), (64, 48, 57, 48), (64, 48, 64, 41), (72, 40, 66, 35), (16, 16, 9, 9), (104, 80, 100, 76)):
+        a = rng.integers(0, 1 << bd, (3, h, w)).astype(dt)
+        d = ctx.to_device(a)
+        ctx.extend_frames(d, w, w, h, vw, vh, bd, 3)
+        got = d.download(a.shape, dt)
+        d.free()
+        assert (got == P.extend_visible(a.copy(), vw, vh)).all(), (w, h, vw, vh)
+        assert (got[:, :vh, :vw] == a[:, :vh, :vw]).all()
