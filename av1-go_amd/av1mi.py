@@ -88,7 +88,7 @@ class LrDecideJob(C.Structure):
                 ("d_out_y", C.c_void_p), ("d_out_u", C.c_void_p), ("d_out_v", C.c_void_p),
                 ("d_orig_y", C.c_void_p), ("d_orig_u", C.c_void_p), ("d_orig_v", C.c_void_p),
                 ("d_units_y", C.c_void_p), ("d_units_uv", C.c_void_p), ("unit_frame_stride_y", C.c_size_t), ("unit_frame_stride_uv", C.c_size_t),
-                ("d_scratch", C.c_void_p), ("d_on", C.c_void_p)]
+                ("d_scratch", C.c_void_p), ("d_on", C.c_void_p), ("no_self_guided_units", C.c_int)]
 
 
 class GopConfig(C.Structure):

@@ -101,6 +101,7 @@ struct LrLaunch {
   // two-pass form of the decision (pass 0 = everything in one launch): pass 1 restores only the tiles the sums run over, pass 2 the
   // others, and only in the frames whose flag keep[f * keep_stride] (written by the decision between the two) is set
   int pass; const uint8_t *keep; int keep_stride;
+  int no_sgr;       // the caller's promise that no unit is self-guided (type 2): the kernel without that path's LDS
 };
 hipError_t launch_lr(const LrLaunch &L, hipStream_t s);
 int lr_stripes(int h, int ss);

@@ -431,7 +431,7 @@ int av1mi_lr_frames(av1mi_ctx *ctx, const void *d_cdef, const void *d_deblocked,
     return fail(ctx, AV1MI_E_INVAL, "restoration unit size %d not allowed", unit_size);
   if (nframes < 0 || nframes > 65535) return fail(ctx, AV1MI_E_INVAL, "nframes %d out of range", nframes);
   if (nframes == 0) return AV1MI_OK;
-  av1mi::LrLaunch L = { d_cdef, d_deblocked, d_out, stride, w, h, bd, subsampled ? 1 : 0, unit_size, nframes, d_units, unit_frame_stride, nullptr, nullptr, 0, 0, nullptr, 0 };
+  av1mi::LrLaunch L = { d_cdef, d_deblocked, d_out, stride, w, h, bd, subsampled ? 1 : 0, unit_size, nframes, d_units, unit_frame_stride, nullptr, nullptr, 0, 0, nullptr, 0, 0 };
   { ProfScope ps(ctx, AV1MI_K_LR); HIP_TRY(ctx, av1mi::launch_lr(L, ctx->stream)); }
   return AV1MI_OK;
 }
@@ -454,7 +454,7 @@ int av1mi_lr_frames_decide(av1mi_ctx *ctx, const void *d_cdef, const void *d_deb
   const int stripes = av1mi::lr_stripes(h, subsampled ? 1 : 0);
   HIP_TRY(ctx, hipMemsetAsync(d_scratch, 0, av1mi_lr_decide_scratch_bytes(h, subsampled, nframes), ctx->stream));
   av1mi::LrLaunch L = { d_cdef, d_deblocked, d_out, stride, w, h, bd, subsampled ? 1 : 0, unit_size, nframes, d_units, unit_frame_stride, d_orig,
-                        (unsigned long long *)d_scratch, stripes, 0, nullptr, 0 };
+                        (unsigned long long *)d_scratch, stripes, 0, nullptr, 0, 0 };
   { ProfScope ps(ctx, AV1MI_K_LR); HIP_TRY(ctx, av1mi::launch_lr(L, ctx->stream)); }
   HIP_TRY(ctx, av1mi::launch_lr_decide((const unsigned long long *)d_scratch, nframes, stripes, d_on, on_stride, ctx->stream));
   return AV1MI_OK;
@@ -488,7 +488,7 @@ int av1mi_lr_yuv_decide(av1mi_ctx *ctx, const av1mi_lr_decide_job *j) {
     for (int p = 0; p < 3; p++) {
       av1mi::LrLaunch L = { cdef[p], dbl[p], out[p], p ? j->stride_uv : j->stride_y, p ? j->width / 2 : j->width, p ? j->height / 2 : j->height, j->bit_depth, p ? 1 : 0,
                             j->unit_size, n, p ? j->d_units_uv : j->d_units_y, p ? j->unit_frame_stride_uv : j->unit_frame_stride_y, orig[p],
-                            sse + 2 * ((size_t)(p ? n * sy + (p - 1) * n * sc : 0)), p ? sc : sy, pass, j->d_on + p, 3 };
+                            sse + 2 * ((size_t)(p ? n * sy + (p - 1) * n * sc : 0)), p ? sc : sy, pass, j->d_on + p, 3, j->no_self_guided_units != 0 };
       ProfScope ps(ctx, AV1MI_K_LR);
       HIP_TRY(ctx, av1mi::launch_lr(L, ctx->stream));
     }

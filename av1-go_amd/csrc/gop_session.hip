@@ -385,6 +385,7 @@ int av1mi_gop_submit(av1mi_gop *g, int frame_type) {
     lj.d_orig_y = s.d_src[0]; lj.d_orig_u = s.d_src[1]; lj.d_orig_v = s.d_src[2];
     lj.d_units_y = (const int8_t *)g->d_lr[0]; lj.d_units_uv = (const int8_t *)g->d_lr[1];
     lj.d_scratch = g->d_lr_scratch; lj.d_on = (uint8_t *)s.d_lr_on;
+    lj.no_self_guided_units = P.lr_unit_y[0] != 2 && P.lr_unit_uv[0] != 2;
     G_TRY(av1mi_lr_yuv_decide(g->ctx, &lj));
   }
   if (padded)      // ... and so do its motion-compensation reads of this frame

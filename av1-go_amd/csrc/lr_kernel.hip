@@ -25,12 +25,15 @@ __device__ constexpr int kSgrParams[16][4] = {
   { 0, 0, 1, 11 }, { 0, 0, 1, 14 }, { 2, 30, 0, 0 }, { 2, 75, 0, 0 } };
 
 // SUBY: vertical subsampling of the plane (0 luma, 1 chroma of 4:2:0) — stripe height and offset become constants
-template <typename Pix, int SUBY>
+// SGR: the launch may hold self-guided units.  Without them (the encoder's policy: Wiener or none) the A / B planes of that path
+// are not allocated — 9 instead of 27 KB of scratch, 20 instead of 38 KB of LDS per workgroup, 8 instead of 4 workgroups per CU —
+// and a unit of type 2 would be copied unfiltered (the caller promises there is none: LrLaunch::no_sgr).
+template <typename Pix, int SUBY, bool SGR = true>
 __global__ __launch_bounds__(256) void k_lr(LrLaunch L) {
   constexpr int MAXH = 64, MAXW = 64, SS = MAXW + 16;      // source tile row stride (u16): tile column 0 = X0 - 4
   constexpr int AS = MAXW + 2 + 2;                         // A/B row stride
   __shared__ __attribute__((aligned(16))) uint16_t src[(MAXH + 6) * SS];
-  __shared__ __attribute__((aligned(16))) unsigned char scratch[(MAXH + 2) * AS * 2 + (MAXH + 2) * AS * 4];
+  __shared__ __attribute__((aligned(16))) unsigned char scratch[SGR ? (MAXH + 2) * AS * 2 + (MAXH + 2) * AS * 4 : (MAXH + 6) * MAXW * 2];
   int16_t *inter = reinterpret_cast<int16_t *>(scratch);                       // Wiener: (SH+6) x tw
   uint16_t *Abuf = reinterpret_cast<uint16_t *>(scratch);                      // self-guided: (SH+2) x (tw+2)
   int32_t *Bbuf = reinterpret_cast<int32_t *>(scratch + (MAXH + 2) * AS * 2);
@@ -61,7 +64,7 @@ __global__ __launch_bounds__(256) void k_lr(LrLaunch L) {
   const uint2 U8 = *reinterpret_cast<const uint2 *>(L.units + ((size_t)f * L.unit_frame_stride + (size_t)ur * ucols + uc) * 8);
   const int U[8] = { (int8_t)(U8.x & 255), (int8_t)((U8.x >> 8) & 255), (int8_t)((U8.x >> 16) & 255), (int8_t)(U8.x >> 24),
                      (int8_t)(U8.y & 255), (int8_t)((U8.y >> 8) & 255), (int8_t)((U8.y >> 16) & 255), (int8_t)(U8.y >> 24) };
-  const int type = U[0];
+  const int type = (!SGR && U[0] == 2) ? 0 : U[0];
   // the on/off decision's two sums (L.orig != nullptr): squared error of the restored samples and of the CDEF samples this workgroup
   // covers, against the source; per lane in 32 bits (16 samples x 2^20), per wave and stripe into 64-bit words (lr_finish)
   const Pix *orig = L.orig && sampled ? reinterpret_cast<const Pix *>(L.orig) + (size_t)f * L.h * L.stride : nullptr;
@@ -279,6 +282,7 @@ __global__ __launch_bounds__(256) void k_lr(LrLaunch L) {
     return;
   }
   // self-guided
+  if constexpr (!SGR) return;
   const int set = U[1] & 15, w0 = U[2], w1 = U[3], w2 = 128 - w0 - w1;
   int flt[2][16];   // this lane's samples: index k <-> sample tid + 256 k of the block (row-major)
 #pragma unroll
@@ -414,13 +418,11 @@ hipError_t launch_lr(const LrLaunch &L, hipStream_t s) {
   const int SH = 64 >> L.ss, off = 8 >> L.ss;
   const int tw = L.unit_size < 64 ? L.unit_size : 64;
   const dim3 grid((unsigned)(((L.w + tw - 1) / tw) * ((L.h + off + SH - 1) / SH) * L.nframes));   // 1-D: the kernel orders the tiles (xcd_tile)
-  if (L.ss) {
-    if (L.bd == 8) hipLaunchKernelGGL((k_lr<uint8_t, 1>), grid, dim3(256), 0, s, L);
-    else hipLaunchKernelGGL((k_lr<uint16_t, 1>), grid, dim3(256), 0, s, L);
-  } else {
-    if (L.bd == 8) hipLaunchKernelGGL((k_lr<uint8_t, 0>), grid, dim3(256), 0, s, L);
-    else hipLaunchKernelGGL((k_lr<uint16_t, 0>), grid, dim3(256), 0, s, L);
-  }
+#define AV1MI_LR(PIX, SUBY) do { if (L.no_sgr) hipLaunchKernelGGL((k_lr<PIX, SUBY, false>), grid, dim3(256), 0, s, L); \
+                                  else hipLaunchKernelGGL((k_lr<PIX, SUBY, true>), grid, dim3(256), 0, s, L); } while (0)
+  if (L.ss) { if (L.bd == 8) AV1MI_LR(uint8_t, 1); else AV1MI_LR(uint16_t, 1); }
+  else { if (L.bd == 8) AV1MI_LR(uint8_t, 0); else AV1MI_LR(uint16_t, 0); }
+#undef AV1MI_LR
   return hipGetLastError();
 }
 

@@ -248,7 +248,8 @@ class GopPipeline:
         s, on = self.d_src[t], self.d_lr_on[t]
         c.lr_yuv_decide(av1mi.LrDecideJob(w, h, self.bd, f, k.lr_unit, w, w // 2, d["cdef_y"].ptr, d["cdef_u"].ptr, d["cdef_v"].ptr,
                                           d["dbl_y"].ptr, d["dbl_u"].ptr, d["dbl_v"].ptr, self.d_ref[0].ptr, self.d_ref[1].ptr, self.d_ref[2].ptr,
-                                          s[0].ptr, s[1].ptr, s[2].ptr, d["lr_y"].ptr, d["lr_c"].ptr, 0, 0, self.d_lr_scratch.ptr, on.ptr))
+                                          s[0].ptr, s[1].ptr, s[2].ptr, d["lr_y"].ptr, d["lr_c"].ptr, 0, 0, self.d_lr_scratch.ptr, on.ptr,
+                                          int(k.lr_units_y[..., 0].max() < 2 and k.lr_units_c[..., 0].max() < 2)))
 
     def lr_on(self, t):
         """[segments, 3] restoration ON / OFF flags of the t-th frames after the last step"""

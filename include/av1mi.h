@@ -228,6 +228,9 @@ typedef struct av1mi_lr_decide_job {
   const void *d_orig_y, *d_orig_u, *d_orig_v;    /* the source */
   const int8_t *d_units_y, *d_units_uv; size_t unit_frame_stride_y, unit_frame_stride_uv;
   void *d_scratch; uint8_t *d_on;
+  int no_self_guided_units;                      /* != 0: the caller promises that no unit record has type 2 (the session's policy:
+                                                    Wiener or none) — the kernel then runs without the self-guided path's 18 KB of LDS, at
+                                                    twice the occupancy; a type-2 unit would be left unfiltered */
 } av1mi_lr_decide_job;
 size_t av1mi_lr_yuv_decide_scratch_bytes(int height, int nframes);
 int av1mi_lr_yuv_decide(av1mi_ctx *ctx, const av1mi_lr_decide_job *job);

@@ -152,3 +152,37 @@ def test_extend_frames_replicates_the_true_edge(ctx, bd):
         d.free()
         assert (got == P.extend_visible(a.copy(), vw, vh)).all(), (w, h, vw, vh)
         assert (got[:, :vh, :vw] == a[:, :vh, :vw]).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,bd", [(576, 328, 10), (200, 136, 8)])
+def test_wiener_only_kernel_equals_the_general_one(ctx, av1mi, O, w, h, bd):
+    """av1mi_lr_decide_job.no_self_guided_units: the kernel without the self-guided path (half the LDS, what the session runs) gives
+    the planes and decisions of the general kernel when no unit is self-guided"""
+    rng = np.random.default_rng(w + bd)
+    nf, unit = 2, 64
+    dims = [(h, w), (h // 2, w // 2), (h // 2, w // 2)]
+    cdef = [np.stack([make_image(rng, hh, ww, bd) for _ in range(nf)]) for hh, ww in dims]
+    mx = (1 << bd) - 1
+    src = [np.clip(c.astype(int) + rng.integers(-2, 3, c.shape), 0, mx).astype(c.dtype) for c in cdef]
+    uy, uc = _random_units(rng, O, unit, h, w), _random_units(rng, O, unit, h // 2, w // 2)
+    for u in (uy, uc):
+        u[u[..., 0] == 2] = 0                       # self-guided units -> none
+    for p in range(3):
+        src[p][1] = O.lr_plane(cdef[p][1], cdef[p][1], bd, int(p > 0), unit, uc if p else uy)       # frame 1 keeps its restoration
+    d_c, d_s = [ctx.to_device(a) for a in cdef], [ctx.to_device(a) for a in src]
+    d_uy, d_uc = ctx.to_device(uy), ctx.to_device(uc)
+    res = []
+    for flag in (0, 1):
+        out = [ctx.alloc(c.nbytes) for c in cdef]
+        on = ctx.to_device(np.full(3 * nf + 1, 9, np.uint8))
+        scr = ctx.alloc(ctx.lr_yuv_decide_scratch_bytes(h, nf))
+        ctx.lr_yuv_decide(av1mi.LrDecideJob(w, h, bd, nf, unit, w, w // 2, *[b.ptr for b in d_c + d_c + out + d_s], d_uy.ptr, d_uc.ptr, 0, 0,
+                                            scr.ptr, on.ptr, flag))
+        res.append((on.download((3 * nf + 1,), np.uint8), [o.download(c.shape, c.dtype) for o, c in zip(out, cdef)]))
+    assert res[0][0].tolist() == res[1][0].tolist() and res[0][0][3] == 1
+    for p in range(3):
+        for f in range(nf):
+            if res[0][0][3 * f + p]:
+                assert (res[0][1][p][f] == res[1][1][p][f]).all()
+                assert (res[1][1][p][f] == O.lr_plane(cdef[p][f], cdef[p][f], bd, int(p > 0), unit, uc if p else uy)).all()
