@@ -455,14 +455,16 @@ __global__ __launch_bounds__(256) void k_inter_pipe(InterLaunch L) {
   constexpr int bd = sizeof(Pix) == 1 ? 8 : 10;
   constexpr int GPW = 32;                        // groups (blocks) per workgroup
   constexpr int YW = 16, YWS = 20;               // luma window 16 x 16 (integer vector -4 .. +11); rows are whole dwords
-  constexpr int CW = 12, CWS = 16;               // chroma window 12 x 12 (chroma integer position -4 .. +7); rows are whole dwords
+  constexpr int CW = 12, CWS = 16;               // chroma window columns: chroma integer position -4 .. +7; rows are whole dwords
+  constexpr int CWR0 = 3, CWR = 7;               // ... of which the 4-tap family reads rows 3 .. 9 only: those are stored
   // ONE LDS region per group, reused by the phases of a block (each ends with a group sync before the next one writes):
   //   luma search     window (YW x YWS samples) | intermediate (16 x 8 int16)
   //   luma residual   transpose buffer (8 x 12 int32) over the dead window / intermediate
-  //   chroma          two windows (CW x CWS samples) | intermediates (2 x (11 x 4 + 4) int16); then the two transpose buffers
+  //   chroma          two windows (CWR x CWS samples) | intermediates (2 x (11 x 4 + 4) int16); then the two transpose buffers
   //                   (2 x 32 int32) over the dead windows
-  // Separate arrays cost 66 KB per workgroup at 10 bits = 2 waves per SIMD; the shared region is 33 KB = the 4 waves the VGPRs allow.
-  constexpr int YWIN_BYTES = YW * YWS * (int)sizeof(ES), CWIN_BYTES = 2 * CW * CWS * (int)sizeof(ES);
+  // Separate arrays cost 66 KB per workgroup at 10 bits = 2 waves per SIMD; the shared region is 29 KB (912 bytes per block: the luma
+  // phase sets it since the chroma windows hold 7 rows instead of 12) = the 5 waves per SIMD the VGPRs allow.
+  constexpr int YWIN_BYTES = YW * YWS * (int)sizeof(ES), CWIN_BYTES = 2 * CWR * CWS * (int)sizeof(ES);
   constexpr int IMY_BYTES = 16 * 8 * 2, IMC_BYTES = 2 * (11 * 4 + 4) * 2, TY_BYTES = 8 * 12 * 4, TC_BYTES = 2 * 32 * 4;
   constexpr int REG_RAW = cmax3(YWIN_BYTES + IMY_BYTES, CWIN_BYTES + IMC_BYTES, TY_BYTES > TC_BYTES ? TY_BYTES : TC_BYTES);
   // per-group stride = 16 bytes past a multiple of 128: the groups of a wave run in lockstep at equal offsets and so start 4 banks apart
@@ -650,7 +652,7 @@ __global__ __launch_bounds__(256) void k_inter_pipe(InterLaunch L) {
     Pix *rec_c = reinterpret_cast<Pix *>(L.rec[1 + pl]) + (size_t)f * chh * L.stride_uv;
     // the vector in 1/16 chroma samples is the luma vector in 1/8 luma samples
     const int cix = mvx >> 4, ciy = mvy >> 4;         // integer chroma displacement (floor)
-    ES *wc = wy + pl * CW * CWS;
+    ES *wc = wy + pl * CWR * CWS - CWR0 * CWS;       // row r of the window at wc + r * CWS, rows CWR0 .. CWR0 + CWR - 1 exist
     int16_t *imc = reinterpret_cast<int16_t *>(reg + CWIN_BYTES) + pl * (11 * 4 + 4);
     AV1MI_GROUP_SYNC();                               // the luma transpose buffer has been read: the region is free
     // the 4-tap family reads window rows 3 .. 9 only (mc_row<4, ES, 2, 6>: taps 2 .. 5 of rows -1 .. +5 around the block)
