@@ -110,7 +110,7 @@ __device__ __forceinline__ void cdef_quad_packed(const uint16_t *p, const int32_
 }
 
 template <typename Pix>
-__global__ __launch_bounds__(256) void k_cdef(CdefLaunch L) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_cdef(CdefLaunch L) {
   constexpr int YS = 64 + 4 + 2, CSZ = 32 + 4 + 2;   // LDS row strides (halo 2 each side, +2 pad)
   __shared__ __attribute__((aligned(16))) uint16_t ty[(64 + 4) * YS + 8];
   __shared__ __attribute__((aligned(16))) uint16_t tc[2][(32 + 4) * CSZ + 8];

@@ -450,7 +450,7 @@ __device__ __forceinline__ void mc_v7(const uint32_t (*pr)[8], int posy, const i
 __host__ __device__ constexpr int cmax3(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
 
 template <typename Pix>
-__global__ __launch_bounds__(256) void k_inter_pipe(InterLaunch L) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_inter_pipe(InterLaunch L) {
   using ES = Pix;
   constexpr int bd = sizeof(Pix) == 1 ? 8 : 10;
   constexpr int GPW = 32;                        // groups (blocks) per workgroup
