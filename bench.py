@@ -310,7 +310,7 @@ def e2e_leg(ctx, W, H, bd, qindex, first_frame, segs=4, gop=30, steps=2, warmup_
         fr = sess.collect()
         t1 = time.perf_counter()
         for sg in range(segs):
-            if gpu_entropy:      # the tiles were coded on the GPU: the host only wraps them (frame header, tile-size fields)
+            if gpu_entropy and "tile_size" in fr:      # the tiles were coded on the GPU: the host only wraps them (frame header, tile-size fields)
                 tu = av1stream.session_frame_unit_gpu(W, H, bd, fr, sg)
             else:
                 tu = av1stream.session_frame_unit(W, H, bd, fr, sg, threads=threads)
@@ -342,7 +342,7 @@ def e2e_leg(ctx, W, H, bd, qindex, first_frame, segs=4, gop=30, steps=2, warmup_
     ctx.sync()
     dt = time.perf_counter() - t0
     frames = coded["frames"]
-    out = {"frames_per_s": frames / dt, "frames": frames, "seconds": dt, "segments_in_lockstep": segs, "gop": gop, "host_threads": threads,
+    out = {"entropy_fallbacks": int(sess.entropy_fallbacks()) if gpu_entropy else None, "frames_per_s": frames / dt, "frames": frames, "seconds": dt, "segments_in_lockstep": segs, "gop": gop, "host_threads": threads,
            "bytes_per_frame": coded["bytes"] / frames, "mbit_per_s_at_30fps": coded["bytes"] / frames * 8 * 30 / 1e6,
            "host_seconds": {"fill_pinned_input": coded["t_fill"], "wait_for_gpu": coded["t_wait"],
                             "assemble_obu" if gpu_entropy else "entropy_code": coded["t_code"]},
