@@ -92,6 +92,55 @@ def temporal_unit(width, height, bit_depth, base_q_idx, frame_type=0, with_seque
     return out[:n].tobytes()
 
 
+BLOCK_DTYPE = np.dtype([("mi_row", "<u2"), ("mi_col", "<u2"), ("bsize", "u1"), ("skip", "u1"), ("is_inter", "u1"), ("y_mode", "u1"), ("uv_mode", "u1"),
+                        ("angle_y", "i1"), ("angle_uv", "i1"), ("cfl_alpha_u", "i1"), ("cfl_alpha_v", "i1"), ("tx_depth", "u1"), ("interp_filter", "u1"),
+                        ("reserved", "u1"), ("mv_x", "<i2"), ("mv_y", "<i2"), ("tx_type_off", "<u4"), ("lev_off", "<u4", (3,))])
+assert BLOCK_DTYPE.itemsize == 36      # struct av1mi_obu_block (include/av1mi_host.h)
+
+
+class ObuBlocks(C.Structure):
+    _fields_ = [("hdr", ObuFrame), ("tx_mode_select", C.c_int32), ("interp_filter", C.c_int32), ("high_precision_mv", C.c_int32), ("partition", C.c_void_p), ("n_partition", C.c_size_t),
+                ("blocks", C.c_void_p), ("n_blocks", C.c_size_t), ("tx_type", C.c_void_p), ("levels", C.c_void_p)]
+
+
+def blocks_temporal_unit(width, height, bit_depth, base_q_idx, partition, blocks, tx_type, levels, frame_type=0, with_sequence_header=True,
+                         tx_mode_select=0, interp_filter=0, high_precision_mv=0, reduced_tx_set=0, disable_cdf_update=0, tile_cols_log2=-1,
+                         tile_rows_log2=-1, lf_level=(0, 0, 0, 0), lf_sharpness=0, cdef_damping=3, cdef_bits=0, cdef_y=(0,), cdef_uv=(0,), cdef_idx=None):
+    """the general block-structured writer (av1mi_obu_write_blocks_temporal_unit): partition = uint8 partition types in decoding order,
+    blocks = array of BLOCK_DTYPE in decoding order, tx_type = uint8 per luma transform block, levels = int16 (see include/av1mi_host.h)"""
+    d = ObuBlocks()
+    f = d.hdr
+    f.width, f.height, f.bit_depth, f.frame_type, f.base_q_idx = width, height, bit_depth, frame_type, base_q_idx
+    for i in range(4):
+        f.lf_level[i] = int(lf_level[i])
+    f.lf_sharpness, f.cdef_damping, f.cdef_bits = lf_sharpness, cdef_damping, cdef_bits
+    for i, v in enumerate(cdef_y):
+        f.cdef_y[i] = int(v)
+    for i, v in enumerate(cdef_uv):
+        f.cdef_uv[i] = int(v)
+    f.reduced_tx_set, f.disable_cdf_update, f.tile_cols_log2, f.tile_rows_log2 = reduced_tx_set, disable_cdf_update, tile_cols_log2, tile_rows_log2
+    keep = [np.ascontiguousarray(partition, np.uint8), np.ascontiguousarray(blocks, BLOCK_DTYPE), np.ascontiguousarray(tx_type, np.uint8),
+            np.ascontiguousarray(levels, np.int16)]
+    if cdef_idx is not None:
+        keep.append(np.ascontiguousarray(cdef_idx, np.uint8))
+        f.cdef_idx = keep[-1].ctypes.data
+    d.tx_mode_select, d.interp_filter, d.high_precision_mv = int(tx_mode_select), int(interp_filter), int(high_precision_mv)
+    d.partition, d.n_partition, d.blocks, d.n_blocks = keep[0].ctypes.data, keep[0].size, keep[1].ctypes.data, keep[1].size
+    d.tx_type, d.levels = keep[2].ctypes.data, keep[3].ctypes.data
+    cap = width * height * 4 + (1 << 16)
+    out = np.empty(cap, np.uint8)
+    err = C.create_string_buffer(256)
+    L = lib()
+    L.av1mi_obu_write_blocks_temporal_unit.restype = C.c_longlong
+    L.av1mi_obu_write_blocks_temporal_unit.argtypes = [C.POINTER(ObuBlocks), C.c_int, C.c_void_p, C.c_longlong, C.c_char_p, C.c_int]
+    n = L.av1mi_obu_write_blocks_temporal_unit(C.byref(d), int(with_sequence_header), out.ctypes.data, cap, err, 256)
+    if n < 0:
+        raise ValueError("av1 block writer: " + err.value.decode())
+    if n > cap:
+        raise RuntimeError("temporal unit of %d bytes exceeds the buffer" % n)
+    return out[:n].tobytes()
+
+
 def assemble_temporal_unit(width, height, bit_depth, base_q_idx, payloads, sizes, with_sequence_header=True, **hdr):
     """temporal unit around tile payloads coded on the GPU (av1mi_obu_assemble_temporal_unit); hdr = header_from_params(...)"""
     f = ObuFrame()

@@ -55,6 +55,8 @@ bool frame_obu_from_tiles(const av1mi_obu_frame &f, const uint8_t *payloads, con
 std::vector<uint8_t> range_code_raw(const uint32_t *fl, const uint32_t *fh, const uint8_t *sym, const uint8_t *nsym, size_t count);
 bool opstream_supported(const av1mi_obu_frame &f, std::string *why);
 bool opstream_tiles(const av1mi_obu_frame &f, std::vector<std::vector<uint8_t>> *tiles, std::string *err);
+// the general block-structured writer (av1_blockstream.cpp, include/av1mi_host.h av1mi_obu_blocks): one temporal unit
+bool blocks_temporal_unit(const av1mi_obu_blocks &d, bool with_sequence_header, std::vector<uint8_t> *out, std::string *err);
 // one temporal unit: delimiter [+ sequence header] + frame
 bool temporal_unit(const av1mi_obu_frame &f, bool with_sequence_header, int threads, std::vector<uint8_t> *out, std::string *err);
 

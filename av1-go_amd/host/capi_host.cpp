@@ -102,6 +102,16 @@ long long av1mi_obu_write_temporal_unit(const av1mi_obu_frame *f, int with_seque
   if ((long long)b.size() <= cap && out) memcpy(out, b.data(), b.size());
   return (long long)b.size();
 }
+// The general block description (av1_blockstream.cpp): any block / transform size, any partition
+long long av1mi_obu_write_blocks_temporal_unit(const av1mi_obu_blocks *f, int with_sequence_header, uint8_t *out, long long cap, char *err, int errcap) {
+  std::vector<uint8_t> b; std::string e;
+  if (!f || !av1::blocks_temporal_unit(*f, with_sequence_header != 0, &b, &e)) {
+    if (err && errcap > 0) { strncpy(err, f ? e.c_str() : "null description", errcap - 1); err[errcap - 1] = 0; }
+    return -1;
+  }
+  if ((long long)b.size() <= cap && out) memcpy(out, b.data(), b.size());
+  return (long long)b.size();
+}
 // One temporal unit from tile payloads coded by the GPU tile entropy coder (include/av1mi.h av1mi_av1_entropy_encode / the GOP
 // session with gpu_entropy): `f` needs only its header fields (geometry, quantiser, filter parameters); payloads = the frame's
 // ntiles finished tile payloads back to back in raster order, sizes[t] bytes each.  Same return convention as

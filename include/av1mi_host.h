@@ -72,6 +72,53 @@ long long av1mi_obu_write_temporal_unit(const av1mi_obu_frame *f, int with_seque
 long long av1mi_obu_assemble_temporal_unit(const av1mi_obu_frame *f, const uint8_t *payloads, const uint32_t *sizes, int ntiles,
                                            int with_sequence_header, uint8_t *out, long long cap, char *err, int errcap);
 
+/* ---- general block structure: every AV1 block size 4x4 .. 64x64 (incl. the 1:2 / 2:1 / 1:4 / 4:1 shapes), every partition type,
+ * every transform size (TX_MODE_LARGEST or TX_MODE_SELECT) and all 16 transform types, the four interpolation filters.  It is
+ * what the encoder behind transcode.go:120 (`-c:v:0 av1_vaapi`) may emit and what north_star's "4x4-64x64" names; the 8x8
+ * description above is the subset the GPU block pipeline produces today.  Symbols are ARBITRARY (tests hand the writer random
+ * ones and compare dav1d's decode with the oracle primitives, tests/test_av1_blocks.py).
+ * Inter blocks: single reference LAST, coded as NEWMV against an EMPTY prediction list — the writer refuses an inter block that
+ * has another inter block of the same tile within the reach of the MV prediction scan (5 units of 4 samples above / to the
+ * left, one to the right); av1_bitstream.cpp has the full list for 8x8 blocks. */
+typedef struct av1mi_obu_block {
+  uint16_t mi_row, mi_col;     /* position in units of 4 luma samples */
+  uint8_t bsize;               /* AV1 BLOCK_* order: 4X4 4X8 8X4 8X8 8X16 16X8 16X16 16X32 32X16 32X32 32X64 64X32 64X64 (12), then
+                                  4X16 = 16, 16X4, 8X32, 32X8, 16X64, 64X16 = 21 */
+  uint8_t skip;                /* no residual */
+  uint8_t is_inter;            /* inter frames only */
+  uint8_t y_mode, uv_mode;     /* intra blocks: 0 DC .. 12 PAETH; uv_mode 13 = chroma from luma (blocks up to 32x32) */
+  int8_t angle_y, angle_uv;    /* -3..3, directional modes of blocks >= 8x8 (BLOCK_* order: also 4x16 / 16x4) */
+  int8_t cfl_alpha_u, cfl_alpha_v;
+  uint8_t tx_depth;            /* TX_MODE_SELECT: 0..2 halvings of the block's largest transform (intra: tx_depth, inter: txfm_split
+                                  down to that depth everywhere); TX_MODE_LARGEST: must be 0 */
+  uint8_t interp_filter;       /* inter blocks when the frame's filter is switchable: 0 regular, 1 smooth, 2 sharp */
+  uint8_t reserved;
+  int16_t mv_x, mv_y;          /* inter blocks: 1/8 luma samples, multiples of 2 */
+  uint32_t tx_type_off;        /* first entry of the block in tx_type[]: one byte per LUMA transform block, coding order */
+  uint32_t lev_off[3];         /* first level of the block's Y / U / V transform blocks in levels[]: the plane's transform blocks back
+                                  to back in coding order, each min(h, 32) rows x min(w, 32) columns, row-major (row = vertical
+                                  frequency).  Transform blocks that start outside the frame are not stored (nor coded). */
+} av1mi_obu_block;
+
+typedef struct av1mi_obu_blocks {
+  av1mi_obu_frame hdr;         /* geometry, quantiser, filter parameters, tiles; its per-8x8 symbol pointers are not read */
+  int32_t tx_mode_select;      /* 0 TX_MODE_LARGEST, 1 TX_MODE_SELECT */
+  int32_t interp_filter;       /* inter frames: 0 regular, 1 smooth, 2 sharp, 3 bilinear for every block; 4 = switchable per block */
+  int32_t high_precision_mv;   /* inter frames: allow_high_precision_mv (vectors in 1/8 luma samples: odd values allowed) */
+  const uint8_t *partition;    /* one partition type (0 NONE, 1 HORZ, 2 VERT, 3 SPLIT, 4 HORZ_A, 5 HORZ_B, 6 VERT_A, 7 VERT_B, 8 HORZ_4,
+                                  9 VERT_4) per decode_partition() call that starts inside the frame with a block of 8x8 or more, in
+                                  decoding order (tiles in raster order, superblocks in raster order inside a tile) */
+  size_t n_partition;
+  const av1mi_obu_block *blocks;  /* in decoding order */
+  size_t n_blocks;
+  const uint8_t *tx_type;      /* enum av1mi_tx_type order (DCT_DCT 0 .. H_FLIPADST 15) */
+  const int16_t *levels;
+} av1mi_obu_blocks;
+
+/* One temporal unit for a general block description; same return convention as av1mi_obu_write_temporal_unit. */
+long long av1mi_obu_write_blocks_temporal_unit(const av1mi_obu_blocks *f, int with_sequence_header, uint8_t *out, long long cap,
+                                               char *err, int errcap);
+
 /* The drop-in for RunTranscode (transcode.go:194-315): argv as TranscodeArgs (transcode.go:17) builds it — the backend reads
  * "-i <input.y4m>", "-global_quality:v:0 <q>" and the output path (last argument), plus its own "-g", "-av1mi_device",
  * "-av1mi_segments", "-av1mi_gpu_entropy", "-threads"; everything else is accepted and ignored.  Returns 0 and leaves the output file in place on
