@@ -22,7 +22,7 @@ def test_host_library_exports_every_declared_symbol():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(root, "include", "av1mi_host.h")).read(), flags=re.S)
     names = sorted(set(re.findall(r"\b(av1mi_[a-z0-9_]+)\s*\(", hdr)))
-    assert names == ["av1mi_obu_assemble_temporal_unit", "av1mi_obu_write_temporal_unit", "av1mi_run_transcode"]
+    assert names == ["av1mi_obu_assemble_temporal_unit", "av1mi_obu_write_blocks_temporal_unit", "av1mi_obu_write_temporal_unit", "av1mi_run_transcode"]
     lib = av1stream.lib()
     for n in names:
         assert hasattr(lib, n), "libav1mi_host.so does not export %s" % n
@@ -31,9 +31,11 @@ def test_host_library_exports_every_declared_symbol():
     import tempfile
     with tempfile.TemporaryDirectory() as d:
         src = os.path.join(d, "sz.c")
-        open(src, "w").write('#include "av1mi_host.h"\n#include <stdio.h>\nint main(void){printf("%zu", sizeof(av1mi_obu_frame));return 0;}\n')
+        open(src, "w").write('#include "av1mi_host.h"\n#include <stdio.h>\nint main(void){printf("%zu %zu %zu", sizeof(av1mi_obu_frame), '
+                             'sizeof(av1mi_obu_block), sizeof(av1mi_obu_blocks));return 0;}\n')
         subprocess.check_call(["gcc", "-I", os.path.join(root, "include"), src, "-o", os.path.join(d, "sz")])
-        assert int(subprocess.check_output([os.path.join(d, "sz")])) == C.sizeof(av1stream.ObuFrame)
+        sizes = [int(x) for x in subprocess.check_output([os.path.join(d, "sz")]).split()]
+        assert sizes == [C.sizeof(av1stream.ObuFrame), av1stream.BLOCK_DTYPE.itemsize, C.sizeof(av1stream.ObuBlocks)]
 
 
 def test_policy_is_exported_and_frame_type_dependent(av1mi):
