@@ -73,13 +73,6 @@ class InterJob(C.Structure):
                 ("d_ref_alt_y", C.c_void_p), ("d_ref_alt_u", C.c_void_p), ("d_ref_alt_v", C.c_void_p), ("d_ref_sel", C.c_void_p)]
 
 
-class EntropyJob(C.Structure):
-    _fields_ = [("width", C.c_int), ("height", C.c_int), ("nframes", C.c_int), ("key", C.c_int), ("tile", C.c_int),
-                ("d_lev_y", C.c_void_p), ("d_lev_u", C.c_void_p), ("d_lev_v", C.c_void_p),
-                ("d_modes_y", C.c_void_p), ("d_modes_uv", C.c_void_p), ("d_mvs", C.c_void_p), ("d_skip", C.c_void_p),
-                ("d_out", C.c_void_p), ("out_cap", C.c_size_t), ("d_frame_off", C.c_void_p)]
-
-
 class LrDecideJob(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("bit_depth", C.c_int), ("nframes", C.c_int), ("unit_size", C.c_int),
                 ("stride_y", C.c_int), ("stride_uv", C.c_int),
@@ -151,6 +144,11 @@ class GopSession:
     def submit(self, frame_type=-1):
         self.ctx._chk(self.ctx.lib.av1mi_gop_submit(self.g, int(frame_type)))
 
+    def submit_device(self, d_y, d_u, d_v, frame_type=-1):
+        """a batch whose source planes (DevBuf) are already in device memory: no upload (av1mi_gop_submit_device)"""
+        self.ctx.lib.av1mi_gop_submit_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        self.ctx._chk(self.ctx.lib.av1mi_gop_submit_device(self.g, d_y.ptr, d_u.ptr, d_v.ptr, int(frame_type)))
+
     def pending(self):
         return self.ctx.lib.av1mi_gop_pending(self.g)
 
@@ -197,7 +195,7 @@ class GopSession:
             self.g = None
 
 
-N_KERNEL_KINDS = 16   # enum av1mi_kernel_kind
+N_KERNEL_KINDS = 17   # enum av1mi_kernel_kind
 _lib = None
 
 
@@ -484,43 +482,6 @@ class Context:
         for b in bufs.values():
             b.free()
         return out
-
-    # ---- K9
-    def entropy_encode(self, job):
-        self._chk(self.lib.av1mi_entropy_encode(self.h, C.byref(job)))
-
-    def entropy_encode_async(self, job, slot):
-        self._chk(self.lib.av1mi_entropy_encode_async(self.h, C.byref(job), slot))
-
-    def entropy_wait(self, slot):
-        self._chk(self.lib.av1mi_entropy_wait(self.h, slot))
-
-    def entropy_encode_arrays(self, w, h, key, tile, lev_y, lev_u, lev_v, modes_y=None, modes_uv=None, mvs=None, skip=None, out_cap=None):
-        """tests: arrays with a leading frame axis; returns the list of frame records (bytes)"""
-        arrs = dict(lev_y=(lev_y, np.int16), lev_u=(lev_u, np.int16), lev_v=(lev_v, np.int16), modes_y=(modes_y, np.uint8),
-                    modes_uv=(modes_uv, np.uint8), mvs=(mvs, np.int16), skip=(skip, np.uint8))
-        nf = np.asarray(lev_y).shape[0]
-        job = EntropyJob(w, h, nf, key, tile)
-        bufs = []
-        for k, (a, dt) in arrs.items():
-            if a is not None:
-                bufs.append(self.to_device(np.ascontiguousarray(a, dt)))
-                setattr(job, "d_" + k, bufs[-1].ptr)
-        cap = out_cap if out_cap is not None else nf * (w * h * 9 + 65536)
-        d_out, d_off = self.alloc(max(cap, 16)), self.alloc((nf + 1) * 8)
-        job.d_out, job.out_cap, job.d_frame_off = d_out.ptr, cap, d_off.ptr
-        self.entropy_encode(job)
-        off = d_off.download((nf + 1,), np.uint64)
-        total = int(off[-1])
-        recs = None
-        if total <= cap:
-            data = d_out.download((max(total, 1),), np.uint8)[:total].tobytes()
-            recs = [data[int(off[i]):int(off[i + 1])] for i in range(nf)]
-        for b in bufs + [d_out, d_off]:
-            b.free()
-        if recs is None:
-            raise Av1miError(-1, "entropy_encode: out_cap %d < %d needed" % (cap, total))
-        return recs
 
     # ---- host-pointer single-block forms
     def inv_txfm2d_add(self, coef, pred, tx_size, tx_type, bd):

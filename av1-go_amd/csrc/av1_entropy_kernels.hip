@@ -345,19 +345,27 @@ __global__ __launch_bounds__(64) void k_av1_gather(Av1EntLaunch L) {
   if (tail0 + threadIdx.x < n) dst[tail0 + threadIdx.x] = src[tail0 + threadIdx.x];
 }
 
-hipError_t launch_av1_front(const Av1EntLaunch &L, hipStream_t s) {
+hipError_t launch_av1_front(av1mi_ctx *ctx, const Av1EntLaunch &L, hipStream_t s) {
   const long nb = (long)L.fv.w8 * L.fv.h8 * L.nframes;
   const int ntiles_all = L.sbr_n * L.sbc_n * L.nframes, ngroups = (ntiles_all + 63) / 64;
+  ProfToken t = ctx_prof_begin(ctx, AV1MI_K_ENTROPY_TOKENS, s);
   hipLaunchKernelGGL(k_av1_info, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, L);
   hipLaunchKernelGGL(k_av1_tokens, dim3((unsigned)ntiles_all), dim3(64), 0, s, L);
+  ctx_prof_end(ctx, t, s);
+  t = ctx_prof_begin(ctx, AV1MI_K_ENTROPY_CHAINS, s);
   hipLaunchKernelGGL(k_av1_chains, dim3((unsigned)(((ngroups + 7) / 8) * 8 * (L.fv.key ? S_KEY_END : S_INTER_END))), dim3(64), 0, s, L, ntiles_all, ngroups);
+  ctx_prof_end(ctx, t, s);
   return hipGetLastError();
 }
-hipError_t launch_av1_back(const Av1EntLaunch &L, hipStream_t s) {
+hipError_t launch_av1_back(av1mi_ctx *ctx, const Av1EntLaunch &L, hipStream_t s) {
   const int ntiles_all = L.sbr_n * L.sbc_n * L.nframes;
+  ProfToken t = ctx_prof_begin(ctx, AV1MI_K_ENTROPY, s);
   hipLaunchKernelGGL(k_av1_code, dim3((unsigned)((ntiles_all + 63) / 64)), dim3(64), 0, s, L, ntiles_all);
+  ctx_prof_end(ctx, t, s);
+  t = ctx_prof_begin(ctx, AV1MI_K_ENTROPY_PACK, s);
   hipLaunchKernelGGL(k_av1_scan, dim3(1), dim3(1024), 0, s, L, ntiles_all);
   hipLaunchKernelGGL(k_av1_gather, dim3((unsigned)ntiles_all), dim3(64), 0, s, L);
+  ctx_prof_end(ctx, t, s);
   return hipGetLastError();
 }
 
@@ -371,6 +379,7 @@ struct av1mi_av1ent_state {      // per-context scratch of the coder, grown on d
   hipEvent_t lists_ready[2] = { nullptr, nullptr }, lists_free[2] = { nullptr, nullptr };
   bool free_recorded[2] = { false, false };
   unsigned long jobs = 0;
+  size_t last_tiles = 0;          // tiles of the most recent job (av1mi_av1_entropy_last_list_words)
   uint16_t *d_image[2][4] = {};   // [key][qcat] default CDF images
   int image_words[2] = { 0, 0 };
   av1ops::SlotTable tab[2];
@@ -433,6 +442,7 @@ int av1mi::av1_entropy_submit(av1mi_ctx *ctx, const av1mi_av1_entropy_job *j, hi
   L.ops_cap = av1mi_av1_entropy_ops_per_tile(); L.slot_cap = av1mi_av1_entropy_slot_bytes();
   L.grouped_cap = L.ops_cap + av1ops::kListAlign * av1ops::S_MAX;      // every slot's entries start on 16 bytes
   const int par = (int)(st->jobs++ & 1);
+  st->last_tiles = nt;
   int rc;
   if ((rc = grow(ctx, &st->info, &st->info_b, nb * sizeof(av1ops::BlockInfo))) ||
       (rc = grow(ctx, &st->ops[par], &st->ops_b[par], nt * L.ops_cap * sizeof(av1ops::op_t))) || (rc = grow(ctx, &st->nops[par], &st->nops_b[par], nt * 4)) ||
@@ -455,9 +465,9 @@ int av1mi::av1_entropy_submit(av1mi_ctx *ctx, const av1mi_av1_entropy_job *j, hi
     if (st->free_recorded[par]) E_HIP(hipStreamWaitEvent(front, st->lists_free[par], 0));      // the coder of two jobs ago still reads this set of lists
   }
   E_HIP(hipMemsetAsync(j->d_total, 0, 16, front));
-  E_HIP(av1mi::launch_av1_front(L, front));
+  E_HIP(av1mi::launch_av1_front(ctx, L, front));
   if (two) { E_HIP(hipEventRecord(st->lists_ready[par], front)); E_HIP(hipStreamWaitEvent(back, st->lists_ready[par], 0)); }
-  E_HIP(av1mi::launch_av1_back(L, back));
+  E_HIP(av1mi::launch_av1_back(ctx, L, back));
   E_HIP(hipMemcpyAsync(j->d_total, L.tile_off + nt, 8, hipMemcpyDeviceToDevice, back));      // total bytes next to the status: tile_off[nt]
   if (two) { E_HIP(hipEventRecord(st->lists_free[par], back)); st->free_recorded[par] = true; }
 #undef E_HIP
@@ -473,6 +483,18 @@ int av1mi_av1_entropy_encode_on(av1mi_ctx *ctx, const av1mi_av1_entropy_job *j, 
 }
 
 int av1mi_av1_entropy_encode(av1mi_ctx *ctx, const av1mi_av1_entropy_job *j) { return av1mi_av1_entropy_encode_on(ctx, j, nullptr); }
+
+int av1mi_av1_entropy_last_list_words(av1mi_ctx *ctx, uint64_t *words) {
+  if (!ctx || !words) return AV1MI_E_INVAL;
+  *words = 0;
+  av1mi_av1ent_state *st = av1mi::ctx_av1ent(ctx);
+  if (!st || !st->jobs || !st->last_tiles) return AV1MI_OK;
+  if (hipSetDevice(av1mi::ctx_device(ctx)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return av1mi::ctx_fail(ctx, AV1MI_E_DEVICE, "synchronising failed");
+  std::vector<uint32_t> n(st->last_tiles);
+  if (hipMemcpy(n.data(), st->nops[(st->jobs - 1) & 1], n.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return av1mi::ctx_fail(ctx, AV1MI_E_DEVICE, "reading the list sizes failed");
+  for (uint32_t v : n) *words += v;
+  return AV1MI_OK;
+}
 
 }  // extern "C"
 

@@ -130,24 +130,6 @@ hipError_t launch_quantize(const int32_t *coef, int16_t *levels, int32_t *dqcoef
 hipError_t launch_dequantize(const int16_t *levels, int32_t *dqcoef, long long n, int coef_per_blk, int dc_q,
                              int ac_q, int log_scale, int bd, hipStream_t s);
 
-// K9: tile entropy coder (entropy_kernels.hip)
-struct EntropyLaunch {
-  const int16_t *lev[3]; const uint8_t *modes_y, *modes_uv; const int16_t *mvs; const uint8_t *skip;
-  int w, h, nframes, key, tile;
-  uint16_t *ops; uint32_t ops_per_tile;       // scratch: one op list per tile (k_ent_tokens -> k_ent_code)
-  uint32_t *nops;                             // scratch: ops per tile
-  uint8_t *slots; uint32_t slot_bytes;        // scratch: one payload slot per tile
-  uint32_t *sizes, *hdr_off, *pay_off;        // scratch: per tile
-  uint32_t *frame_hdr; uint64_t *frame_size;  // scratch: per frame
-  uint32_t *status;                           // scratch: bit 0 = out_cap too small, bit 1 = a slot ran over
-  uint8_t *out; uint64_t out_cap; uint64_t *frame_off;
-};
-hipError_t entropy_init_tables();
-size_t entropy_ops_per_tile(int tile);
-hipError_t launch_entropy_tokens(const EntropyLaunch &L, hipStream_t s);
-hipError_t launch_entropy_code(const EntropyLaunch &L, hipStream_t s);
-hipError_t launch_entropy_pack(const EntropyLaunch &L, hipStream_t s);
-
 // the AV1 tile entropy coder's per-context scratch (av1_entropy_kernels.hip); created on first use, freed by av1mi_close
 struct av1mi_av1ent_state_fwd;
 }  // namespace av1mi
@@ -166,5 +148,10 @@ int av1_entropy_submit(av1mi_ctx *ctx, const struct av1mi_av1_entropy_job *j, hi
 hipStream_t ctx_stream(av1mi_ctx *ctx);
 int ctx_device(av1mi_ctx *ctx);
 int ctx_fail(av1mi_ctx *ctx, int code, const char *fmt, ...);
+// the per-kernel profile (av1mi_prof_*) for launches made outside capi.hip, on any stream of the context: an event pair around the
+// launch(es) while profiling is enabled, nothing otherwise
+struct ProfToken { hipEvent_t e0 = nullptr; int kind = 0; };
+ProfToken ctx_prof_begin(av1mi_ctx *ctx, int kind, hipStream_t st);
+void ctx_prof_end(av1mi_ctx *ctx, const ProfToken &t, hipStream_t st);
 
 }  // namespace av1mi

@@ -12,17 +12,13 @@
 struct av1mi_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
-  hipStream_t side = nullptr;             // K9 asynchronous form: the coder overlaps the main stream's next launches
+  hipStream_t side = nullptr;             // AV1 coder of a GOP session: tokenizer + chains beside the main stream's next launches
   hipStream_t back = nullptr;             // AV1 coder of a GOP session: the serial range coder, beside the next batch's tokenizer on `side`
-  hipEvent_t fork = nullptr;              // main -> side dependency
-  hipEvent_t slot_done[8] = { nullptr };  // side -> main: the coder of slot i has finished
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   char err[801] = { 0 };  // transcode.go:295-297 caps the reason text at 800 chars
   char name[256] = { 0 };
   void *scratch = nullptr;  // staging for the host-pointer single-block forms
   size_t scratch_bytes = 0;
-  void *ent_scratch = nullptr;  // K9: tile slots + layout arrays
-  size_t ent_bytes = 0;
   av1mi_av1ent_state *av1ent = nullptr;   // the AV1-syntax tile coder's scratch (av1_entropy_kernels.hip)
   // per-kernel profile: one event pair per launch while enabled
   bool prof_on = false;
@@ -76,6 +72,7 @@ void prof_drain(av1mi_ctx *ctx) {
   if (ctx->prof_recs.empty()) return;
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->side) (void)hipStreamSynchronize(ctx->side);
+  if (ctx->back) (void)hipStreamSynchronize(ctx->back);
   for (auto &r : ctx->prof_recs) {
     float ms = 0;
     if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) { ctx->prof_calls[r.kind]++; ctx->prof_ms[r.kind] += ms; }
@@ -135,6 +132,18 @@ hipStream_t ctx_back_stream(av1mi_ctx *ctx) {
   }
   return ctx->back;
 }
+ProfToken ctx_prof_begin(av1mi_ctx *ctx, int kind, hipStream_t st) {
+  ProfToken t;
+  t.kind = kind;
+  if (ctx->prof_on) { t.e0 = prof_event(ctx); (void)hipEventRecord(t.e0, st); }
+  return t;
+}
+void ctx_prof_end(av1mi_ctx *ctx, const ProfToken &t, hipStream_t st) {
+  if (!t.e0) return;
+  hipEvent_t e1 = prof_event(ctx);
+  (void)hipEventRecord(e1, st);
+  ctx->prof_recs.push_back({ t.kind, t.e0, e1 });
+}
 int ctx_fail(av1mi_ctx *ctx, int code, const char *fmt, ...) {
   if (ctx) {
     va_list ap;
@@ -167,8 +176,7 @@ int av1mi_open(int device, av1mi_ctx **out) {
   hipDeviceProp_t prop;
   if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess ||
       hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
-      av1mi::entropy_init_tables() != hipSuccess) {
+      hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
     delete ctx;
     return AV1MI_E_NODEV;
   }
@@ -183,10 +191,7 @@ void av1mi_close(av1mi_ctx *ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); }
   if (ctx->back) { (void)hipStreamSynchronize(ctx->back); (void)hipStreamDestroy(ctx->back); }
-  if (ctx->fork) (void)hipEventDestroy(ctx->fork);
-  for (hipEvent_t ev : ctx->slot_done) if (ev) (void)hipEventDestroy(ev);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
-  if (ctx->ent_scratch) (void)hipFree(ctx->ent_scratch);
   if (ctx->av1ent) av1mi::av1ent_free(ctx->av1ent);
   for (auto &r : ctx->prof_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   for (auto e : ctx->prof_pool) (void)hipEventDestroy(e);
@@ -280,7 +285,7 @@ int av1mi_prof_get(av1mi_ctx *ctx, int kind, int *launches, double *total_ms) {
 }
 const char *av1mi_kernel_kind_name(int kind) {
   static const char *n[AV1MI_K_KINDS] = { "fwd_txfm", "inv_txfm", "quantize", "dequantize", "intra_pred", "mc", "deblock",
-                                          "cdef", "loop_restoration", "intra_pipeline", "inter_pipeline", "misc", "entropy_code", "entropy_pack", "entropy_tokens", "me_integer" };
+                                          "cdef", "loop_restoration", "intra_pipeline", "inter_pipeline", "misc", "entropy_code", "entropy_pack", "entropy_tokens", "me_integer", "entropy_chains" };
   return kind < 0 || kind >= AV1MI_K_KINDS ? "?" : n[kind];
 }
 
@@ -564,72 +569,6 @@ int av1mi_inter_encode(av1mi_ctx *ctx, const av1mi_inter_job *j) {
   return AV1MI_OK;
 }
 
-static int entropy_run(av1mi_ctx *ctx, const av1mi_entropy_job *j, hipStream_t st) {
-  if (!j) return fail(ctx, AV1MI_E_INVAL, "null job");
-  if (j->width <= 0 || j->height <= 0 || (j->width & 7) || (j->height & 7) || j->width > 16384 || j->height > 16384)
-    return fail(ctx, AV1MI_E_INVAL, "frame %dx%d must be a multiple of 8", j->width, j->height);
-  if (j->tile != 32 && j->tile != 64 && j->tile != 128) return fail(ctx, AV1MI_E_INVAL, "entropy tile %d not supported (32, 64, 128)", j->tile);
-  if (j->nframes < 0 || j->nframes > 65535) return fail(ctx, AV1MI_E_INVAL, "bad nframes");
-  const void *need[] = { j->d_lev_y, j->d_lev_u, j->d_lev_v, j->key ? (const void *)j->d_modes_y : (const void *)j->d_mvs,
-                         j->key ? (const void *)j->d_modes_uv : (const void *)j->d_skip, j->d_out, j->d_frame_off };
-  for (const void *p : need) if (!p) return fail(ctx, AV1MI_E_INVAL, "null device pointer");
-  if (((uintptr_t)j->d_lev_y | (uintptr_t)j->d_lev_u | (uintptr_t)j->d_lev_v) & 15) return fail(ctx, AV1MI_E_INVAL, "level planes must be 16-byte aligned");
-  if (((uintptr_t)j->d_frame_off & 7) || (!j->key && ((uintptr_t)j->d_mvs & 3))) return fail(ctx, AV1MI_E_INVAL, "misaligned device pointer");
-  if (j->nframes == 0) return AV1MI_OK;
-  const size_t tc = (size_t)(j->width + j->tile - 1) / j->tile, tr = (size_t)(j->height + j->tile - 1) / j->tile, tiles = tc * tr * j->nframes;
-  const size_t slot = (size_t)j->tile * j->tile * 9 + 64;   // 1.5 coefficients per luma sample, 6 bytes each
-  auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
-  const size_t opt = av1mi::entropy_ops_per_tile(j->tile);
-  const size_t o_ops = up(tiles * slot), o_nops = o_ops + up(tiles * opt * 2), o_sizes = o_nops + up(tiles * 4), o_hdr = o_sizes + up(tiles * 4), o_pay = o_hdr + up(tiles * 4), o_fh = o_pay + up(tiles * 4),
-               o_fs = o_fh + up((size_t)j->nframes * 4), o_st = o_fs + up((size_t)j->nframes * 8), total = o_st + 256;
-  if (ctx->ent_bytes < total) {
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->side) HIP_TRY(ctx, hipStreamSynchronize(ctx->side));
-    if (ctx->ent_scratch) (void)hipFree(ctx->ent_scratch);
-    ctx->ent_scratch = nullptr; ctx->ent_bytes = 0;
-    HIP_TRY(ctx, hipMalloc(&ctx->ent_scratch, total));
-    ctx->ent_bytes = total;
-  }
-  char *sc = (char *)ctx->ent_scratch;
-  av1mi::EntropyLaunch L;
-  L.lev[0] = j->d_lev_y; L.lev[1] = j->d_lev_u; L.lev[2] = j->d_lev_v;
-  L.modes_y = j->d_modes_y; L.modes_uv = j->d_modes_uv; L.mvs = j->d_mvs; L.skip = j->d_skip;
-  L.w = j->width; L.h = j->height; L.nframes = j->nframes; L.key = j->key != 0; L.tile = j->tile;
-  L.slots = (uint8_t *)sc; L.slot_bytes = (uint32_t)slot;
-  L.ops = (uint16_t *)(sc + o_ops); L.ops_per_tile = (uint32_t)opt; L.nops = (uint32_t *)(sc + o_nops);
-  L.sizes = (uint32_t *)(sc + o_sizes); L.hdr_off = (uint32_t *)(sc + o_hdr); L.pay_off = (uint32_t *)(sc + o_pay);
-  L.frame_hdr = (uint32_t *)(sc + o_fh); L.frame_size = (uint64_t *)(sc + o_fs); L.status = (uint32_t *)(sc + o_st);
-  L.out = j->d_out; L.out_cap = j->out_cap; L.frame_off = j->d_frame_off;
-  HIP_TRY(ctx, hipMemsetAsync(L.status, 0, 4, st));
-  { ProfScope ps(ctx, AV1MI_K_ENTROPY_TOKENS, st); HIP_TRY(ctx, av1mi::launch_entropy_tokens(L, st)); }
-  { ProfScope ps(ctx, AV1MI_K_ENTROPY, st); HIP_TRY(ctx, av1mi::launch_entropy_code(L, st)); }
-  { ProfScope ps(ctx, AV1MI_K_ENTROPY_PACK, st); HIP_TRY(ctx, av1mi::launch_entropy_pack(L, st)); }
-  return AV1MI_OK;
-}
-int av1mi_entropy_encode(av1mi_ctx *ctx, const av1mi_entropy_job *j) {
-  BIND(ctx);
-  if (ctx->side) HIP_TRY(ctx, hipStreamSynchronize(ctx->side));   // the scratch is shared with the asynchronous form
-  return entropy_run(ctx, j, ctx->stream);
-}
-int av1mi_entropy_encode_async(av1mi_ctx *ctx, const av1mi_entropy_job *j, int slot) {
-  BIND(ctx);
-  if (slot < 0 || slot >= 8) return fail(ctx, AV1MI_E_INVAL, "slot %d out of range (0..7)", slot);
-  // (the side stream may exist already — a GOP session of this context creates it for the AV1 coder — without these events)
-  if (!ctx->side) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
-  if (!ctx->fork) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->fork, hipEventDisableTiming));
-  for (hipEvent_t &ev : ctx->slot_done) if (!ev) HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-  HIP_TRY(ctx, hipEventRecord(ctx->fork, ctx->stream));            // everything queued so far produced the job's inputs
-  HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->fork, 0));
-  if (int rc = entropy_run(ctx, j, ctx->side)) return rc;
-  HIP_TRY(ctx, hipEventRecord(ctx->slot_done[slot], ctx->side));
-  return AV1MI_OK;
-}
-int av1mi_entropy_wait(av1mi_ctx *ctx, int slot) {
-  BIND(ctx);
-  if (slot < 0 || slot >= 8) return fail(ctx, AV1MI_E_INVAL, "slot %d out of range (0..7)", slot);
-  if (ctx->slot_done[slot]) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->slot_done[slot], 0));   // never created or never recorded = no wait
-  return AV1MI_OK;
-}
 
 int av1mi_dc_q(int qindex, int bd) {
   const int q = qindex < 0 ? 0 : qindex > 255 ? 255 : qindex;

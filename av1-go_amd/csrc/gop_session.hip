@@ -293,9 +293,9 @@ int av1mi_gop_acquire_input(av1mi_gop *g, void **y, void **u, void **v) {
   return AV1MI_OK;
 }
 
-int av1mi_gop_submit(av1mi_gop *g, int frame_type) {
-  if (!g) return AV1MI_E_INVAL;
-  if (!g->acquired) return av1mi::ctx_fail(g->ctx, AV1MI_E_INVAL, "submit without av1mi_gop_acquire_input");
+// one batch through the block pipeline, the filters and (gpu_entropy) the tile coder; dev_src: the source planes in device memory
+// (av1mi_gop_submit_device), or null = upload the slot's pinned planes first
+static int submit_batch(av1mi_gop *g, int frame_type, const void *const *dev_src) {
   if (g->submitted - g->collected >= kSlots) return av1mi::ctx_fail(g->ctx, AV1MI_E_INVAL, "%d batches in flight: collect first", (int)kSlots);
   if (frame_type < -1 || frame_type > 1) return av1mi::ctx_fail(g->ctx, AV1MI_E_INVAL, "frame_type %d", frame_type);
   if (frame_type < 0) frame_type = g->gop_pos == 0 ? 0 : 1;
@@ -305,19 +305,24 @@ int av1mi_gop_submit(av1mi_gop *g, int frame_type) {
   const int w = c.width, h = c.height, S = c.segments, bd = c.bit_depth;
   Slot &s = g->slot[g->submitted % kSlots];
   hipStream_t main = av1mi::ctx_stream(g->ctx);
-  // upload: not before the kernels that last read this slot's source have finished (the restoration decision is the last reader)
-  if (s.kernel_pending) G_HIP(hipStreamWaitEvent(g->up, s.filters_done, 0));
-  for (int p = 0; p < 3; p++) G_HIP(hipMemcpyAsync(s.d_src[p], s.h_src[p], (p ? g->nc : g->ny) * g->bps, hipMemcpyHostToDevice, g->up));
-  G_HIP(hipEventRecord(s.uploaded, g->up));
-  s.upload_pending = true;
-  G_HIP(hipStreamWaitEvent(main, s.uploaded, 0));
+  const void *src[3] = { s.d_src[0], s.d_src[1], s.d_src[2] };
+  if (dev_src) {
+    for (int p = 0; p < 3; p++) src[p] = dev_src[p];
+  } else {
+    // upload: not before the kernels that last read this slot's source have finished (the restoration decision is the last reader)
+    if (s.kernel_pending) G_HIP(hipStreamWaitEvent(g->up, s.filters_done, 0));
+    for (int p = 0; p < 3; p++) G_HIP(hipMemcpyAsync(s.d_src[p], s.h_src[p], (p ? g->nc : g->ny) * g->bps, hipMemcpyHostToDevice, g->up));
+    G_HIP(hipEventRecord(s.uploaded, g->up));
+    s.upload_pending = true;
+    G_HIP(hipStreamWaitEvent(main, s.uploaded, 0));
+  }
   if (s.ent_pending) G_HIP(hipStreamWaitEvent(main, s.ent_done, 0));      // the GPU coder of the slot's previous batch still reads its symbols
   // the block pipeline (the symbols of this slot were downloaded before the slot was collected, so they may be overwritten)
   if (frame_type == 0) {
     av1mi_intra_job j;
     memset(&j, 0, sizeof(j));
     j.width = w; j.height = h; j.bit_depth = bd; j.nframes = S; j.qindex = c.base_q_idx; j.block_size = 8; j.stride_y = w; j.stride_uv = w / 2;
-    j.d_src_y = s.d_src[0]; j.d_src_u = s.d_src[1]; j.d_src_v = s.d_src[2];
+    j.d_src_y = src[0]; j.d_src_u = src[1]; j.d_src_v = src[2];
     j.d_rec_y = g->d_rec[0]; j.d_rec_u = g->d_rec[1]; j.d_rec_v = g->d_rec[2];
     j.d_lev_y = (int16_t *)s.d_lev[0]; j.d_lev_u = (int16_t *)s.d_lev[1]; j.d_lev_v = (int16_t *)s.d_lev[2];
     j.d_modes_y = (uint8_t *)s.d_modes[0]; j.d_modes_uv = (uint8_t *)s.d_modes[1];
@@ -326,7 +331,7 @@ int av1mi_gop_submit(av1mi_gop *g, int frame_type) {
     av1mi_inter_job j;
     memset(&j, 0, sizeof(j));
     j.width = w; j.height = h; j.bit_depth = bd; j.nframes = S; j.qindex = c.base_q_idx; j.search_range = c.search_range; j.stride_y = w; j.stride_uv = w / 2;
-    j.d_src_y = s.d_src[0]; j.d_src_u = s.d_src[1]; j.d_src_v = s.d_src[2];
+    j.d_src_y = src[0]; j.d_src_u = src[1]; j.d_src_v = src[2];
     j.d_ref_y = g->d_ref[0]; j.d_ref_u = g->d_ref[1]; j.d_ref_v = g->d_ref[2];
     j.d_rec_y = g->d_rec[0]; j.d_rec_u = g->d_rec[1]; j.d_rec_v = g->d_rec[2];
     j.d_lev_y = (int16_t *)s.d_lev[0]; j.d_lev_u = (int16_t *)s.d_lev[1]; j.d_lev_v = (int16_t *)s.d_lev[2];
@@ -382,7 +387,7 @@ int av1mi_gop_submit(av1mi_gop *g, int frame_type) {
     lj.d_cdef_y = g->d_cdef[0]; lj.d_cdef_u = g->d_cdef[1]; lj.d_cdef_v = g->d_cdef[2];
     lj.d_dbl_y = g->d_dbl[0]; lj.d_dbl_u = g->d_dbl[1]; lj.d_dbl_v = g->d_dbl[2];
     lj.d_out_y = g->d_ref[0]; lj.d_out_u = g->d_ref[1]; lj.d_out_v = g->d_ref[2];
-    lj.d_orig_y = s.d_src[0]; lj.d_orig_u = s.d_src[1]; lj.d_orig_v = s.d_src[2];
+    lj.d_orig_y = src[0]; lj.d_orig_u = src[1]; lj.d_orig_v = src[2];
     lj.d_units_y = (const int8_t *)g->d_lr[0]; lj.d_units_uv = (const int8_t *)g->d_lr[1];
     lj.d_scratch = g->d_lr_scratch; lj.d_on = (uint8_t *)s.d_lr_on;
     lj.no_self_guided_units = P.lr_unit_y[0] != 2 && P.lr_unit_uv[0] != 2;
@@ -427,6 +432,19 @@ int av1mi_gop_submit(av1mi_gop *g, int frame_type) {
   g->gop_pos = frame_type == 0 ? 1 % c.gop_length : (g->gop_pos + 1) % c.gop_length;
   g->acquired = false;
   return AV1MI_OK;
+}
+
+int av1mi_gop_submit(av1mi_gop *g, int frame_type) {
+  if (!g) return AV1MI_E_INVAL;
+  if (!g->acquired) return av1mi::ctx_fail(g->ctx, AV1MI_E_INVAL, "submit without av1mi_gop_acquire_input");
+  return submit_batch(g, frame_type, nullptr);
+}
+
+int av1mi_gop_submit_device(av1mi_gop *g, const void *d_y, const void *d_u, const void *d_v, int frame_type) {
+  if (!g) return AV1MI_E_INVAL;
+  if (!d_y || !d_u || !d_v || (((uintptr_t)d_y | (uintptr_t)d_u | (uintptr_t)d_v) & 7)) return av1mi::ctx_fail(g->ctx, AV1MI_E_INVAL, "null or misaligned device source plane");
+  const void *src[3] = { d_y, d_u, d_v };
+  return submit_batch(g, frame_type, src);
 }
 
 int av1mi_gop_collect(av1mi_gop *g, av1mi_gop_frame *out) {

@@ -191,7 +191,7 @@ struct TileEnc {
       return;
     }
     const int is_inter = inter_of(b);
-    const int tx_type = f.tx_type ? f.tx_type[b] : T_DCT_DCT;
+    const int tx_type = f.tx_type ? f.tx_type[b] : (int)T_DCT_DCT;
     coeffs(0, x4, y4, 8, f.lev_y + (size_t)b * 64, is_inter, tx_type, f.y_mode ? f.y_mode[b] : 0);
     coeffs(1, cx4, cy4, 4, f.lev_u + (size_t)b * 16, is_inter, 0, 0);
     coeffs(2, cx4, cy4, 4, f.lev_v + (size_t)b * 16, is_inter, 0, 0);
@@ -213,7 +213,7 @@ struct TileEnc {
     write_skip(b, au, al, skip);
     write_cdef(r8, c8, skip);
     const int ym = f.y_mode[b];
-    const int actx = kIntraModeContext[au ? f.y_mode[b - fi.w8] : DC_PRED], lctx = kIntraModeContext[al ? f.y_mode[b - 1] : DC_PRED];
+    const int actx = kIntraModeContext[au ? f.y_mode[b - fi.w8] : (int)DC_PRED], lctx = kIntraModeContext[al ? f.y_mode[b - 1] : (int)DC_PRED];
     sym(cdf.kf_y_mode[actx][lctx], 13, ym);
     intra_tail(b, ym);
   }

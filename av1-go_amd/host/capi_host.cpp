@@ -2,7 +2,6 @@
 // values read off the reference source.
 #include <cstring>
 #include "daemon.hpp"
-#include "entropy.hpp"
 #include "av1_bitstream.hpp"
 #include "mux.hpp"
 
@@ -51,44 +50,6 @@ int av1mi_host_process_job(const char *source, long long orig_size, double ratio
   strncpy(status, job.Status.c_str(), cap - 1); status[cap - 1] = 0;
   strncpy(reason, job.Reason.c_str(), cap - 1); reason[cap - 1] = 0;
   return e.empty() ? 0 : 1;
-}
-// entropy.hpp hooks.  One frame: returns the coded size (bytes copied into out when they fit), -1 when cap is too small.
-long long av1mi_host_entropy_encode(int w, int h, int key, int tile, const int16_t *ly, const int16_t *lu, const int16_t *lv, const uint8_t *my,
-                                    const uint8_t *muv, const int16_t *mvs, const uint8_t *skip, uint8_t *out, long long cap) {
-  FrameSyms f; f.width = w; f.height = h; f.key = key; f.tile = tile; f.lev_y = ly; f.lev_u = lu; f.lev_v = lv; f.modes_y = my; f.modes_uv = muv; f.mvs = mvs; f.skip = skip;
-  const std::vector<uint8_t> b = entropy_encode_frame(f);
-  if ((long long)b.size() > cap) return -1;
-  memcpy(out, b.data(), b.size());
-  return (long long)b.size();
-}
-int av1mi_host_entropy_decode(const uint8_t *data, long long n, int w, int h, int key, int16_t *ly, int16_t *lu, int16_t *lv, uint8_t *my,
-                              uint8_t *muv, int16_t *mvs, uint8_t *skip) {
-  return entropy_decode_frame(data, (size_t)n, w, h, key, ly, lu, lv, my, muv, mvs, skip) ? 0 : 1;
-}
-// nframes key frames stacked like av1mi_intra_job's outputs, coded on `threads` threads; returns the total coded bytes
-long long av1mi_host_entropy_encode_stack(int w, int h, int nframes, int threads, int tile, const int16_t *ly, const int16_t *lu, const int16_t *lv,
-                                          const uint8_t *my, const uint8_t *muv) {
-  const size_t ny = (size_t)w * h, nc = ny / 4, nb = ny / 64;
-  std::vector<FrameSyms> fs((size_t)nframes);
-  for (int i = 0; i < nframes; i++) {
-    FrameSyms &f = fs[(size_t)i]; f.width = w; f.height = h; f.key = 1; f.tile = tile;
-    f.lev_y = ly + ny * i; f.lev_u = lu + nc * i; f.lev_v = lv + nc * i; f.modes_y = my + nb * i; f.modes_uv = muv + nb * i;
-  }
-  std::vector<std::vector<uint8_t>> out;
-  entropy_encode_frames(fs, threads, &out);
-  long long tot = 0;
-  for (auto &o : out) tot += (long long)o.size();
-  return tot;
-}
-// training aid for tools/train_cdfs.py: codes the whole frame as ONE tile and returns the adapted models (uint16 words)
-int av1mi_host_entropy_final_models(int w, int h, int key, const int16_t *ly, const int16_t *lu, const int16_t *lv, const uint8_t *my,
-                                    const uint8_t *muv, const int16_t *mvs, const uint8_t *skip, uint16_t *out, int cap_words) {
-  FrameSyms f; f.width = w; f.height = h; f.key = key; f.tile = 4096; f.lev_y = ly; f.lev_u = lu; f.lev_v = lv; f.modes_y = my; f.modes_uv = muv; f.mvs = mvs; f.skip = skip;
-  RangeEncoder e; EntropyModels m;
-  entropy_encode_tile(f, 0, 0, e, &m);
-  if ((size_t)cap_words * 2 < sizeof(m)) return -1;
-  memcpy(out, &m, sizeof(m));
-  return (int)(sizeof(m) / 2);
 }
 // AV1 bitstream writer (av1_bitstream.hpp): one temporal unit (delimiter [+ sequence header] + frame) for a frame description.
 // Returns the size in bytes (copied into out when it fits in cap), -1 on a description the writer cannot code (text in err).

@@ -3,8 +3,9 @@
 All frames of a segment are stacked into one tall plane per component so that every stage is ONE launch per
 segment (a 1080p frame is a few tens of microseconds of device work per stage: per-frame launches would be
 launch-bound).  Everything stays resident in HBM between stages; only the int16 levels and the mode bytes are
-meant to leave the device: either uncoded for the host entropy coder (host/entropy.cpp), or as the
-finished byte stream of the GPU tile entropy coder (K9, `entropy_tile` > 0).
+meant to leave the device.  These classes drive the per-stage entry points of include/av1mi.h one by one: the parity tests
+compare every stage with the oracle through them.  The PRODUCT's orchestration (and what bench.py times) is the GOP session in
+the library (csrc/gop_session.hip, av1mi.GopSession), which adds the PCIe plumbing and the AV1 tile entropy coder.
 """
 import numpy as np
 
@@ -58,10 +59,9 @@ class IntraPipeline:
          3 launches k_deblock     deblocking of Y, U, V (both passes fused)         rec -> dbl
          1 launch   k_cdef        CDEF of the three planes                          dbl -> cdef
          3 launches k_lr          loop restoration (Wiener, fixed default taps)     cdef (+ dbl rows) -> out
-         2 steps    k_ent_code + pack   (entropy_tile > 0 only) tile entropy coder: levels + modes -> one byte stream
     Filter parameters are fixed per segment by simple policies (no RD search)."""
 
-    def __init__(self, ctx, width, height, bd, frames, qindex, first_frame=0, block_size=8, entropy_tile=0, entropy_async=False):
+    def __init__(self, ctx, width, height, bd, frames, qindex, first_frame=0, block_size=8):
         self.ctx, self.bd, self.frames, self.bs, self.qindex = ctx, bd, frames, block_size, qindex
         self.width, self.height = width, height
         Y, U, V = synth.frames(width, height, frames, bd, first_frame)
@@ -77,30 +77,10 @@ class IntraPipeline:
                         ("lev_y", Y.size * 2), ("lev_u", U.size * 2), ("lev_v", V.size * 2),
                         ("modes_y", frames * nb), ("modes_uv", frames * nb)):
             self.d[name] = ctx.alloc(n)
-        self.entropy_tile, self.entropy_in_step, self.entropy_async, self.nsteps = entropy_tile, True, bool(entropy_async and entropy_tile), 0
-        self.jobs, self.ent_jobs = [], []
-        for slot in range(2 if self.entropy_async else 1):
-            sfx = "" if slot == 0 else "_b"               # asynchronous coder: levels / modes / stream are double-buffered
-            if slot:
-                for name, n in (("lev_y", Y.size * 2), ("lev_u", U.size * 2), ("lev_v", V.size * 2), ("modes_y", frames * nb), ("modes_uv", frames * nb)):
-                    self.d[name + sfx] = ctx.alloc(n)
-            job = av1mi.IntraJob(width, height, bd, frames, qindex, block_size, width, width // 2)
-            for k in ("src_y", "src_u", "src_v", "rec_y", "rec_u", "rec_v"):
-                setattr(job, "d_" + k, self.d[k].ptr)
-            for k in ("lev_y", "lev_u", "lev_v", "modes_y", "modes_uv"):
-                setattr(job, "d_" + k, self.d[k + sfx].ptr)
-            self.jobs.append(job)
-            if entropy_tile:
-                if block_size != 8:
-                    raise ValueError("the entropy coder's syntax is defined for 8x8 blocks")
-                self.ent_cap = frames * (width * height * 3 + 65536)      # raw int16 size: the coded stream stays far below
-                self.d["ent_out" + sfx], self.d["ent_off" + sfx] = ctx.alloc(self.ent_cap), ctx.alloc((frames + 1) * 8)
-                ej = av1mi.EntropyJob(width, height, frames, 1, entropy_tile)
-                for k in ("lev_y", "lev_u", "lev_v", "modes_y", "modes_uv"):
-                    setattr(ej, "d_" + k, self.d[k + sfx].ptr)
-                ej.d_out, ej.out_cap, ej.d_frame_off = self.d["ent_out" + sfx].ptr, self.ent_cap, self.d["ent_off" + sfx].ptr
-                self.ent_jobs.append(ej)
-        self.job, self.ent_job = self.jobs[0], (self.ent_jobs[0] if self.ent_jobs else None)
+        job = av1mi.IntraJob(width, height, bd, frames, qindex, block_size, width, width // 2)
+        for k in ("src_y", "src_u", "src_v", "rec_y", "rec_u", "rec_v", "lev_y", "lev_u", "lev_v", "modes_y", "modes_uv"):
+            setattr(job, "d_" + k, self.d[k].ptr)
+        self.job = job
         lib = ctx.lib
         self.dc_q, self.ac_q = lib.av1mi_dc_q(qindex, bd), lib.av1mi_ac_q(qindex, bd)
         # filter parameters: the library's policy (key-frame and inter-frame sets: the deblocking level differs for 8-bit)
@@ -125,27 +105,14 @@ class IntraPipeline:
 
     def describe(self):
         return ("%dx%d %d-bit 4:2:0 intra-only (all key frames), tile = 64x64 superblock, %dx%d blocks: intra prediction "
-                "(11 modes, SAD decision) + fwd DCT + quant + dequant + inv DCT + recon fused, then deblocking (level %d), "
-                "CDEF (strengths %s, damping %d) and Wiener loop restoration (64x64 units, default taps); %s"
-                % (self.width, self.height, self.bd, self.bs, self.bs, self.lf_level, self.cdef_sb[0].tolist(), self.cdef_damping,
-                   "levels + modes coded on the GPU by the tile entropy coder (%dx%d tiles, own syntax, not an AV1 bitstream%s)"
-                   % (self.entropy_tile, self.entropy_tile, "; side stream, overlapping the next step" if self.entropy_async else "")
-                   if self.entropy_tile and self.entropy_in_step else
-                   "levels + modes stay uncoded in HBM (entropy coding not in the timed step)"))
+                "(13 modes, SAD decision) + fwd DCT + quant + dequant + inv DCT + recon fused, then deblocking (level %d), "
+                "CDEF (strengths %s, damping %d) and Wiener loop restoration (64x64 units, default taps); levels + modes stay in HBM"
+                % (self.width, self.height, self.bd, self.bs, self.bs, self.lf_level, self.cdef_sb[0].tolist(), self.cdef_damping))
 
     def step(self):
         c, d = self.ctx, self.d
         w, h, f = self.width, self.height, self.frames
-        slot = self.nsteps % len(self.jobs)
-        self.nsteps += 1
-        if self.entropy_async and self.entropy_in_step:
-            c.entropy_wait(slot)               # the coder that read this slot's levels two steps ago has finished (device-side wait)
-        c.intra_encode(self.jobs[slot])
-        if self.ent_jobs and self.entropy_in_step:
-            if self.entropy_async:
-                c.entropy_encode_async(self.ent_jobs[slot], slot)   # side stream: overlaps the filters and the next step's coding kernel
-            else:
-                c.entropy_encode(self.ent_jobs[slot])
+        c.intra_encode(self.job)
         c.deblock_frames(d["rec_y"], w, d["dbl_y"], w, w, h, self.bd, 0, d["mi_y"], w // 4, 0, 0, f)
         c.deblock_frames(d["rec_u"], w // 2, d["dbl_u"], w // 2, w // 2, h // 2, self.bd, 1, d["mi_c"], w // 8, 0, 0, f)
         c.deblock_frames(d["rec_v"], w // 2, d["dbl_v"], w // 2, w // 2, h // 2, self.bd, 1, d["mi_c"], w // 8, 0, 0, f)
@@ -159,19 +126,7 @@ class IntraPipeline:
         reconstruction (b) and the int16 levels (2); deblocking reads and writes a plane (2b)."""
         b = self.bps
         return {"intra_pipeline": (2 * b + 2) * self.samples, "deblock": 2 * b * self.samples / 3.0,
-                "cdef": 2 * b * self.samples, "loop_restoration": 2 * b * self.samples / 3.0,
-                "entropy_code": 2 * self.samples}      # reads the int16 levels; the coded bytes are < 1 per coefficient
-
-    def coded_records(self):
-        """the frame records written by the last step (entropy_tile > 0)"""
-        self.ctx.sync()
-        sfx = "_b" if self.entropy_async and self.entropy_in_step and self.nsteps % 2 == 0 else ""
-        off = self.d["ent_off" + sfx].download((self.frames + 1,), np.uint64)
-        total = int(off[-1])
-        if total > self.ent_cap:
-            raise RuntimeError("entropy output needs %d bytes, capacity %d" % (total, self.ent_cap))
-        data = self.d["ent_out" + sfx].download((max(total, 1),), np.uint8)[:total].tobytes()
-        return [data[int(off[i]):int(off[i + 1])] for i in range(self.frames)]
+                "cdef": 2 * b * self.samples, "loop_restoration": 2 * b * self.samples / 3.0}
 
     def download(self, frame=0):
         """outputs of one frame of the segment (tests / PSNR)"""
@@ -191,13 +146,10 @@ class GopPipeline:
     """BASELINE config 3: closed GOPs of `gop` frames (1 key frame + gop-1 P frames, single reference = the previous
     reconstructed, loop-filtered frame).  Frames inside a GOP are serially dependent, so the batch dimension is the
     SEGMENT: `segments` independent GOPs are coded in lockstep, the t-th frames of all of them stacked in one launch.
-    Per step: gop x (coding launch(es) + 3 deblock + 1 CDEF + 3 LR [+ the tile entropy coder, entropy_tile > 0: every frame's
-    symbols — modes or vectors + skip flags, levels — coded on the GPU; with entropy_async on the side stream, overlapping
-    the filters of the same frame and the coding kernel of the next, symbols double-buffered])."""
+    Per step: gop x (coding launch(es) + 3 deblock + 1 CDEF + restoration with its ON / OFF decision)."""
 
-    def __init__(self, ctx, width, height, bd, segments, gop, qindex, first_frame=0, search_range=8, entropy_tile=0, entropy_async=False):
+    def __init__(self, ctx, width, height, bd, segments, gop, qindex, first_frame=0, search_range=8):
         self.ctx, self.bd, self.segments, self.gop, self.qindex, self.range = ctx, bd, segments, gop, qindex, search_range
-        self.entropy_tile, self.entropy_async = entropy_tile, bool(entropy_async and entropy_tile)
         self.width, self.height, self.frames = width, height, segments * gop
         self.key = IntraPipeline(ctx, width, height, bd, segments, qindex, first_frame=first_frame)   # buffers + filter params
         # source: segment s holds frames first + s*gop .. ; re-stack as [t][s]
@@ -208,16 +160,8 @@ class GopPipeline:
         self.d_src = [[ctx.to_device(p) for p in self.src[t]] for t in range(gop)]
         nb = (height // 8) * (width // 8)
         self.d_mvs, self.d_skip = ctx.alloc(segments * nb * 4), ctx.alloc(segments * nb)
-        # symbol buffers: slot 0 = the key pipeline's; slot 1 only for the asynchronous coder (frame t uses slot t % 2)
         self.sym = [dict(lev_y=d["lev_y"], lev_u=d["lev_u"], lev_v=d["lev_v"], modes_y=d["modes_y"], modes_uv=d["modes_uv"],
                          mvs=self.d_mvs, skip=self.d_skip)]
-        if self.entropy_async:
-            self.sym.append(dict(lev_y=ctx.alloc(Y.size // gop * 2), lev_u=ctx.alloc(U.size // gop * 2), lev_v=ctx.alloc(V.size // gop * 2),
-                                 modes_y=ctx.alloc(segments * nb), modes_uv=ctx.alloc(segments * nb),
-                                 mvs=ctx.alloc(segments * nb * 4), skip=ctx.alloc(segments * nb)))
-        self.ent_cap = segments * (width * height * 3 // 2 + 65536)
-        self.ent_out = [ctx.alloc(self.ent_cap) for _ in range(gop)] if entropy_tile else []     # one stream per frame index t
-        self.ent_off = [ctx.alloc((segments + 1) * 8) for _ in range(gop)] if entropy_tile else []
         self.d_ref = [ctx.alloc(self.src[0][i].nbytes) for i in range(3)]      # restored previous frame (see d_lr_on)
         # restoration ON / OFF per (segment, plane) of every frame index, decided on the GPU against the source (the session's policy:
         # av1mi_lr_frames_decide); frame t + 1 predicts from d_ref where ON and from the CDEF output where OFF
@@ -229,11 +173,8 @@ class GopPipeline:
 
     def describe(self):
         return ("%dx%d %d-bit 4:2:0, %d closed GOPs of %d frames in lockstep (1 key + %d P frames, single reference, +-%d full "
-                "search + half/quarter-pel refinement, 8x8 blocks), deblock + CDEF + Wiener LR + its on/off decision on every frame; %s"
-                % (self.width, self.height, self.bd, self.segments, self.gop, self.gop - 1, self.range,
-                   ("symbols coded on the GPU by the tile entropy coder (%dx%d tiles, own syntax, not an AV1 bitstream%s)"
-                    % (self.entropy_tile, self.entropy_tile, "; side stream" if self.entropy_async else ""))
-                   if self.entropy_tile else "symbols stay uncoded in HBM"))
+                "search + half/quarter-pel refinement, 8x8 blocks), deblock + CDEF + Wiener LR + its on/off decision on every frame; "
+                "symbols stay uncoded in HBM" % (self.width, self.height, self.bd, self.segments, self.gop, self.gop - 1, self.range))
 
     def _filters(self, skip_buf, skip_stride, key, t):
         c, k, d = self.ctx, self.key, self.key.d
@@ -262,10 +203,7 @@ class GopPipeline:
         nb = (h // 8) * (w // 8)
         for t in range(self.gop):
             s = self.d_src[t]
-            slot = t % len(self.sym)
-            y = self.sym[slot]
-            if self.entropy_async:
-                c.entropy_wait(slot)         # the coder of frame t - 2 has released this slot's symbol buffers
+            y = self.sym[0]
             if t == 0:
                 job = av1mi.IntraJob(w, h, self.bd, f, self.qindex, 8, w, w // 2, s[0].ptr, s[1].ptr, s[2].ptr, d["rec_y"].ptr,
                                      d["rec_u"].ptr, d["rec_v"].ptr, y["lev_y"].ptr, y["lev_u"].ptr, y["lev_v"].ptr, y["modes_y"].ptr,
@@ -277,14 +215,6 @@ class GopPipeline:
                                      d["rec_v"].ptr, y["lev_y"].ptr, y["lev_u"].ptr, y["lev_v"].ptr, y["mvs"].ptr, y["skip"].ptr,
                                      d["cdef_y"].ptr, d["cdef_u"].ptr, d["cdef_v"].ptr, self.d_lr_on[t - 1].ptr)
                 c.inter_encode(job)
-            if self.entropy_tile:
-                ej = av1mi.EntropyJob(w, h, f, int(t == 0), self.entropy_tile, y["lev_y"].ptr, y["lev_u"].ptr, y["lev_v"].ptr,
-                                      y["modes_y"].ptr, y["modes_uv"].ptr, y["mvs"].ptr, y["skip"].ptr,
-                                      self.ent_out[t].ptr, self.ent_cap, self.ent_off[t].ptr)
-                if self.entropy_async:
-                    c.entropy_encode_async(ej, slot)
-                else:
-                    c.entropy_encode(ej)
             self._filters(self.zero_skip if t == 0 else y["skip"], 0 if t == 0 else nb, t == 0, t)
             if on_frame:
                 on_frame(t)
@@ -294,28 +224,18 @@ class GopPipeline:
         p = self.key.pol[0 if t == 0 else 1]
         return p["mi_y"], p["mi_c"], p["cdef_damping"], p["cdef_sb"], p["lr_unit"], p["lr_units_y"], p["lr_units_c"]
 
-    def coded_records(self, t):
-        """records of the t-th frames of all segments written by the last step (entropy_tile > 0)"""
-        self.ctx.sync()
-        off = self.ent_off[t].download((self.segments + 1,), np.uint64)
-        total = int(off[-1])
-        if total > self.ent_cap:
-            raise RuntimeError("entropy output needs %d bytes, capacity %d" % (total, self.ent_cap))
-        data = self.ent_out[t].download((max(total, 1),), np.uint8)[:total].tobytes()
-        return [data[int(off[i]):int(off[i + 1])] for i in range(self.segments)]
-
     def algorithmic_bytes(self):
         b, per_frame = self.bps, self.samples / self.gop
         # k_me_int reads the luma source and the luma reference (2b per LUMA sample = 2/3 of the frame's samples); k_inter_pipe
         # reads source + reference, writes reconstruction + int16 levels (SURVEY.md §8d: (3b + 2) per sample)
         return {"intra_pipeline": (2 * b + 2) * per_frame, "inter_pipeline": (3 * b + 2) * per_frame, "me_integer": 2 * b * per_frame * 2.0 / 3.0,
                 "deblock": 2 * b * per_frame / 3.0,
-                "cdef": 2 * b * per_frame, "loop_restoration": 2 * b * per_frame / 3.0, "entropy_code": 2 * per_frame}
+                "cdef": 2 * b * per_frame, "loop_restoration": 2 * b * per_frame / 3.0}
 
     def close(self):
         for t in self.d_src:
             for b in t:
                 b.free()
-        for b in [self.d_mvs, self.d_skip, self.zero_skip] + self.d_ref + self.d_lr_on + [self.d_lr_scratch] + self.ent_out + self.ent_off + (list(self.sym[1].values()) if len(self.sym) > 1 else []):
+        for b in [self.d_mvs, self.d_skip, self.zero_skip] + self.d_ref + self.d_lr_on + [self.d_lr_scratch]:
             b.free()
         self.key.close()

@@ -83,7 +83,7 @@ int av1mi_timer_end(av1mi_ctx *ctx, float *elapsed_ms);
 enum av1mi_kernel_kind {
   AV1MI_K_FWD_TXFM, AV1MI_K_INV_TXFM, AV1MI_K_QUANT, AV1MI_K_DEQUANT, AV1MI_K_INTRA_PRED, AV1MI_K_MC,
   AV1MI_K_DEBLOCK, AV1MI_K_CDEF, AV1MI_K_LR, AV1MI_K_INTRA_PIPE, AV1MI_K_INTER_PIPE, AV1MI_K_MISC, AV1MI_K_ENTROPY,
-  AV1MI_K_ENTROPY_PACK, AV1MI_K_ENTROPY_TOKENS, AV1MI_K_ME_INT, AV1MI_K_KINDS
+  AV1MI_K_ENTROPY_PACK, AV1MI_K_ENTROPY_TOKENS, AV1MI_K_ME_INT, AV1MI_K_ENTROPY_CHAINS, AV1MI_K_KINDS
 };
 int av1mi_prof_enable(av1mi_ctx *ctx, int on);
 int av1mi_prof_reset(av1mi_ctx *ctx);
@@ -283,38 +283,7 @@ typedef struct av1mi_inter_job {
 } av1mi_inter_job;
 int av1mi_inter_encode(av1mi_ctx *ctx, const av1mi_inter_job *job);
 
-/* ---- K9: tile entropy coder (the stage that follows the block pipelines: SURVEY.md §8a row H1 keeps it on the host
- * cores and §8e names it the scaling risk; here the symbols never leave HBM uncoded).  Codes the outputs of
- * av1mi_intra_encode (key = 1: levels + modes) or av1mi_inter_encode (key = 0: levels + vectors + skip flags), 8x8
- * blocks, of `nframes` stacked frames into ONE contiguous byte stream of frame records
- *   [log2(tile)] [varint payload size of every tile, raster order] [tile payloads]
- * in the syntax of av1-go_amd/host/entropy.hpp (AV1's range-coder arithmetic and CDF adaptation, spec §8.2.6, over
- * this project's own symbols and initial CDFs — not an AV1 bitstream).  Every tile (tile x tile luma samples, tile =
- * 32, 64 or 128) has an independent coder state: one GPU lane per tile.  d_frame_off receives nframes + 1 byte
- * offsets into d_out (the last one = total size).  If the total exceeds out_cap nothing is written to d_out and
- * d_frame_off[nframes] still holds the size needed (worst case 6 bytes per coefficient + 64 per tile); if a tile overran its
- * scratch slot (levels beyond that bound) d_frame_off[nframes] = UINT64_MAX and nothing is written.
- * Scratch (one slot per tile) is owned by the context and grows on demand. */
-typedef struct av1mi_entropy_job {
-  int width, height, nframes, key, tile;
-  const int16_t *d_lev_y, *d_lev_u, *d_lev_v;
-  const uint8_t *d_modes_y, *d_modes_uv;   /* key = 1 */
-  const int16_t *d_mvs; const uint8_t *d_skip;   /* key = 0 */
-  uint8_t *d_out; size_t out_cap;
-  uint64_t *d_frame_off;                   /* nframes + 1 entries, 8-byte aligned */
-} av1mi_entropy_job;
-int av1mi_entropy_encode(av1mi_ctx *ctx, const av1mi_entropy_job *job);
-/* Asynchronous form.  The coder is a latency-bound kernel (one wave per SIMD at most, a serial chain per tile) that
- * leaves most of the chip idle, so it runs on the context's SIDE stream: it starts after everything queued so far on
- * the main stream (which produced its inputs) and overlaps whatever the main stream is given next — the next batch's
- * block pipeline, the in-loop filters.  `slot` (0..7) names the completion event.  av1mi_entropy_wait makes the MAIN
- * stream (not the host) wait for that slot's coder: call it before launching work that overwrites the job's input
- * buffers (double-buffer levels / modes and alternate two slots).  av1mi_sync waits for both streams. */
-int av1mi_entropy_encode_async(av1mi_ctx *ctx, const av1mi_entropy_job *job, int slot);
-int av1mi_entropy_wait(av1mi_ctx *ctx, int slot);
-
-
-/* ---- K9 for the real syntax: the AV1 tile entropy coder on the GPU (av1-go_amd/csrc/av1_entropy_kernels.hip).  Codes the outputs
+/* ---- K9: the AV1 tile entropy coder on the GPU (av1-go_amd/csrc/av1_entropy_kernels.hip).  Codes the outputs
  * of av1mi_intra_encode (key = 1) or av1mi_inter_encode (key = 0) of `nframes` stacked frames in AV1's tile syntax — the tool
  * set of the block pipeline: 8x8 blocks, one 64x64 superblock per tile, TX_MODE_LARGEST, DCT_DCT luma, cdef_bits = 0, Wiener
  * restoration on 64x64 units — byte-identical to the host writer (include/av1mi_host.h), which dav1d verifies.  Output: the tile
@@ -341,6 +310,9 @@ int av1mi_av1_entropy_encode(av1mi_ctx *ctx, const av1mi_av1_entropy_job *job);
 /* the same on another HIP stream of the caller's (hipStream_t passed as void *; NULL = the context's stream) */
 int av1mi_av1_entropy_encode_on(av1mi_ctx *ctx, const av1mi_av1_entropy_job *job, void *stream);
 uint32_t av1mi_av1_entropy_ops_per_tile(void);
+/* measurement: 32-bit list words (one per syntax element) the most recent job handed from the tokenizer to the range coder, summed
+ * over its tiles; synchronises the device */
+int av1mi_av1_entropy_last_list_words(av1mi_ctx *ctx, uint64_t *words);
 uint32_t av1mi_av1_entropy_slot_bytes(void);
 
 /* ---- GOP session: the encoder object a cgo replacement of RunTranscode drives (reference call site
@@ -424,6 +396,11 @@ int av1mi_gop_acquire_input(av1mi_gop *g, void **y, void **u, void **v);
 /* queue the batch in the acquired buffers.  frame_type: 0 key, 1 inter, -1 = by position in the GOP (gop_length).
  * AV1MI_E_INVAL when av1mi_gop_max_in_flight() batches are already in flight (collect first). */
 int av1mi_gop_submit(av1mi_gop *g, int frame_type);
+/* The same for a batch whose source planes are ALREADY in device memory (same layout as the pinned planes: segments stacked, stride =
+ * width): no upload is queued, the kernels read the caller's buffers, which must stay valid and unchanged until the batch has been
+ * collected.  No av1mi_gop_acquire_input() before it.  (A decoder that leaves its frames in HBM feeds the session this way; bench.py
+ * times this path, the bench contract's "inputs already resident in HBM".) */
+int av1mi_gop_submit_device(av1mi_gop *g, const void *d_y, const void *d_u, const void *d_v, int frame_type);
 /* wait for the oldest batch in flight and describe its symbols; AV1MI_E_INVAL when nothing is in flight */
 int av1mi_gop_collect(av1mi_gop *g, av1mi_gop_frame *out);
 /* number of batches in flight (0..av1mi_gop_max_in_flight()) */

@@ -1,7 +1,7 @@
 /*
  * av1o_cdef.c — CPU oracle for SURVEY.md §8 row K6: the constrained directional enhancement filter, 4:2:0.
  *
- * TEST INFRASTRUCTURE ONLY; PARITY UNPINNED (see av1o_common.h).  Restates, from knowledge:
+ * TEST INFRASTRUCTURE ONLY; pinned to dav1d, not to the reference (see av1o_common.h).  Restates, from knowledge:
  *   av1o_cdef_find_dir    AV1 spec §7.15.2 "CDEF direction process" == libaom cdef_find_dir_c (av1/common/cdef_block.c)
  *   cdef_filter_block     spec §7.15.3 "CDEF filter process" == libaom cdef_filter_block_c / constrain()
  *   av1o_cdef_frame       spec §7.15 / §7.15.1: per 64x64, per 8x8 (all-skip blocks untouched), luma primary strength

@@ -5,16 +5,23 @@
  * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * load liboracle.so.  The product (libav1mi.so) never links or calls it.
  *
- * PARITY UNPINNED: the reference (IONIQ6000/av1-go) holds no codec arithmetic,
- * no tests and no golden vectors for this path.  The
- * arithmetic lives in an un-vendored third-party binary (FFmpeg 8.x "latest"
- * → av1_vaapi → Intel hardware; reference internal/ffmpeg/transcode.go:120,195,
- * internal/config/config.go:33).  This oracle restates the published AV1
- * decoding process (AV1 Bitstream & Decoding Process Specification §7.11-7.17)
- * and the matching libaom C functions from knowledge; neither text is in the
- * container, so every function names the spec section / libaom function it
- * restates instead of a reference file:line.  It must be re-verified against
- * libaom on any box that has it.
+ * PARITY: the reference (IONIQ6000/av1-go) holds no codec arithmetic, no tests
+ * and no golden vectors for this path: by the
+ * reference's own fixtures this oracle is "parity unpinned", and no reference
+ * build exists to compare with (the arithmetic lives in an un-vendored FFmpeg 8.x
+ * "latest" -> av1_vaapi -> Intel hardware; internal/ffmpeg/transcode.go:120,195,
+ * internal/config/config.go:33).  What pins it instead is a conformant third-party
+ * DECODER: every normative function here (dequantiser, inverse transforms of all
+ * 19 sizes x 16 types, intra prediction of every block size, motion compensation
+ * of every block size x 4 filters, deblocking with every filter length, CDEF,
+ * loop restoration) is compared bit for bit with dav1d 1.5.3 on arbitrary
+ * symbols (tests/test_av1_conformance.py, tests/test_av1_blocks.py).  The
+ * non-normative encoder side (forward transforms, quantiser rounding, searches)
+ * has no external pin; it is checked by round-trip properties.  The oracle
+ * restates the AV1 decoding process (AV1 Bitstream & Decoding Process
+ * Specification §7.11-7.17) and the matching libaom C functions from knowledge;
+ * neither text is in the container, so every function names the spec section /
+ * libaom function it restates instead of a reference file:line.
  */
 #ifndef AV1O_COMMON_H
 #define AV1O_COMMON_H

@@ -1,7 +1,7 @@
 /*
  * av1o_deblock.c — CPU oracle for SURVEY.md §8 row K5: the deblocking loop filter of one plane.
  *
- * TEST INFRASTRUCTURE ONLY; PARITY UNPINNED (see av1o_common.h).  Restates, from knowledge:
+ * TEST INFRASTRUCTURE ONLY; pinned to dav1d, not to the reference (see av1o_common.h).  Restates, from knowledge:
  *   av1o_deblock_plane        AV1 spec §7.14.2 edge loop (pass 0: all vertical edges of the plane, then
  *                             pass 1: all horizontal edges), §7.14.3 filter size, §7.14.4 adaptive strength
  *   lf_limits                 spec §7.14.4 == libaom update_sharpness()/av1_loop_filter_init

@@ -3,7 +3,7 @@
  * (directional modes incl. intra-edge filter / corner filter / edge upsampling; plus the adjacent
  * DC, Paeth and Smooth predictors the intra-only pipeline needs).
  *
- * TEST INFRASTRUCTURE ONLY; PARITY UNPINNED (see av1o_common.h).  Restates, from knowledge:
+ * TEST INFRASTRUCTURE ONLY; pinned to dav1d, not to the reference (see av1o_common.h).  Restates, from knowledge:
  *   av1o_intra_predict      AV1 spec §7.11.2 "intra prediction process" == libaom
  *                           build_intra_predictors() (av1/common/reconintra.c), incl. the
  *                           unavailable-edge rules (base-1 above / base+1 left)

@@ -1,7 +1,7 @@
 /*
  * av1o_lr.c — CPU oracle for SURVEY.md §8 row K7: loop restoration (Wiener and self-guided) of one plane.
  *
- * TEST INFRASTRUCTURE ONLY; PARITY UNPINNED (see av1o_common.h).  Restates, from knowledge:
+ * TEST INFRASTRUCTURE ONLY; pinned to dav1d, not to the reference (see av1o_common.h).  Restates, from knowledge:
  *   src_sample            AV1 spec §7.17.6 "get source sample process": picture-edge clamp, then 64-row stripes offset
  *                         by 8 luma rows; up to 2 rows beyond the stripe come from the DEBLOCKED (pre-CDEF) frame,
  *                         further rows replicate them; inside the stripe the CDEF output is used

@@ -2,7 +2,7 @@
  * av1o_mc.c — CPU oracle for SURVEY.md §8 row K4: sub-pel motion compensation of one block (single reference,
  * no scaling, no compound): separable 8-tap FIR, 1/16-sample phases, two-stage rounding.
  *
- * TEST INFRASTRUCTURE ONLY; PARITY UNPINNED (see av1o_common.h).  Restates, from knowledge:
+ * TEST INFRASTRUCTURE ONLY; pinned to dav1d, not to the reference (see av1o_common.h).  Restates, from knowledge:
  *   av1o_mc_block         AV1 spec §7.11.3.4 "block inter prediction process" (InterRound0 = 3, InterRound1 = 11
  *                         for a single 8/10-bit prediction) == libaom av1_highbd_convolve_2d_sr_c (its bias
  *                         terms cancel exactly), plus the reference-edge clamping of §7.11.3.3/4

@@ -2,7 +2,7 @@
  * av1o_pipeline.c — oracle-side frame loops: the same per-block stages the GPU pipeline runs,
  * applied block after block over a plane.  Used as the checker for whole-plane parity tests and as
  * bench.py's cpu_baseline ("port": own CPU restatement, not the reference — the reference's CPU path
- * does not exist in its tree).  TEST INFRASTRUCTURE ONLY; PARITY UNPINNED.
+ * does not exist in its tree).  TEST INFRASTRUCTURE ONLY; the encoder loops are non-normative: no external pin (see av1o_common.h).
  */
 #include "av1o_common.h"
 #include <string.h>

@@ -2,7 +2,7 @@
  * av1o_txfm.c — CPU oracle for SURVEY.md §8 rows K1 (forward 2-D transform),
  * K2 (inverse 2-D transform + reconstruct) and K8 (quantise / dequantise).
  *
- * TEST INFRASTRUCTURE ONLY (see av1o_common.h).  PARITY UNPINNED: restated from
+ * TEST INFRASTRUCTURE ONLY (see av1o_common.h).  The inverse transforms are pinned to dav1d (all sizes and types); restated from
  * the AV1 specification and libaom from knowledge; the reference tree holds no
  * arithmetic for this path (reference internal/ffmpeg/transcode.go:120 only
  * names the external encoder).

@@ -3,7 +3,7 @@
  * av1_idct16 / av1_idct32 (av1/common/av1_inv_txfm1d.c) written out longhand from knowledge.
  * They exist only to pin the generic generator in av1o_txfm.c (idct_core/idct_odd): the
  * tests require both to agree bit-for-bit on random and extreme inputs.
- * TEST INFRASTRUCTURE ONLY; PARITY UNPINNED (see av1o_common.h).
+ * TEST INFRASTRUCTURE ONLY; pinned to dav1d, not to the reference (see av1o_common.h).
  */
 #include "av1o_common.h"
 

@@ -1,7 +1,7 @@
 """ctypes binding of the CPU oracle (oracle/liboracle.so).
 
 TEST INFRASTRUCTURE ONLY: import this from tests/, __graft_entry__.smoke() and
-bench.py's cpu_baseline leg, never from the product.  PARITY UNPINNED — see
+bench.py's cpu_baseline leg, never from the product.  Pinned to dav1d, not to the reference — see
 oracle/av1o_common.h.
 """
 import ctypes as C
@@ -321,22 +321,6 @@ def inter_encode_frame(src, ref, bd, qindex, search_range=8, bs=8):
     if rc:
         raise ValueError("av1o_inter_encode_frame rc=%d" % rc)
     return out
-
-
-def entropy_encode_frame(w, h, key, tile, lev_y, lev_u, lev_v, modes_y=None, modes_uv=None, mvs=None, skip=None):
-    """oracle tile entropy coder: returns the frame record as bytes (format: av1o_entropy.c header)"""
-    L = lib()
-    L.av1o_entropy_encode_frame.restype = C.c_size_t
-    L.av1o_entropy_encode_frame.argtypes = [C.c_int] * 4 + [C.c_void_p] * 8 + [C.c_size_t]
-    arrs = [None if a is None else np.ascontiguousarray(a, dt) for a, dt in
-            ((lev_y, np.int16), (lev_u, np.int16), (lev_v, np.int16), (modes_y, np.uint8), (modes_uv, np.uint8), (mvs, np.int16), (skip, np.uint8))]
-    cap = 2 * (w * h * 10 + 65536)
-    out = np.zeros(cap, np.uint8)
-    n = L.av1o_entropy_encode_frame(w, h, key, tile, *[None if a is None else a.ctypes.data_as(C.c_void_p) for a in arrs],
-                                    out.ctypes.data_as(C.c_void_p), cap)
-    if n == C.c_size_t(-1).value:
-        raise ValueError("av1o_entropy_encode_frame: capacity")
-    return out[:n].tobytes()
 
 
 def cfl_predict(luma, dc_plane, bd, x, y, bw, bh, alpha_q3, max_luma_w=None, max_luma_h=None):

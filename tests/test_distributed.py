@@ -21,6 +21,11 @@ def test_bench_two_ranks_gloo():
     # rank 1 sleeps 20 ms per step, rank 0 10 ms: the aggregate time is the slower rank's
     assert j["ms_per_step"] >= 19.0
     assert abs(j["value"] - 2 * j["frames_per_step"] * 5 / (j["ms_per_step"] * 5e-3)) < 1e-6 * j["value"] + 1e-6
+    # the end-to-end leg runs on EVERY rank between barriers: frames of both ranks over the slower rank's time
+    # (rank 1 sleeps 40 ms), host threads shared between the ranks
+    e = j["e2e_gpu_entropy"]
+    assert e["ranks"] == 2 and e["host_threads_per_rank"] >= 1
+    assert 2 * j["frames_per_step"] / 0.2 < j["e2e_gpu_entropy_frames_per_s"] <= 2 * j["frames_per_step"] / 0.04 + 1e-6
 
 
 def test_single_rank_dry_run():
@@ -49,6 +54,29 @@ def test_gpus_flag_spawns_the_ranks_itself():
     assert len(lines) == 1
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["ms_per_step"] >= 19.0
+
+
+def test_world_size_without_gpus_flag_is_taken_from_the_launcher():
+    """a launcher run that sets WORLD_SIZE without repeating --gpus must not exit"""
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run-cpu", "--steps", "1"], env=env, capture_output=True, text=True,
+                         timeout=120, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+
+
+def test_a_dying_rank_takes_the_others_down(tmp_path):
+    """spawn_ranks polls its children: when one exits non-zero the rest are terminated instead of waiting in a barrier"""
+    import time
+    sys.path.insert(0, ROOT)
+    code = ("import os, sys, time\n"
+            "sys.exit(3) if os.environ['RANK'] == '1' else time.sleep(600)\n")
+    script = tmp_path / "bench.py"
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    script.write_text(src.replace("def main():\n    args = parse()", "def main():\n    args = parse()\n    if 'RANK' in os.environ:\n        exec(%r)" % code, 1))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    t0 = time.time()
+    out = subprocess.run([sys.executable, str(script), "--gpus", "2", "--dry-run-cpu"], env=env, capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert out.returncode != 0 and "rank(s) failed" in out.stderr and time.time() - t0 < 60
 
 
 def test_gpus_flag_must_match_the_launcher():

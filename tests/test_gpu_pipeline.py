@@ -94,80 +94,6 @@ def test_closed_gop_chain_matches_oracle(ctx, O, w, h, bd, q, segs, gop, rng_):
     gp.close()
 
 
-def test_pipeline_with_gpu_entropy_stage(ctx, O):
-    """levels + modes never leave HBM uncoded: the records of the fused step equal the oracle coder run on the oracle's
-    encoder-loop outputs (block pipeline parity and entropy parity chained)."""
-    import pipeline
-    w, h, bd, q = 320, 200, 8, 110
-    pipe = pipeline.IntraPipeline(ctx, w, h, bd, 3, q, first_frame=4, entropy_tile=64)
-    pipe.step()
-    recs = pipe.coded_records()
-    Y, U, V = pipe.src
-    for f in range(3):
-        r = O.intra_encode_frame(Y[f], U[f], V[f], bd, 8, q)
-        ref = O.entropy_encode_frame(w, h, 1, 64, r["lev_y"], r["lev_u"], r["lev_v"], r["modes_y"], r["modes_uv"])
-        assert recs[f] == ref, "frame %d: %d vs %d bytes" % (f, len(recs[f]), len(ref))
-        assert len(ref) < Y[f].nbytes           # and it compresses
-    pipe.close()
-
-
-def test_async_entropy_stage_matches_sync(ctx, av1mi, O):
-    """side-stream coder with double-buffered levels: every step's records equal the oracle's, whichever slot they used — also
-    on a context whose side stream a GOP session has created before (the events of this path are then still to be made)"""
-    import pipeline
-    w, h, bd, q = 256, 136, 8, 150
-    av1mi.GopSession(ctx, 64, 64, 8, 100, 2, 1, gpu_entropy=1).close()
-    pipe = pipeline.IntraPipeline(ctx, w, h, bd, 2, q, first_frame=0, entropy_tile=32, entropy_async=True)
-    Y, U, V = pipe.src
-    ref = []
-    for f in range(2):
-        r = O.intra_encode_frame(Y[f], U[f], V[f], bd, 8, q)
-        ref.append(O.entropy_encode_frame(w, h, 1, 32, r["lev_y"], r["lev_u"], r["lev_v"], r["modes_y"], r["modes_uv"]))
-    for _ in range(3):                      # slots 0, 1, 0: the third step had to wait for the first one's coder
-        pipe.step()
-        assert pipe.coded_records() == ref
-    for _ in range(4):                      # back to back without host syncs in between
-        pipe.step()
-    assert pipe.coded_records() == ref
-    pipe.close()
-
-
-@pytest.mark.parametrize("use_async", [False, True])
-def test_closed_gop_chain_coded_records(ctx, O, use_async):
-    """config 3 with the entropy stage: key + P frames of 2 segments, every frame's record (modes or vectors + skip flags,
-    levels) equals the oracle coder's on the oracle chain's symbols — in the serial and in the side-stream form, twice in a
-    row (the second step reuses every double-buffered slot)"""
-    import pipeline
-    w, h, bd, q, gop = 192, 136, 8, 120, 4
-    gp = pipeline.GopPipeline(ctx, w, h, bd, segments=2, gop=gop, qindex=q, first_frame=3, search_range=6, entropy_tile=64,
-                              entropy_async=use_async)
-    k = gp.key
-    want = [[None] * 2 for _ in range(gop)]
-    for s in range(2):
-        ref = None
-        for t in range(gop):
-            src = [gp.src[t][i][s] for i in range(3)]
-            if t == 0:
-                r = O.intra_encode_frame(src[0], src[1], src[2], bd, 8, q)
-                skip8 = np.zeros((h // 8, w // 8), np.uint8)
-                want[t][s] = O.entropy_encode_frame(w, h, 1, 64, r["lev_y"], r["lev_u"], r["lev_v"], r["modes_y"], r["modes_uv"])
-            else:
-                r = O.inter_encode_frame(src, ref, bd, q, 6)
-                skip8 = r["skip"].reshape(h // 8, w // 8)
-                want[t][s] = O.entropy_encode_frame(w, h, 0, 64, r["lev_y"], r["lev_u"], r["lev_v"], mvs=r["mvs"], skip=r["skip"])
-            mi_y, mi_c, damping, cdef_sb, lr_unit, lr_y, lr_c = gp.oracle_filter_args(t)
-            dbl = [O.deblock_plane(r["rec_y"], bd, 0, mi_y), O.deblock_plane(r["rec_u"], bd, 1, mi_c), O.deblock_plane(r["rec_v"], bd, 1, mi_c)]
-            cdef = O.cdef_frame(dbl[0], dbl[1], dbl[2], bd, damping, cdef_sb, skip8)
-            lr = [O.lr_plane(cdef[0], dbl[0], bd, 0, lr_unit, lr_y), O.lr_plane(cdef[1], dbl[1], bd, 1, lr_unit, lr_c),
-                  O.lr_plane(cdef[2], dbl[2], bd, 1, lr_unit, lr_c)]
-            ref, _ = O.lr_select(src, cdef, lr, bd)
-    for _ in range(2):
-        gp.step()
-        for t in range(gop):
-            assert gp.coded_records(t) == want[t], "frame index %d" % t
-    gp.close()
-
-
 def test_job_edge_cases_and_error_behaviour(ctx, av1mi):
     """the boundary's error contract on the fused pipelines: an empty segment is a no-op that touches nothing, malformed jobs are
     refused with a negative code and a message (never a launch), 12-bit content is rejected (only 8 and 10 are built)"""

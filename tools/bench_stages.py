@@ -104,18 +104,13 @@ def main():
         for x in (d_l, d_dst, d_m, d_plane, d_c, d_cd):
             x.free()
         # K5 / K6 / K7 / fused pipelines / K9 through the segment pipeline's buffers
-        pipe = pipeline.IntraPipeline(ctx, 1920, 1080, bd, F, 128, entropy_tile=64 if bd == 8 else 0)
-        pipe.entropy_in_step = False
+        pipe = pipeline.IntraPipeline(ctx, 1920, 1080, bd, F, 128)
         t = timed(ctx, pipe.step)
         alg = pipe.algorithmic_bytes()
         add("pipe", "k_intra_pipe", t["intra_pipeline"], alg["intra_pipeline"], "%d-bit %d x 1080p intra coding loop" % (bd, F))
         add("K5", "k_deblock", t["deblock"], alg["deblock"], "%d-bit, avg of Y/U/V launches" % bd)
         add("K6", "k_cdef", t["cdef"], alg["cdef"], "%d-bit Y+U+V" % bd)
         add("K7", "k_lr (Wiener)", t["loop_restoration"], alg["loop_restoration"], "%d-bit, avg of Y/U/V launches" % bd)
-        if bd == 8:
-            t = timed(ctx, lambda: ctx.entropy_encode(pipe.ent_job))
-            add("K9", "k_ent_tokens", t["entropy_tokens"], 2 * pipe.samples, "levels -> ops, 64x64 tiles")
-            add("K9", "k_ent_code", t["entropy_code"], 2 * pipe.samples, "ops -> bytes, one lane per tile (serial chain)")
         pipe.close()
         gp = pipeline.GopPipeline(ctx, 1920, 1080, bd, F, 2, 128)
         t = timed(ctx, gp.step, reps=3)

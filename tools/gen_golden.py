@@ -111,35 +111,8 @@ def gen_stages():
     print("stages_kat.npz:", len(d), "arrays")
 
 
-def gen_entropy():
-    """H1 / K9: symbols in, coded frame records out (oracle/av1o_entropy.c).  The syntax and the initial CDFs are this
-    project's own, so these bytes pin the FORMAT: a change to entropy_init.hpp or to the syntax must regenerate them."""
-    sys.path.insert(0, os.path.join(ROOT, "av1-go_amd"))
-    import synth
-    rng = np.random.default_rng(0xA51C0DE + 2)
-    d = {}
-    Y, U, V = synth.frames(136, 72, 2, 8, 5)                   # ragged for every tile size
-    k = O.intra_encode_frame(Y[0], U[0], V[0], 8, 8, 110)
-    p = O.inter_encode_frame((Y[1], U[1], V[1]), (k["rec_y"], k["rec_u"], k["rec_v"]), 8, 110, 6)
-    nb = (136 // 8) * (72 // 8)
-    adv = dict(lev_y=rng.integers(-32768, 32768, (nb, 8, 8)).astype(np.int16), lev_u=rng.integers(-3, 4, (nb, 4, 4)).astype(np.int16),
-               lev_v=np.zeros((nb, 4, 4), np.int16), modes_y=rng.integers(0, 13, nb).astype(np.uint8), modes_uv=np.full(nb, 12, np.uint8))
-    adv["lev_y"][::3] = 0
-    adv["lev_v"][:, 3, 3] = -32768
-    for name, r, key in (("key", k, 1), ("p", p, 0), ("adv", adv, 1)):
-        for f in ("lev_y", "lev_u", "lev_v") + (("modes_y", "modes_uv") if key else ("mvs", "skip")):
-            d["%s_%s" % (name, f)] = r[f]
-        for tile in (32, 64, 128):
-            rec = O.entropy_encode_frame(136, 72, key, tile, r["lev_y"], r["lev_u"], r["lev_v"], r.get("modes_y") if key else None,
-                                         r.get("modes_uv") if key else None, None if key else r["mvs"], None if key else r["skip"])
-            d["%s_rec_%d" % (name, tile)] = np.frombuffer(rec, np.uint8)
-    np.savez_compressed(os.path.join(OUT, "entropy_kat.npz"), **d)
-    print("entropy_kat.npz:", len(d), "arrays,", sum(v.nbytes for v in d.values()), "bytes raw")
-
-
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     O.build()
     gen_txfm()
     gen_stages()
-    gen_entropy()
