@@ -98,6 +98,7 @@ struct av1mi_gop {
   long fallbacks = 0;                          // batches the GPU coder could not hold (handed out as symbols instead)
   int gop_pos = 0;
   bool acquired = false;
+  int coder_streams = 0;                       // 0 = tokenizer + chains on the side stream, range coder on the back stream (default)
   std::vector<void *> dev_allocs, host_allocs;
 };
 
@@ -238,6 +239,7 @@ int av1mi_gop_open(av1mi_ctx *ctx, const av1mi_gop_config *cfg, av1mi_gop **out)
   av1mi_gop *g = new (std::nothrow) av1mi_gop();
   if (!g) return AV1MI_E_NOMEM;
   g->ctx = ctx; g->cfg = *cfg;
+  if (const char *e = getenv("AV1MI_CODER_STREAMS")) g->coder_streams = !strcmp(e, "side") ? 1 : !strcmp(e, "main") ? 2 : 0;
   const int rc = setup(g);
   if (rc != AV1MI_OK) { av1mi_gop_close(g); return rc; }
   *out = g;
@@ -408,7 +410,9 @@ static int submit_batch(av1mi_gop *g, int frame_type, const void *const *dev_src
     // next batch's tokenizer does not wait for it)
     hipStream_t side = av1mi::ctx_side_stream(g->ctx), back = av1mi::ctx_back_stream(g->ctx);
     if (!side || !back) return av1mi::ctx_fail(g->ctx, AV1MI_E_DEVICE, "no side stream");
-    G_HIP(hipStreamWaitEvent(side, s.filters_done, 0));
+    if (g->coder_streams == 1) back = side;                 // diagnostic arrangements (AV1MI_CODER_STREAMS): the whole coder on the side stream
+    else if (g->coder_streams == 2) side = back = main;     // ... or on the main stream, serialised behind the filters
+    if (side != main) G_HIP(hipStreamWaitEvent(side, s.filters_done, 0));
     av1mi_av1_entropy_job ej;
     memset(&ej, 0, sizeof(ej));
     ej.width = w; ej.height = h; ej.nframes = S; ej.key = frame_type == 0; ej.base_q_idx = c.base_q_idx;

@@ -3,7 +3,8 @@
 // libav1mi.so's GOP session (include/av1mi.h av1mi_gop_*), entropy coding + OBU packing in av1_bitstream.cpp on the host
 // cores, so nothing about the encoder is decided here.
 //
-// Input is Y4M (4:2:0, 8- or 10-bit) because demux / H.264 decode stay FFmpeg's job (SURVEY.md §8b "Gap to flag").
+// Input is Y4M (4:2:0, 8- or 10-bit), from a file or from a stream ("-i -", a FIFO: y4m.hpp), because demux / H.264 decode stay
+// FFmpeg's job (SURVEY.md §8b "Gap to flag"): any decoder process can pipe its frames in.
 // Output, chosen by the file name: ".obu" = Section-5 low-overhead OBU stream (what `dav1d -i x.obu` / `aomdec --obu` read),
 // ".ivf" = IVF, anything else (the reference's "<base>.av1-tmp.mkv") = Matroska with one V_AV1 video track (mux.cpp);
 // audio / subtitle copy (transcode.go:134-137) needs a demuxer and is not done.
@@ -20,78 +21,9 @@
 #include "../../include/av1mi.h"
 #include "av1_bitstream.hpp"
 #include "mux.hpp"
+#include "y4m.hpp"
 
 namespace av1mi_host {
-namespace {
-
-struct Y4m {
-  FILE *f = nullptr;
-  int w = 0, h = 0, bd = 8, fps_n = 30, fps_d = 1;
-  long hdr_len = 0;
-  size_t frame_bytes = 0;
-  long nframes = 0;
-};
-
-bool y4m_open(const std::string &path, Y4m *y, std::string *err) {
-  y->f = fopen(path.c_str(), "rb");
-  if (!y->f) { *err = path + ": No such file or directory"; return false; }
-  char hdr[512];
-  if (!fgets(hdr, sizeof(hdr), y->f) || strncmp(hdr, "YUV4MPEG2", 9)) { *err = path + ": Invalid data found when processing input (not Y4M)"; return false; }
-  y->hdr_len = (long)strlen(hdr);
-  std::string cs = "420jpeg";
-  for (char *t = strtok(hdr, " \n"); t; t = strtok(nullptr, " \n")) {
-    if (t[0] == 'W') y->w = atoi(t + 1);
-    else if (t[0] == 'H') y->h = atoi(t + 1);
-    else if (t[0] == 'F') sscanf(t + 1, "%d:%d", &y->fps_n, &y->fps_d);
-    else if (t[0] == 'C') cs = t + 1;
-  }
-  if (cs.rfind("420p10", 0) == 0) y->bd = 10;
-  else if (cs.rfind("420", 0) == 0 && cs.find("p1") == std::string::npos) y->bd = 8;
-  else { *err = "Invalid argument: unsupported Y4M colourspace " + cs + " (4:2:0 8/10-bit only)"; return false; }
-  if (y->w < 8 || y->h < 8) { *err = "Invalid argument: frame size below 8x8"; return false; }
-  if (y->w > 4096 || y->h > 4096) { *err = "Invalid argument: frames above 4096x4096 need more than 64 tile rows / columns"; return false; }
-  if (y->fps_n <= 0 || y->fps_d <= 0) { y->fps_n = 30; y->fps_d = 1; }
-  // Y4M 4:2:0 planes of a w x h picture: w * h luma and two ceil(w / 2) * ceil(h / 2) chroma planes
-  y->frame_bytes = ((size_t)y->w * y->h + 2 * (size_t)((y->w + 1) / 2) * ((y->h + 1) / 2)) * (y->bd == 8 ? 1 : 2);
-  struct stat st;
-  if (fstat(fileno(y->f), &st)) { *err = path + ": cannot stat"; return false; }
-  y->nframes = (long)((st.st_size - y->hdr_len) / (off_t)(6 + y->frame_bytes));   // "FRAME\n" + planes
-  return true;
-}
-// frame idx -> the three planes of the CODED size cw x ch (the true size rounded up to 8: the last column / row replicated into
-// the padding); pread, so the segments of a batch are read by threads of their own (a single thread copies ~5 GB/s out of the
-// page cache: 215 frames/s at 4K 10-bit, one eighth of what the GPU takes).  false on a malformed or truncated frame.
-bool y4m_read(const Y4m *y, long idx, int cw, int ch, unsigned char *Y, unsigned char *U, unsigned char *V) {
-  const int fd = fileno(y->f);
-  off_t off = (off_t)y->hdr_len + (off_t)idx * (off_t)(6 + y->frame_bytes);
-  auto rd = [&](void *dst, size_t n) {
-    unsigned char *p = (unsigned char *)dst;
-    while (n) {
-      const ssize_t k = pread(fd, p, n, off);
-      if (k <= 0) return false;
-      p += k; off += k; n -= (size_t)k;
-    }
-    return true;
-  };
-  char tag[6];
-  if (!rd(tag, 6) || memcmp(tag, "FRAME\n", 6)) return false;
-  const size_t bps = y->bd == 8 ? 1 : 2;
-  // one plane: pw x ph samples in the file -> dw x dh in memory
-  auto plane = [&](unsigned char *dst, int pw, int ph, int dw, int dh) {
-    if (pw == dw) { if (!rd(dst, (size_t)pw * ph * bps)) return false; }
-    else
-      for (int r = 0; r < ph; r++) {
-        unsigned char *row = dst + (size_t)r * dw * bps;
-        if (!rd(row, (size_t)pw * bps)) return false;
-        for (int c = pw; c < dw; c++) memcpy(row + (size_t)c * bps, row + (size_t)(pw - 1) * bps, bps);
-      }
-    for (int r = ph; r < dh; r++) memcpy(dst + (size_t)r * dw * bps, dst + (size_t)(ph - 1) * dw * bps, (size_t)dw * bps);
-    return true;
-  };
-  return plane(Y, y->w, y->h, cw, ch) && plane(U, (y->w + 1) / 2, (y->h + 1) / 2, cw / 2, ch / 2) && plane(V, (y->w + 1) / 2, (y->h + 1) / 2, cw / 2, ch / 2);
-}
-
-}  // namespace
 
 void DescribeSessionFrame(const av1mi_gop_frame &fr, int seg, int width, int height, int bit_depth, SessionFrameDesc *d, int visible_width, int visible_height) {
   const av1mi_frame_params &p = fr.params;
@@ -121,24 +53,44 @@ void DescribeSessionFrame(const av1mi_gop_frame &fr, int seg, int width, int hei
   if (fr.lev_y) { f.lev_y = fr.lev_y + o * 64; f.lev_u = fr.lev_u + o * 16; f.lev_v = fr.lev_v + o * 16; }     // absent when the tiles were coded on the GPU
 }
 
+bool SessionTemporalUnit(const av1mi_gop_frame &fr, int seg, int width, int height, int bit_depth, int visible_width, int visible_height,
+                         bool with_sequence_header, int threads, std::vector<uint8_t> *out, std::string *err) {
+  SessionFrameDesc desc;
+  DescribeSessionFrame(fr, seg, width, height, bit_depth, &desc, visible_width, visible_height);
+  std::string werr;
+  if (fr.tile_size) {      // tiles coded on the GPU: frame header + tile group around them
+    const uint32_t *sz = fr.tile_size + (size_t)seg * fr.tiles_per_frame;
+    size_t off = 0;
+    for (size_t i = 0; i < (size_t)seg * fr.tiles_per_frame; i++) off += fr.tile_size[i];
+    std::vector<uint8_t> frame;
+    if (!av1::frame_obu_from_tiles(desc.f, fr.tile_payload + off, sz, fr.tiles_per_frame, &frame, &werr)) { if (err) *err = "bitstream assembly: " + werr; return false; }
+    *out = av1::temporal_delimiter_obu();
+    if (with_sequence_header) { const std::vector<uint8_t> sh = av1::sequence_header_obu(av1::sequence_params(desc.f)); out->insert(out->end(), sh.begin(), sh.end()); }
+    out->insert(out->end(), frame.begin(), frame.end());
+    return true;
+  }
+  if (!av1::temporal_unit(desc.f, with_sequence_header, threads, out, &werr)) { if (err) *err = "bitstream writer: " + werr; return false; }
+  return true;
+}
+
 int RunBackend(const BackendJob &job, std::string *err) {
   av1mi_ctx *ctx = nullptr;
   if (av1mi_device_count() <= 0 || av1mi_open(job.device, &ctx) != AV1MI_OK) {
     *err = "Error: no usable HIP device for the av1mi backend (device " + std::to_string(job.device) + ")";
     return -1;
   }
-  Y4m y;
+  Y4mSource y;
   av1mi_gop *gop = nullptr;
   StreamSink sink;
   int code = 0;
 #define CHK(call)                                                                                   \
   do { int rc_ = (call); if (rc_ != AV1MI_OK) { *err = std::string(#call) + ": " + av1mi_last_error(ctx); code = 2; goto done; } } while (0)
-  if (!y4m_open(job.input, &y, err)) { code = 1; goto done; }
-  if (y.nframes <= 0) { *err = job.input + ": Invalid data found when processing input (no frames)"; code = 1; goto done; }
+  if (!y.open(job.input, err)) { code = 1; goto done; }
   {
     const int G = job.gop, w = (y.w + 7) & ~7, h = (y.h + 7) & ~7;       // the coded size; y.w x y.h is what a decoder outputs
-    const long ngops = (y.nframes + G - 1) / G;
-    const int S = (int)std::min<long>(std::max(job.segments, 1), ngops);
+    int S = std::max(job.segments, 1);
+    if (y.known_frames() >= 0) S = (int)std::max<long>(1, std::min<long>(S, (y.known_frames() + G - 1) / G));      // no more segments than the file has GOPs
+    long total_frames = 0;
     const int threads = job.threads > 0 ? job.threads : (int)std::max(1u, std::thread::hardware_concurrency());
     const size_t bps = y.bd == 8 ? 1 : 2, fy = (size_t)w * h * bps, fc = fy / 4;
     av1mi_gop_config cfg;
@@ -151,12 +103,16 @@ int RunBackend(const BackendJob &job, std::string *err) {
     av1::SequenceParams sp; sp.width = y.w; sp.height = y.h; sp.bit_depth = y.bd;
     if (!sink.open(job.output, sp, y.fps_n, y.fps_d, err)) { code = 1; goto done; }
     std::vector<std::vector<std::vector<uint8_t>>> units((size_t)S);   // [segment][frame] temporal units of the batch in flight
-    SessionFrameDesc desc;
     const int lag = av1mi_gop_max_in_flight() - 1;      // batches the GPU holds while the host works on the oldest
-    for (long g0 = 0; g0 < ngops; g0 += S) {
+    for (long g0 = 0;; g0 += S) {
       for (auto &u : units) u.clear();
-      // frames of this batch of GOPs that exist: segment s, position t -> file frame (g0 + s) * G + t
-      auto exists = [&](int s, int t) { return g0 + s < ngops && (g0 + s) * G + t < y.nframes; };
+      // the next GROUP of S GOPs: a file is read in place, a stream one group ahead of the encoder (y4m.hpp)
+      const long have_frames = y.prepare(g0 * G, (long)S * G, err);
+      if (have_frames < 0) { code = 1; goto done; }
+      if (have_frames == 0) break;
+      total_frames += have_frames;
+      // frames of this group that exist: segment s, position t -> frame s * G + t of the group
+      auto exists = [&](int s, int t) { return (long)s * G + t < have_frames; };
       int T = 0;
       for (int t = 0; t < G; t++) if (exists(0, t)) T = t + 1;
       av1mi_gop_frame fr;
@@ -167,19 +123,8 @@ int RunBackend(const BackendJob &job, std::string *err) {
       auto assemble = [&](int t) -> bool {         // the collected batch t -> temporal units (frame header + tile group, or the host coder)
         for (int s = 0; s < S; s++) {
           if (!exists(s, t)) continue;
-          DescribeSessionFrame(fr, s, w, h, y.bd, &desc, cfg.visible_width, cfg.visible_height);
           std::vector<uint8_t> tu;
-          std::string werr;
-          if (fr.tile_size) {      // tiles coded on the GPU: frame header + tile group around them
-            const uint32_t *sz = fr.tile_size + (size_t)s * fr.tiles_per_frame;
-            size_t off = 0;
-            for (size_t i = 0; i < (size_t)s * fr.tiles_per_frame; i++) off += fr.tile_size[i];
-            std::vector<uint8_t> frame;
-            if (!av1::frame_obu_from_tiles(desc.f, fr.tile_payload + off, sz, fr.tiles_per_frame, &frame, &werr)) { *err = "bitstream assembly: " + werr; return false; }
-            tu = av1::temporal_delimiter_obu();
-            if (t == 0) { const std::vector<uint8_t> sh = av1::sequence_header_obu(sp); tu.insert(tu.end(), sh.begin(), sh.end()); }
-            tu.insert(tu.end(), frame.begin(), frame.end());
-          } else if (!av1::temporal_unit(desc.f, t == 0, threads, &tu, &werr)) { *err = "bitstream writer: " + werr; return false; }
+          if (!SessionTemporalUnit(fr, s, w, h, y.bd, cfg.visible_width, cfg.visible_height, t == 0, threads, &tu, err)) return false;
           units[(size_t)s].push_back(std::move(tu));
         }
         return true;
@@ -196,9 +141,14 @@ int RunBackend(const BackendJob &job, std::string *err) {
         if (av1mi_gop_acquire_input(gop, &py, &pu, &pv) != AV1MI_OK) { *err = std::string("av1mi_gop_acquire_input: ") + av1mi_last_error(ctx); return false; }
         reads.ok.assign((size_t)S, 1);
         for (int s = 0; s < S; s++) {
-          if (!exists(s, t)) continue;     // a shorter last GOP / fewer GOPs than segments: the slot keeps stale pixels, its output is dropped
+          if (!exists(s, t)) {
+            // a shorter last GOP / fewer GOPs than segments: the slot is coded (the batch is one launch) and its output dropped.  Flat
+            // planes, not whatever the pinned buffer held: stale pixels could cost the GPU coder's tile capacity for the whole batch
+            memset((unsigned char *)py + fy * s, 0, fy); memset((unsigned char *)pu + fc * s, 0, fc); memset((unsigned char *)pv + fc * s, 0, fc);
+            continue;
+          }
           reads.th.emplace_back([&, s, t, py, pu, pv]() {
-            reads.ok[(size_t)s] = y4m_read(&y, (g0 + s) * G + t, w, h, (unsigned char *)py + fy * s, (unsigned char *)pu + fc * s, (unsigned char *)pv + fc * s);
+            reads.ok[(size_t)s] = y.read((long)s * G + t, w, h, (unsigned char *)py + fy * s, (unsigned char *)pu + fc * s, (unsigned char *)pv + fc * s);
           });
         }
         return true;
@@ -218,12 +168,13 @@ int RunBackend(const BackendJob &job, std::string *err) {
         for (size_t t = 0; t < units[(size_t)s].size(); t++)
           if (!sink.write(units[(size_t)s][t], t == 0, err)) { code = 1; goto done; }
     }
+    if (total_frames == 0) { *err = job.input + ": Invalid data found when processing input (no frames)"; code = 1; goto done; }
     if (!sink.close(err)) { code = 1; goto done; }
   }
 done:
   sink.abort();
   if (gop) av1mi_gop_close(gop);
-  if (y.f) fclose(y.f);
+  y.close();
   av1mi_close(ctx);
   return code;
 #undef CHK

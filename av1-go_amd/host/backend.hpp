@@ -14,4 +14,7 @@ int RunBackend(const BackendJob &job, std::string *err);
 // visible_*: the true frame size when width x height is it rounded up to 8 (0 = the coded size)
 void DescribeSessionFrame(const av1mi_gop_frame &fr, int seg, int width, int height, int bit_depth, SessionFrameDesc *d, int visible_width = 0,
                           int visible_height = 0);
+// the temporal unit of segment `seg` of a collected batch: GPU-coded tiles wrapped, or the symbols coded on `threads` host threads
+bool SessionTemporalUnit(const av1mi_gop_frame &fr, int seg, int width, int height, int bit_depth, int visible_width, int visible_height,
+                         bool with_sequence_header, int threads, std::vector<uint8_t> *out, std::string *err);
 }

@@ -4,6 +4,8 @@
 #include "daemon.hpp"
 #include "av1_bitstream.hpp"
 #include "mux.hpp"
+#include "y4m.hpp"
+#include "backend.hpp"
 
 using namespace av1mi_host;
 
@@ -19,6 +21,32 @@ int av1mi_host_transcode_args(const char *in, const char *out, int has_video, in
   if (ok) for (size_t i = 0; i < a.size(); i++) j += (i ? "\n" : "") + a[i]; else j = err;
   strncpy(buf, j.c_str(), cap - 1); buf[cap - 1] = 0;
   return ok ? (int)a.size() : -1;
+}
+// Y4mSource (y4m.hpp) alone, for the CPU tests: reads the whole input in groups of `group` frames the way RunBackend does and
+// returns the number of frames (-1 on error, text in err); *sum = a checksum over every frame's padded planes; *seekable = the mode
+long long av1mi_host_y4m_scan(const char *path, int group, unsigned long long *sum, int *seekable, int *geometry, char *err, int cap) {
+  Y4mSource y;
+  std::string e;
+  auto fail = [&]() { strncpy(err, e.c_str(), cap - 1); err[cap - 1] = 0; return -1LL; };
+  if (!y.open(path, &e)) return fail();
+  const int cw = (y.w + 7) & ~7, ch = (y.h + 7) & ~7;
+  const size_t bps = y.bd == 8 ? 1 : 2;
+  std::vector<unsigned char> Y((size_t)cw * ch * bps), U((size_t)cw * ch * bps / 4), V((size_t)cw * ch * bps / 4);
+  unsigned long long acc = 1469598103934665603ull;
+  long long total = 0;
+  for (long first = 0;; first += group) {
+    const long n = y.prepare(first, group, &e);
+    if (n < 0) return fail();
+    if (n == 0) break;
+    for (long i = 0; i < n; i++) {
+      if (!y.read(i, cw, ch, Y.data(), U.data(), V.data())) { e = "read failed"; return fail(); }
+      for (const auto *pl : { &Y, &U, &V }) for (unsigned char b : *pl) acc = (acc ^ b) * 1099511628211ull;
+    }
+    total += n;
+  }
+  *sum = acc; *seekable = y.seekable() ? 1 : 0;
+  geometry[0] = y.w; geometry[1] = y.h; geometry[2] = y.bd; geometry[3] = y.fps_n; geometry[4] = y.fps_d;
+  return total;
 }
 // The drop-in for internal/ffmpeg/transcode.go:194 `RunTranscode(ffmpegPath string, args []string) (int, error)`: what the cgo
 // shim of INTEGRATION.md binds.  Returns the exit code of the contract (0 = output written, -1 = could not run, else failed);
@@ -62,6 +90,18 @@ long long av1mi_obu_write_temporal_unit(const av1mi_obu_frame *f, int with_seque
   }
   if ((long long)b.size() <= cap && out) memcpy(out, b.data(), b.size());
   return (long long)b.size();
+}
+// One segment of a collected session batch -> its temporal unit (include/av1mi_host.h; backend.cpp SessionTemporalUnit)
+long long av1mi_session_temporal_unit(const av1mi_gop_frame *fr, int seg, int width, int height, int bit_depth, int visible_width, int visible_height,
+                                      int with_sequence_header, int threads, uint8_t *out, long long cap, char *err, int errcap) {
+  std::vector<uint8_t> b; std::string e;
+  if (!fr || seg < 0 || seg >= fr->segments) e = "bad batch / segment";
+  else if (SessionTemporalUnit(*fr, seg, width, height, bit_depth, visible_width, visible_height, with_sequence_header != 0, threads, &b, &e)) {
+    if ((long long)b.size() <= cap && out) memcpy(out, b.data(), b.size());
+    return (long long)b.size();
+  }
+  if (err && errcap > 0) { strncpy(err, e.c_str(), errcap - 1); err[errcap - 1] = 0; }
+  return -1;
 }
 // The general block description (av1_blockstream.cpp): any block / transform size, any partition
 long long av1mi_obu_write_blocks_temporal_unit(const av1mi_obu_blocks *f, int with_sequence_header, uint8_t *out, long long cap, char *err, int errcap) {

@@ -15,6 +15,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include "av1mi.h"
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -71,6 +73,15 @@ long long av1mi_obu_write_temporal_unit(const av1mi_obu_frame *f, int with_seque
  * pointers are not read), payloads = the frame's ntiles finished tile payloads back to back in raster order, sizes[t] bytes each. */
 long long av1mi_obu_assemble_temporal_unit(const av1mi_obu_frame *f, const uint8_t *payloads, const uint32_t *sizes, int ntiles,
                                            int with_sequence_header, uint8_t *out, long long cap, char *err, int errcap);
+
+/* A collected GOP-session batch (av1mi.h av1mi_gop_collect) -> the temporal unit of its segment `seg`: what a caller that drives the
+ * session itself does per frame (INTEGRATION.md §3 collect()).  Fills the frame description from fr->params and the restoration
+ * decision fr->lr_on, then either wraps the segment's GPU-coded tile payloads (fr->tile_size != NULL) or entropy-codes its symbols
+ * on `threads` host threads (gpu_entropy = 0, or a batch the GPU coder gave back).  width x height: the CODED size of the session;
+ * visible_*: the true size when that is not a multiple of 8 (0 = the coded size).  Same return convention as above. */
+long long av1mi_session_temporal_unit(const av1mi_gop_frame *fr, int seg, int width, int height, int bit_depth, int visible_width,
+                                      int visible_height, int with_sequence_header, int threads, uint8_t *out, long long cap, char *err,
+                                      int errcap);
 
 /* ---- general block structure: every AV1 block size 4x4 .. 64x64 (incl. the 1:2 / 2:1 / 1:4 / 4:1 shapes), every partition type,
  * every transform size (TX_MODE_LARGEST or TX_MODE_SELECT) and all 16 transform types, the four interpolation filters.  It is

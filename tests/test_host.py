@@ -122,6 +122,52 @@ def _ebml_blocks(data):
     return frames, codec_private
 
 
+def _scan(host, path, group):
+    host.av1mi_host_y4m_scan.restype = C.c_longlong
+    host.av1mi_host_y4m_scan.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_ulonglong), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int]
+    s, seek, geo, err = C.c_ulonglong(), C.c_int(), (C.c_int * 5)(), C.create_string_buffer(512)
+    n = host.av1mi_host_y4m_scan(str(path).encode(), group, C.byref(s), C.byref(seek), geo, err, 512)
+    return n, s.value, seek.value, list(geo), err.value.decode()
+
+
+def test_y4m_source_file_stream_and_header_variants(host, tmp_path):
+    """the backend's input (host/y4m.cpp): a seekable file is read in place, a FIFO sequentially one group ahead — same frames; a
+    header longer than any fixed buffer and FRAME lines with parameters are legal Y4M; a truncated frame is an error"""
+    import threading
+    w, h, n, bd = 70, 38, 7, 10
+    plain = tmp_path / "plain.y4m"
+    _write_y4m(str(plain), w, h, n, bd)
+    n0, sum0, seek0, geo, _ = _scan(host, plain, 4)
+    assert (n0, seek0, geo) == (n, 1, [w, h, bd, 30, 1])
+    assert _scan(host, plain, 3)[:2] == (n, sum0) and _scan(host, plain, 64)[:2] == (n, sum0)      # the group size does not matter
+    # the same frames with a 3000-byte header comment and per-frame parameters: not seekable in place, read sequentially
+    raw = plain.read_bytes()
+    hdr_end = raw.index(b"\n") + 1
+    fb = (len(raw) - hdr_end) // n
+    fancy = tmp_path / "fancy.y4m"
+    with open(fancy, "wb") as f:
+        f.write(raw[:hdr_end - 1] + b" X" + b"c" * 3000 + b" XYSCSS=420P10\n")
+        for i in range(n):
+            f.write(b"FRAME Ip\n" + raw[hdr_end + i * fb + 6:hdr_end + (i + 1) * fb])
+    assert _scan(host, fancy, 4)[:3] == (n, sum0, 0)
+    # a FIFO fed by another thread
+    fifo = tmp_path / "in.fifo"
+    os.mkfifo(fifo)
+    t = threading.Thread(target=lambda: open(fifo, "wb").write(raw))
+    t.start()
+    assert _scan(host, fifo, 2)[:3] == (n, sum0, 0)
+    t.join()
+    # errors
+    cut = tmp_path / "cut.y4m"
+    cut.write_bytes(raw[:-100])
+    nn, _, _, _, err = _scan(host, cut, 4)
+    assert nn == -1 and "truncated" in err
+    bad = tmp_path / "bad.y4m"
+    bad.write_bytes(b"YUV4MPEG2 W64 H64 F30:1 C444\nFRAME\n")
+    assert _scan(host, bad, 4)[0] == -1 and "colourspace" in _scan(host, bad, 4)[4]
+    assert "No such file" in _scan(host, tmp_path / "nope.y4m", 4)[4]
+
+
 def test_run_transcode_fails_cleanly_without_gpu_or_input(host, tmp_path, av1mi):
     buf = C.create_string_buffer(1024)
     args = "\n".join(["-i", str(tmp_path / "missing.y4m"), "-global_quality:v:0", "25", str(tmp_path / "o.mkv")])
@@ -250,6 +296,46 @@ def test_run_transcode_of_a_source_whose_size_is_not_a_multiple_of_8(host, tmp_p
         assert host.av1mi_host_run_transcode(args.encode(), buf, 1024) == 0
         data = mkv.read_bytes()
         assert b"\xb0" + bytes([0x81, vw]) in data and b"\xba" + bytes([0x81, vh]) in data      # PixelWidth / PixelHeight = the true size
+
+
+@pytest.mark.gpu
+def test_the_public_drop_in_and_streamed_input(host, tmp_path):
+    """(1) av1mi_run_transcode(argc, argv, err, cap) itself — the symbol the cgo shim of INTEGRATION.md binds in place of
+    internal/ffmpeg/transcode.go:194 (call site internal/daemon/daemon.go:101) — with the argv TranscodeArgs builds; (2) the same
+    clip piped into the command line (`cat clip.y4m | av1mi_transcode -i - ...`, transcode.go:68 `-i`) and through a FIFO gives the
+    file the in-place reader gives, byte for byte (streams are read one group of GOPs ahead: y4m.cpp)"""
+    import subprocess
+    import threading
+    w, h, n, q, gop = 136, 72, 11, 110, 4
+    src = tmp_path / "clip.y4m"
+    _write_y4m(str(src), w, h, n)
+    host.av1mi_run_transcode.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.c_char_p, C.c_size_t]
+    _, argv = _args(host, str(src), str(tmp_path / "clip.av1-tmp.mkv"), height=h)      # the reference's own argv
+    argv = argv[:-1] + ["-g", str(gop), "-av1mi_segments", "2", argv[-1]]
+    argv[argv.index("-global_quality:v:0") + 1] = str(q)
+    arr = (C.c_char_p * len(argv))(*[a.encode() for a in argv])
+    err = C.create_string_buffer(1024)
+    assert host.av1mi_run_transcode(len(argv), arr, err, 1024) == 0 and err.value == b""
+    ref = (tmp_path / "clip.av1-tmp.mkv").read_bytes()
+    assert len(_ebml_blocks(ref)[0]) == n
+    bad = (C.c_char_p * 3)(b"-i", str(tmp_path / "missing.y4m").encode(), str(tmp_path / "x.mkv").encode())
+    assert host.av1mi_run_transcode(3, bad, err, 1024) == 1 and err.value.startswith(b"av1mi failed with exit code 1: ") and not (tmp_path / "x.mkv").exists()
+    cli = os.path.join(os.path.dirname(HOST), "av1mi_transcode")
+    tail = ["-global_quality:v:0", str(q), "-g", str(gop), "-av1mi_segments", "2"]
+    out = tmp_path / "piped.mkv"
+    with open(src, "rb") as f:
+        r = subprocess.run([cli, "-i", "-"] + tail + [str(out)], stdin=f, capture_output=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert out.read_bytes() == ref
+    fifo, out2 = tmp_path / "in.fifo", tmp_path / "fifo.mkv"
+    os.mkfifo(fifo)
+    t = threading.Thread(target=lambda: open(fifo, "wb").write(src.read_bytes()))
+    t.start()
+    argv2 = ["-i", str(fifo)] + tail + [str(out2)]
+    arr2 = (C.c_char_p * len(argv2))(*[a.encode() for a in argv2])
+    assert host.av1mi_run_transcode(len(argv2), arr2, err, 1024) == 0, err.value
+    t.join()
+    assert out2.read_bytes() == ref
 
 
 def sys_path_synth():
