@@ -22,7 +22,8 @@ def test_host_library_exports_every_declared_symbol():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(root, "include", "av1mi_host.h")).read(), flags=re.S)
     names = sorted(set(re.findall(r"\b(av1mi_[a-z0-9_]+)\s*\(", hdr)))
-    assert names == ["av1mi_obu_assemble_temporal_unit", "av1mi_obu_write_blocks_temporal_unit", "av1mi_obu_write_temporal_unit", "av1mi_run_transcode"]
+    assert names == ["av1mi_obu_assemble_temporal_unit", "av1mi_obu_write_blocks_temporal_unit", "av1mi_obu_write_temporal_unit", "av1mi_run_transcode",
+                     "av1mi_session_temporal_unit"]
     lib = av1stream.lib()
     for n in names:
         assert hasattr(lib, n), "libav1mi_host.so does not export %s" % n
