@@ -87,7 +87,7 @@ class LrDecideJob(C.Structure):
 class GopConfig(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("bit_depth", C.c_int), ("base_q_idx", C.c_int), ("gop_length", C.c_int),
                 ("segments", C.c_int), ("search_range", C.c_int), ("gpu_entropy", C.c_int), ("visible_width", C.c_int),
-                ("visible_height", C.c_int)]
+                ("visible_height", C.c_int), ("coder_streams", C.c_int)]
 
 
 class FrameParams(C.Structure):
@@ -120,11 +120,11 @@ def _view(ptr, shape, dtype):
 class GopSession:
     """av1mi_gop_* (include/av1mi.h): closed GOPs in lockstep, policy and PCIe plumbing inside the library."""
 
-    def __init__(self, ctx, width, height, bit_depth, base_q_idx, gop_length, segments=1, search_range=8, gpu_entropy=0, visible=None):
+    def __init__(self, ctx, width, height, bit_depth, base_q_idx, gop_length, segments=1, search_range=8, gpu_entropy=0, visible=None, coder_streams=0):
         """visible: the true (width, height) when width x height is it rounded up to 8 (the caller replicates the source edge)"""
         self.ctx, self.w, self.h, self.bd, self.segments = ctx, width, height, bit_depth, segments
         vw, vh = visible if visible is not None else (0, 0)
-        self.cfg = GopConfig(width, height, bit_depth, base_q_idx, gop_length, segments, search_range, gpu_entropy, vw, vh)
+        self.cfg = GopConfig(width, height, bit_depth, base_q_idx, gop_length, segments, search_range, gpu_entropy, vw, vh, coder_streams)
         self.g = C.c_void_p()
         ctx.lib.av1mi_gop_open.argtypes = [C.c_void_p, C.POINTER(GopConfig), C.POINTER(C.c_void_p)]
         ctx._chk(ctx.lib.av1mi_gop_open(ctx.h, C.byref(self.cfg), C.byref(self.g)))

@@ -57,7 +57,7 @@ void frame_params(int q, int bd, int frame_type, av1mi_frame_params *p) {
   memcpy(p->lr_unit_y, wy, 8); memcpy(p->lr_unit_uv, wc, 8);
 }
 
-enum { kSlots = 3 };      // batches in flight: one uploading / in the block pipeline, one in the coder, one being read by the host
+enum { kSlots = 3, kFallbacksToHostMode = 3 };      // batches in flight: one uploading / in the block pipeline, one in the coder, one being read by the host
 
 struct Slot {
   void *h_src[3] = { nullptr, nullptr, nullptr };       // pinned
@@ -96,6 +96,7 @@ struct av1mi_gop {
   size_t ent_cap = 0; int tiles = 0;           // GPU entropy coding: payload capacity of a batch, tiles per frame
   long submitted = 0, collected = 0;           // batches
   long fallbacks = 0;                          // batches the GPU coder could not hold (handed out as symbols instead)
+  bool symbols_always = false;                 // after kFallbacksToHostMode of them: the symbols go down with every batch, beside the filters
   int gop_pos = 0;
   bool acquired = false;
   int coder_streams = 0;                       // 0 = tokenizer + chains on the side stream, range coder on the back stream (default)
@@ -232,13 +233,14 @@ int av1mi_gop_open(av1mi_ctx *ctx, const av1mi_gop_config *cfg, av1mi_gop **out)
                            cfg->width, cfg->height);
   if (cfg->bit_depth != 8 && cfg->bit_depth != 10) return av1mi::ctx_fail(ctx, AV1MI_E_INVAL, "bit depth %d not supported (8 or 10)", cfg->bit_depth);
   if (cfg->base_q_idx < 1 || cfg->base_q_idx > 255 || cfg->gop_length < 1 || cfg->segments < 1 || cfg->segments > 4096 || cfg->search_range < 0 ||
-      cfg->search_range > 15 || cfg->gpu_entropy < 0 || cfg->gpu_entropy > 2)
+      cfg->search_range > 15 || cfg->gpu_entropy < 0 || cfg->gpu_entropy > 2 || cfg->coder_streams < 0 || cfg->coder_streams > 2)
     return av1mi::ctx_fail(ctx, AV1MI_E_INVAL, "bad base_q_idx / gop_length / segments / search_range / gpu_entropy");
   if (cfg->gpu_entropy && (cfg->width > 4096 || cfg->height > 4096)) return av1mi::ctx_fail(ctx, AV1MI_E_INVAL, "the AV1 tile coder takes frames up to 4096x4096");
   if ((size_t)cfg->height * cfg->segments > 65535u * 8u) return av1mi::ctx_fail(ctx, AV1MI_E_INVAL, "segments x height too large for one launch");
   av1mi_gop *g = new (std::nothrow) av1mi_gop();
   if (!g) return AV1MI_E_NOMEM;
   g->ctx = ctx; g->cfg = *cfg;
+  g->coder_streams = cfg->coder_streams;
   if (const char *e = getenv("AV1MI_CODER_STREAMS")) g->coder_streams = !strcmp(e, "side") ? 1 : !strcmp(e, "main") ? 2 : 0;
   const int rc = setup(g);
   if (rc != AV1MI_OK) { av1mi_gop_close(g); return rc; }
@@ -348,7 +350,7 @@ static int submit_batch(av1mi_gop *g, int frame_type, const void *const *dev_src
   s.frame_type = frame_type;
   // symbols -> pinned host memory, beside the filters.  Not when the GPU codes the tiles (gpu_entropy == 1): the host then needs
   // the payloads only (and a fifth busy stream would share a hardware queue with one of the other four)
-  s.symbols_down = c.gpu_entropy != 1;
+  s.symbols_down = c.gpu_entropy != 1 || g->symbols_always;
   if (s.symbols_down) {
     G_HIP(hipStreamWaitEvent(g->down, s.kernel_done, 0));
     for (int p = 0; p < 3; p++) G_HIP(hipMemcpyAsync(s.h_lev[p], s.d_lev[p], (p ? g->nc : g->ny) * 2, hipMemcpyDeviceToHost, g->down));
@@ -478,14 +480,19 @@ int av1mi_gop_collect(av1mi_gop *g, av1mi_gop_frame *out) {
       // lost: its symbols are still in the slot's device buffers (the next kernel that overwrites them is kSlots submits away),
       // so they are downloaded now and handed out like in host mode: tile_size stays NULL, the caller entropy-codes this batch.
       if (!s.symbols_down) {
-        for (int p = 0; p < 3; p++) {
-          if (!s.h_lev[p]) G_TRY(host_alloc(g, &s.h_lev[p], (p ? g->nc : g->ny) * 2));
-          G_HIP(hipMemcpyAsync(s.h_lev[p], s.d_lev[p], (p ? g->nc : g->ny) * 2, hipMemcpyDeviceToHost, g->down));
-        }
+        // the pinned mirrors of the levels exist only once a batch has needed them: all slots' at the first fallback (pinning memory
+        // stalls the device), not one slot at a time in the middle of later batches
+        for (Slot &o : g->slot)
+          for (int p = 0; p < 3; p++)
+            if (!o.h_lev[p]) G_TRY(host_alloc(g, &o.h_lev[p], (p ? g->nc : g->ny) * 2));
+        for (int p = 0; p < 3; p++) G_HIP(hipMemcpyAsync(s.h_lev[p], s.d_lev[p], (p ? g->nc : g->ny) * 2, hipMemcpyDeviceToHost, g->down));
         G_TRY(download_modes(g, s, g->down));
         G_HIP(hipStreamSynchronize(g->down));
         symbols(true);
       }
+      // content the GPU coder cannot hold tends to stay that way: from the third such batch on the symbols are sent down with every
+      // batch, beside the filters (as in host mode), instead of after the coder has given the batch back
+      if (g->fallbacks + 1 >= kFallbacksToHostMode) g->symbols_always = true;
       g->fallbacks++;
     } else {
       out->tiles_per_frame = g->tiles; out->tile_size = (const uint32_t *)s.h_tile_size; out->tile_payload = (const uint8_t *)s.h_ent_out; out->payload_bytes = total;

@@ -597,6 +597,40 @@ def main():
         copy_gbps = copy_bandwidth(ctx)
         out["roofline"]["copy_GBps_measured"] = copy_gbps
         out["roofline"]["frac_of_measured_copy"] = ach / copy_gbps
+        out["roofline"]["note"] = ("measured in the timed region, where the tile coder's kernels run on their own streams BESIDE the block pipeline: a "
+                                   "kernel's event span includes the time it shares the chip with them (the spans of all kinds add up to more than the "
+                                   "wall time).  `kernels_isolated` / `roofline_isolated` are the same kernels with the coder serialised on the main "
+                                   "stream (av1mi_gop_config.coder_streams = 2): every kernel alone on the GPU")
+        # the same batches once more with every kernel ALONE on the GPU: the numbers to judge a kernel by
+        iso = av1mi.GopSession(ctx, W, H, bd, args.qindex, gop, segs, gpu_entropy=1, coder_streams=2)
+        for rep in range(2):
+            if rep == 1:
+                ctx.prof_reset()
+                ctx.prof_enable(True)
+            for t in range(batches):
+                iso.submit_device(d_src[t][0], d_src[t][1], d_src[t][2], 0 if (t == 0 or not gop_wl) else 1)
+                if iso.pending() > lag:
+                    iso.collect()
+            while iso.pending():
+                iso.collect()
+            ctx.sync()
+        ctx.prof_enable(False)
+        iprof = ctx.prof_get()
+        iso.close()
+        ikb = {"intra_pipeline": 1 if gop_wl else batches, "inter_pipeline": batches - 1, "me_integer": batches - 1}
+        out["kernels_isolated"] = {k: {"launches": n, "ms_per_batch": ms / (ikb.get(k, batches) or batches),
+                                       "algorithmic_GBps": alg[k] / (ms / (ikb.get(k, batches) or batches) * 1e-3) / 1e9 if k in alg else None}
+                                   for k, (n, ms) in iprof.items()}
+        idom = max(iprof, key=lambda k: iprof[k][1])
+        n_i, ms_i = iprof[idom]
+        nb_i = ikb.get(idom, batches) or batches
+        ach_i = alg[idom] * nb_i / n_i / (ms_i / n_i * 1e-3) / 1e9
+        tr_i, valu_i, tsrc_i = pmc_numbers(idom, args.workload, segs)
+        out["roofline_isolated"] = {"kernel": idom, "bound": "hbm", "achieved": ach_i, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach_i / HBM_PEAK_GBPS,
+                                    "traffic": tr_i, "traffic_source": tsrc_i, "algorithmic_bytes_per_launch": alg[idom] * nb_i / n_i,
+                                    "avg_launch_ms": ms_i / n_i, "launches": n_i, "valu_issue_frac": valu_i,
+                                    "serialised_ms_per_batch": sum(ms / (ikb.get(k, batches) or batches) for k, (n, ms) in iprof.items() if k != "intra_pipeline") ,
+                                    "what": "one step with the coder serialised on the main stream: the dominant kernel by summed device time and its roofline"}
         # whole pipeline: (9b + 2) S per inter frame, (8b + 2) S per intra-only frame, times the job's frame rate
         per_frame = ((9 * b_ + 2) if gop_wl else (8 * b_ + 2)) * (W * H * 3 // 2)
         out["pipeline_roofline"] = {"algorithmic_bytes_per_frame": per_frame, "achieved": per_frame * fps / world / 1e9, "peak": HBM_PEAK_GBPS,

@@ -348,6 +348,11 @@ typedef struct av1mi_gop_config {
    * deblocked, CDEF and restored planes is replicated into the padding (what the decoder's clamps at lastX / lastY, 7.11.3.4, and
    * PlaneEndX / PlaneEndY, 7.17, read), the restoration units of the tile syntax are counted on the true size. */
   int visible_width, visible_height;
+  /* gpu_entropy != 0: where the tile coder runs.  0 (default) = tokenizer + chains on a side stream and the range coder on a third,
+   * beside the next batches' block pipeline (fastest); 1 = the whole coder on one side stream; 2 = on the main stream, serialised
+   * behind the filters — slower, but every kernel then runs ALONE on the GPU: the arrangement for per-kernel measurements (bench.py
+   * `kernels_isolated`, rocprofv3 passes).  The environment variable AV1MI_CODER_STREAMS = split | side | main overrides it. */
+  int coder_streams;
 } av1mi_gop_config;
 
 /* Frame-header parameters chosen by the session's policy for one frame (non-normative encoder choices; the bitstream carries

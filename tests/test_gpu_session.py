@@ -127,7 +127,9 @@ def test_session_api_misuse_is_reported(ctx, av1mi):
 
 
 @pytest.mark.parametrize("w,h,bd,q,gop,segs", [(192, 128, 8, 110, 4, 2), (136, 72, 10, 40, 3, 3), (64, 64, 8, 30, 2, 1), (328, 184, 8, 200, 2, 5),
-                                                (640, 360, 10, 50, 2, 1), (1920, 1080, 8, 128, 3, 2), (3840, 2160, 10, 128, 3, 2)])
+                                                (640, 360, 10, 50, 2, 1), (1920, 1080, 8, 128, 3, 2), (3840, 2160, 10, 128, 3, 2),
+                                                # the reference's own quality points (DetermineQuality, transcode.go:157-165: 24 at 1080p, 23 at 2160p)
+                                                (1920, 1080, 8, 24, 2, 2), (3840, 2160, 10, 23, 2, 2)])
 def test_gpu_tile_entropy_coder_bytes_equal_the_host_writer(ctx, av1mi, w, h, bd, q, gop, segs):
     """K9 for the real syntax: the AV1 tile entropy coder on the GPU (csrc/av1_entropy_kernels.hip).  With gpu_entropy = 2 the
     session hands out both the symbols and the GPU-coded tile payloads: the temporal unit assembled around the GPU's payloads
@@ -151,6 +153,7 @@ def test_gpu_tile_entropy_coder_bytes_equal_the_host_writer(ctx, av1mi, w, h, bd
             s.submit()
             fr = s.collect()
             refs.append(s.download_reference())
+            assert "tile_size" in fr, "the GPU coder gave the batch back (capacity) at q %d" % q
             assert fr["tiles_per_frame"] == ((w + 63) // 64) * ((h + 63) // 64) and (fr["tile_size"] > 0).all()
             for sgi in range(segs):
                 host = av1stream.session_frame_unit(w, h, bd, fr, sgi, threads=8)
@@ -218,6 +221,48 @@ def test_gpu_coder_capacity_overflow_falls_back_to_the_host(ctx, av1mi):
         assert len(got) == 2 and all((got[t][i] == refs[t][i]).all() for t in range(2) for i in range(3))
     finally:
         s.close()
+
+
+@pytest.mark.skipif(not D.available(), reason="no dav1d in this image")
+def test_fallback_with_three_batches_in_flight_at_the_reference_quality(ctx, av1mi):
+    """white noise at the reference's quality 24 overflows the GPU coder's per-block records in EVERY batch.  Pipelined
+    (submit t + 2 before collect t) the session hands every batch out as symbols — the first ones after the coder gave them back,
+    later ones downloaded beside the filters (the session switches after three fallbacks) — and the host-coded stream equals the
+    one of a host-mode session byte for byte and decodes in dav1d to the GPU's reference frames."""
+    import av1stream
+    w, h, bd, q, gop, segs, n = 256, 192, 8, 24, 3, 2, 9
+    rng = np.random.default_rng(7)
+    src = [rng.integers(0, 256, (n, segs * h // d, w // d)).astype(np.uint8) for d in (1, 2, 2)]
+
+    def run(mode, lag):
+        s = av1mi.GopSession(ctx, w, h, bd, q, gop, segs, gpu_entropy=mode)
+        units, refs, gave_back = [[] for _ in range(segs)], [], 0
+        try:
+            for t in range(n):
+                for dst, a in zip(s.input_planes(), src):
+                    dst[:] = a[t]
+                s.submit()
+                if lag == 0:
+                    refs.append(s.download_reference())
+                while s.pending() > lag or (t == n - 1 and s.pending()):
+                    fr = s.collect()
+                    gave_back += "tile_size" not in fr
+                    for sgi in range(segs):
+                        units[sgi].append(av1stream.session_frame_unit_gpu(w, h, bd, fr, sgi) if "tile_size" in fr else av1stream.session_frame_unit(w, h, bd, fr, sgi, threads=4))
+            return units, refs, gave_back, s.entropy_fallbacks()
+        finally:
+            s.close()
+
+    host, refs, _, _ = run(0, 0)
+    gpu, _, gave_back, fallbacks = run(1, 2)
+    assert gave_back == n and fallbacks == n, (gave_back, fallbacks)
+    assert gpu == host
+    for sgi in range(segs):
+        got = D.decode(b"".join(host[sgi]))
+        assert len(got) == n
+        for t in range(n):
+            for i, hh in ((0, h), (1, h // 2), (2, h // 2)):
+                assert (got[t][i] == refs[t][i][sgi * hh:(sgi + 1) * hh]).all()
 
 
 @pytest.mark.parametrize("mode", [1, 0])

@@ -338,6 +338,32 @@ def test_the_public_drop_in_and_streamed_input(host, tmp_path):
     assert out2.read_bytes() == ref
 
 
+@pytest.mark.gpu
+def test_run_transcode_of_dense_content_at_the_reference_quality(host, tmp_path):
+    """noise at quality 25 (DetermineQuality of a sub-1080p source) overflows the GPU coder; RunTranscode must still write
+    the stream — the same bytes as with the host coder — also when the file holds fewer GOPs than segments x groups (absent segments
+    are coded from flat planes and dropped), and dav1d must decode every frame"""
+    import dav1d_ref as D
+    w, h, n, gop = 192, 128, 8, 3
+    rng = np.random.default_rng(3)
+    src = tmp_path / "noise.y4m"
+    with open(src, "wb") as f:
+        f.write(("YUV4MPEG2 W%d H%d F30:1 Ip A1:1 C420jpeg\n" % (w, h)).encode())
+        for i in range(n):
+            f.write(b"FRAME\n" + rng.integers(0, 256, w * h * 3 // 2).astype(np.uint8).tobytes())
+    buf = C.create_string_buffer(1024)
+    outs = []
+    for ge in ("1", "0"):
+        out = tmp_path / ("noise%s.obu" % ge)
+        args = "\n".join(["-i", str(src), "-global_quality:v:0", str(host.av1mi_host_determine_quality(h)), "-g", str(gop), "-av1mi_segments", "2",
+                          "-av1mi_gpu_entropy", ge, str(out)])
+        assert host.av1mi_host_run_transcode(args.encode(), buf, 1024) == 0, buf.value
+        outs.append(out.read_bytes())
+    assert outs[0] == outs[1]
+    if D.available():
+        assert len(D.decode(outs[0])) == n
+
+
 def sys_path_synth():
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(HOST), ".."))
