@@ -379,6 +379,9 @@ struct av1mi_av1ent_state {      // per-context scratch of the coder, grown on d
   hipEvent_t lists_ready[2] = { nullptr, nullptr }, lists_free[2] = { nullptr, nullptr };
   bool free_recorded[2] = { false, false };
   unsigned long jobs = 0;
+  av1mi::Av1EntLaunch pending[2];             // a job whose back half (range coder, scan, gather) is still to be launched (av1_entropy_back)
+  uint64_t *pending_total[2] = { nullptr, nullptr };
+  bool pending_valid[2] = { false, false };
   size_t last_tiles = 0;          // tiles of the most recent job (av1mi_av1_entropy_last_list_words)
   uint16_t *d_image[2][4] = {};   // [key][qcat] default CDF images
   int image_words[2] = { 0, 0 };
@@ -403,8 +406,9 @@ uint32_t av1mi_av1_entropy_slot_bytes(void) { return 16384; }
 
 }  // extern "C"
 
-int av1mi::av1_entropy_submit(av1mi_ctx *ctx, const av1mi_av1_entropy_job *j, hipStream_t front, hipStream_t back) {
-  if (!ctx) return AV1MI_E_INVAL;
+int av1mi::av1_entropy_front(av1mi_ctx *ctx, const av1mi_av1_entropy_job *j, hipStream_t front, int *ticket) {
+  if (!ctx || !ticket) return AV1MI_E_INVAL;
+  *ticket = -1;
   if (!j) return av1mi::ctx_fail(ctx, AV1MI_E_INVAL, "null job");
   if (hipSetDevice(av1mi::ctx_device(ctx)) != hipSuccess) return av1mi::ctx_fail(ctx, AV1MI_E_DEVICE, "hipSetDevice failed");
   if (j->width <= 0 || j->height <= 0 || (j->width & 7) || (j->height & 7) || j->width > 4096 || j->height > 4096)
@@ -459,19 +463,37 @@ int av1mi::av1_entropy_submit(av1mi_ctx *ctx, const av1mi_av1_entropy_job *j, hi
   L.cdf_image = st->d_image[key][qcat]; L.cdf_words = st->image_words[key]; L.tab = st->tab[key];
   L.lr_on_frame = j->d_lr_on;
 #define E_HIP(call) do { const hipError_t e_ = (call); if (e_ != hipSuccess) return av1mi::ctx_fail(ctx, AV1MI_E_DEVICE, "%s: %s", #call, hipGetErrorString(e_)); } while (0)
-  const bool two = front != back;
-  if (two) {
-    for (hipEvent_t *ev : { &st->lists_ready[par], &st->lists_free[par] }) if (!*ev) E_HIP(hipEventCreateWithFlags(ev, hipEventDisableTiming));
-    if (st->free_recorded[par]) E_HIP(hipStreamWaitEvent(front, st->lists_free[par], 0));      // the coder of two jobs ago still reads this set of lists
-  }
+  for (hipEvent_t *ev : { &st->lists_ready[par], &st->lists_free[par] }) if (!*ev) E_HIP(hipEventCreateWithFlags(ev, hipEventDisableTiming));
+  if (st->free_recorded[par]) E_HIP(hipStreamWaitEvent(front, st->lists_free[par], 0));      // the coder of two jobs ago still reads this set of lists
   E_HIP(hipMemsetAsync(j->d_total, 0, 16, front));
   E_HIP(av1mi::launch_av1_front(ctx, L, front));
-  if (two) { E_HIP(hipEventRecord(st->lists_ready[par], front)); E_HIP(hipStreamWaitEvent(back, st->lists_ready[par], 0)); }
+  E_HIP(hipEventRecord(st->lists_ready[par], front));
+  st->pending[par] = L; st->pending_total[par] = j->d_total; st->pending_valid[par] = true;
+  *ticket = par;
+  return AV1MI_OK;
+}
+
+// the back half of the job `ticket` names (av1_entropy_front): the serial range coder, the scan of the tile sizes, the gather
+int av1mi::av1_entropy_back(av1mi_ctx *ctx, int ticket, hipStream_t back) {
+  if (!ctx || ticket < 0 || ticket > 1) return AV1MI_E_INVAL;
+  av1mi_av1ent_state *st = av1mi::ctx_av1ent(ctx);
+  if (!st || !st->pending_valid[ticket]) return av1mi::ctx_fail(ctx, AV1MI_E_INVAL, "no entropy job pending under this ticket");
+  const av1mi::Av1EntLaunch &L = st->pending[ticket];
+  const size_t nt = (size_t)L.sbr_n * L.sbc_n * L.nframes;
+  E_HIP(hipStreamWaitEvent(back, st->lists_ready[ticket], 0));
   E_HIP(av1mi::launch_av1_back(ctx, L, back));
-  E_HIP(hipMemcpyAsync(j->d_total, L.tile_off + nt, 8, hipMemcpyDeviceToDevice, back));      // total bytes next to the status: tile_off[nt]
-  if (two) { E_HIP(hipEventRecord(st->lists_free[par], back)); st->free_recorded[par] = true; }
+  E_HIP(hipMemcpyAsync(st->pending_total[ticket], L.tile_off + nt, 8, hipMemcpyDeviceToDevice, back));      // total bytes next to the status: tile_off[nt]
+  E_HIP(hipEventRecord(st->lists_free[ticket], back)); st->free_recorded[ticket] = true;
+  st->pending_valid[ticket] = false;
 #undef E_HIP
   return AV1MI_OK;
+}
+
+int av1mi::av1_entropy_submit(av1mi_ctx *ctx, const av1mi_av1_entropy_job *j, hipStream_t front, hipStream_t back) {
+  int ticket = -1;
+  const int rc = av1_entropy_front(ctx, j, front, &ticket);
+  if (rc != AV1MI_OK || ticket < 0) return rc;      // (an empty job has no back half)
+  return av1_entropy_back(ctx, ticket, back);
 }
 
 extern "C" {

@@ -144,6 +144,10 @@ hipStream_t ctx_back_stream(av1mi_ctx *ctx);
 // coder + scan + gather on `back` (the same stream, or a second one: the lists are double-buffered, so the front half of the next
 // job runs beside the back half of this one)
 int av1_entropy_submit(av1mi_ctx *ctx, const struct av1mi_av1_entropy_job *j, hipStream_t front, hipStream_t back);
+// ... and the halves on their own: the back half of a job may be launched later (the session defers the range coder of batch t behind
+// the filters of batch t + 1 on the main stream); at most two jobs' back halves can be outstanding (the list sets)
+int av1_entropy_front(av1mi_ctx *ctx, const struct av1mi_av1_entropy_job *j, hipStream_t front, int *ticket);
+int av1_entropy_back(av1mi_ctx *ctx, int ticket, hipStream_t back);
 // accessors of the opaque context for translation units other than capi.hip (gop_session.hip)
 hipStream_t ctx_stream(av1mi_ctx *ctx);
 int ctx_device(av1mi_ctx *ctx);

@@ -76,6 +76,7 @@ struct Slot {
   hipEvent_t ent_done = nullptr;      // coder + download of sizes / total finished (side stream)
   bool ent_pending = false;
   bool symbols_down = false;          // this batch's symbols were sent to the host at submit time
+  int ent_ticket = -1;                // >= 0: the range coder of this batch is still to be launched (coder_streams 3: av1_entropy_back)
 };
 
 }  // namespace
@@ -233,7 +234,7 @@ int av1mi_gop_open(av1mi_ctx *ctx, const av1mi_gop_config *cfg, av1mi_gop **out)
                            cfg->width, cfg->height);
   if (cfg->bit_depth != 8 && cfg->bit_depth != 10) return av1mi::ctx_fail(ctx, AV1MI_E_INVAL, "bit depth %d not supported (8 or 10)", cfg->bit_depth);
   if (cfg->base_q_idx < 1 || cfg->base_q_idx > 255 || cfg->gop_length < 1 || cfg->segments < 1 || cfg->segments > 4096 || cfg->search_range < 0 ||
-      cfg->search_range > 15 || cfg->gpu_entropy < 0 || cfg->gpu_entropy > 2 || cfg->coder_streams < 0 || cfg->coder_streams > 2)
+      cfg->search_range > 15 || cfg->gpu_entropy < 0 || cfg->gpu_entropy > 2 || cfg->coder_streams < 0 || cfg->coder_streams > 3)
     return av1mi::ctx_fail(ctx, AV1MI_E_INVAL, "bad base_q_idx / gop_length / segments / search_range / gpu_entropy");
   if (cfg->gpu_entropy && (cfg->width > 4096 || cfg->height > 4096)) return av1mi::ctx_fail(ctx, AV1MI_E_INVAL, "the AV1 tile coder takes frames up to 4096x4096");
   if ((size_t)cfg->height * cfg->segments > 65535u * 8u) return av1mi::ctx_fail(ctx, AV1MI_E_INVAL, "segments x height too large for one launch");
@@ -241,7 +242,7 @@ int av1mi_gop_open(av1mi_ctx *ctx, const av1mi_gop_config *cfg, av1mi_gop **out)
   if (!g) return AV1MI_E_NOMEM;
   g->ctx = ctx; g->cfg = *cfg;
   g->coder_streams = cfg->coder_streams;
-  if (const char *e = getenv("AV1MI_CODER_STREAMS")) g->coder_streams = !strcmp(e, "side") ? 1 : !strcmp(e, "main") ? 2 : 0;
+  if (const char *e = getenv("AV1MI_CODER_STREAMS")) g->coder_streams = !strcmp(e, "side") ? 1 : !strcmp(e, "main") ? 2 : !strcmp(e, "defer") ? 3 : 0;
   const int rc = setup(g);
   if (rc != AV1MI_OK) { av1mi_gop_close(g); return rc; }
   *out = g;
@@ -295,6 +296,22 @@ int av1mi_gop_acquire_input(av1mi_gop *g, void **y, void **u, void **v) {
   *y = s.h_src[0]; *u = s.h_src[1]; *v = s.h_src[2];
   g->acquired = true;
   return AV1MI_OK;
+}
+
+// the coder's results of a slot -> its pinned mirrors, then ent_done (on the stream the range coder ran on)
+static int entropy_results(av1mi_gop *g, Slot &s, hipStream_t st) {
+  const int S = g->cfg.segments;
+  G_HIP(hipMemcpyAsync(s.h_tile_size, s.d_tile_size, (size_t)g->tiles * S * 4, hipMemcpyDeviceToHost, st));
+  G_HIP(hipMemcpyAsync(s.h_total, s.d_total, 16, hipMemcpyDeviceToHost, st));
+  G_HIP(hipMemcpyAsync(s.h_lr_on, s.d_lr_on, (size_t)S * 3, hipMemcpyDeviceToHost, st));
+  G_HIP(hipEventRecord(s.ent_done, st));
+  return AV1MI_OK;
+}
+// the deferred back half of a slot's entropy job (coder_streams 3)
+static int finish_entropy(av1mi_gop *g, Slot &s, hipStream_t st) {
+  G_TRY(av1mi::av1_entropy_back(g->ctx, s.ent_ticket, st));
+  s.ent_ticket = -1;
+  return entropy_results(g, s, st);
 }
 
 // one batch through the block pipeline, the filters and (gpu_entropy) the tile coder; dev_src: the source planes in device memory
@@ -426,11 +443,17 @@ static int submit_batch(av1mi_gop *g, int frame_type, const void *const *dev_src
     ej.visible_width = g->vw; ej.visible_height = g->vh;
     memcpy(ej.lr_unit_y, P.lr_unit_y, 8); memcpy(ej.lr_unit_uv, P.lr_unit_uv, 8);
     ej.d_out = (uint8_t *)s.h_ent_out; ej.out_cap = g->ent_cap; ej.d_tile_size = (uint32_t *)s.d_tile_size; ej.d_total = (uint64_t *)s.d_total;
-    G_TRY(av1mi::av1_entropy_submit(g->ctx, &ej, side, back));
-    G_HIP(hipMemcpyAsync(s.h_tile_size, s.d_tile_size, (size_t)g->tiles * S * 4, hipMemcpyDeviceToHost, back));
-    G_HIP(hipMemcpyAsync(s.h_total, s.d_total, 16, hipMemcpyDeviceToHost, back));
-    G_HIP(hipMemcpyAsync(s.h_lr_on, s.d_lr_on, (size_t)S * 3, hipMemcpyDeviceToHost, back));
-    G_HIP(hipEventRecord(s.ent_done, back));
+    if (g->coder_streams == 3) {
+      // tokenizer + chains of THIS batch on the side stream; the range coder of the PREVIOUS batch on the main stream, behind this
+      // batch's filters: two queues that are both busy all the time ((pipeline + filters + coder) beside (tokenizer + chains)) instead of
+      // a short one and a long one
+      G_TRY(av1mi::av1_entropy_front(g->ctx, &ej, side, &s.ent_ticket));
+      Slot &prev = g->slot[(g->submitted + kSlots - 1) % kSlots];
+      if (g->submitted > 0 && prev.ent_ticket >= 0) G_TRY(finish_entropy(g, prev, main));
+    } else {
+      G_TRY(av1mi::av1_entropy_submit(g->ctx, &ej, side, back));
+      G_TRY(entropy_results(g, s, back));
+    }
     s.ent_pending = true;
   }
   g->last = (int)(g->submitted % kSlots);
@@ -471,6 +494,7 @@ int av1mi_gop_collect(av1mi_gop *g, av1mi_gop_frame *out) {
   };
   if (s.symbols_down) symbols(true);
   if (g->cfg.gpu_entropy) {
+    if (s.ent_ticket >= 0) G_TRY(finish_entropy(g, s, av1mi::ctx_stream(g->ctx)));      // no later batch came to carry it (coder_streams 3)
     G_HIP(hipEventSynchronize(s.ent_done));
     const uint64_t total = ((const uint64_t *)s.h_total)[0], status = ((const uint64_t *)s.h_total)[1];
     // the payloads are already here: k_av1_gather wrote them into the slot's pinned buffer (a copy enqueued NOW would queue
