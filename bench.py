@@ -338,10 +338,11 @@ def pmc_numbers(kind, workload, frames_per_launch):
             corr = (prof.get("calibration") or {}).get("read_correction_8B_per_lane") or 2.0
             traffic = (d["fetch_bytes_uncorrected"] * corr + d["write_bytes"]) * frames_per_launch / prof["frames_per_step"]
             sq = d.get("sq_counters_per_launch") or {}
-            # SQ_INSTS_VALU counts wave instructions over the whole chip; a SIMD issues one VALU instruction per 4 cycles at most
+            # SQ_INSTS_VALU counts wave instructions over the whole chip; a SIMD issues one VALU instruction per 4 cycles at most.
+            # GRBM_GUI_ACTIVE comes back summed over the 8 XCDs (k_inter_pipe: 14.6 M "cycles" for a 0.83 ms kernel): / 8 = kernel cycles
             valu = None
             if sq.get("SQ_INSTS_VALU") and sq.get("GRBM_GUI_ACTIVE"):
-                valu = sq["SQ_INSTS_VALU"] * 4.0 / (1024.0 * sq["GRBM_GUI_ACTIVE"])
+                valu = sq["SQ_INSTS_VALU"] * 4.0 / (1024.0 * sq["GRBM_GUI_ACTIVE"] / 8.0)
             return traffic, valu, os.path.relpath(path, ROOT)
     return None, None, None
 

@@ -3,9 +3,11 @@
 # (no sys/hip/hsa tracing), as the pool requires.  Output: gpurun_out/pmc_<tag>/*counter_collection.csv
 set -u
 TAG=${1:-r01}
-ARGS=${2:-"--steps 3 --warmup 1 --no-cpu-baseline --no-e2e"}
+ARGS=${2:-"--steps 1 --warmup 1 --no-cpu-baseline --no-e2e"}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
+# per-kernel counters want every kernel ALONE on the GPU: the coder serialised behind the filters on the main stream
+export AV1MI_CODER_STREAMS=${AV1MI_CODER_STREAMS:-main}
 i=0
 for CTRS in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS" \
             "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" \
