@@ -59,7 +59,7 @@ class IntraJob(C.Structure):
                 ("d_src_y", C.c_void_p), ("d_src_u", C.c_void_p), ("d_src_v", C.c_void_p),
                 ("d_rec_y", C.c_void_p), ("d_rec_u", C.c_void_p), ("d_rec_v", C.c_void_p),
                 ("d_lev_y", C.c_void_p), ("d_lev_u", C.c_void_p), ("d_lev_v", C.c_void_p),
-                ("d_modes_y", C.c_void_p), ("d_modes_uv", C.c_void_p)]
+                ("d_modes_y", C.c_void_p), ("d_modes_uv", C.c_void_p), ("open_loop", C.c_int)]
 
 
 class InterJob(C.Structure):
@@ -427,7 +427,7 @@ class Context:
     def intra_encode(self, job):
         self._chk(self.lib.av1mi_intra_encode(self.h, C.byref(job)))
 
-    def intra_encode_arrays(self, Y, U, V, bd, bs, qindex):
+    def intra_encode_arrays(self, Y, U, V, bd, bs, qindex, open_loop=False):
         """convenience for tests: Y/U/V are [frames, h, w] arrays; returns dict of outputs like the oracle's"""
         dt = np.uint8 if bd == 8 else np.uint16
         Y, U, V = (np.ascontiguousarray(a, dt) for a in (Y, U, V))
@@ -435,6 +435,7 @@ class Context:
         nb = (h // bs) * (w // bs)
         bufs = {}
         job = IntraJob(w, h, bd, nf, qindex, bs, w, w // 2)
+        job.open_loop = 1 if open_loop else 0
         for name, arr in (("src_y", Y), ("src_u", U), ("src_v", V)):
             bufs[name] = self.to_device(arr)
         for name, n in (("rec_y", Y.nbytes), ("rec_u", U.nbytes), ("rec_v", V.nbytes), ("lev_y", Y.size * 2), ("lev_u", U.size * 2),

@@ -70,6 +70,7 @@ struct IntraPipeLaunch {
   uint8_t *modes_y, *modes_uv;
   int w, h, stride_y, stride_uv, bd, nframes, dc_q, ac_q;
   int dc_quant, ac_quant;   // (1 << 16) / step (libaom quant_fp): computed once by the host, see block_code.hpp
+  int open_loop;            // 1: the modes are decided on the source first (k_intra_modes), the chain predicts each block once
 };
 hipError_t launch_intra_pipe(const IntraPipeLaunch &L, int bs, hipStream_t s);
 

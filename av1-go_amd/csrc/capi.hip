@@ -534,6 +534,7 @@ int av1mi_intra_encode(av1mi_ctx *ctx, const av1mi_intra_job *j) {
   L.w = j->width; L.h = j->height; L.stride_y = j->stride_y; L.stride_uv = j->stride_uv; L.bd = j->bit_depth; L.nframes = j->nframes;
   L.dc_q = av1mi_dc_q(j->qindex, j->bit_depth); L.ac_q = av1mi_ac_q(j->qindex, j->bit_depth);
   L.dc_quant = (1 << 16) / L.dc_q; L.ac_quant = (1 << 16) / L.ac_q;
+  L.open_loop = j->open_loop ? 1 : 0;
   { ProfScope ps(ctx, AV1MI_K_INTRA_PIPE); HIP_TRY(ctx, av1mi::launch_intra_pipe(L, j->block_size, ctx->stream)); }
   return AV1MI_OK;
 }

@@ -101,6 +101,7 @@ struct av1mi_gop {
   int gop_pos = 0;
   bool acquired = false;
   int coder_streams = 0;                       // 0 = tokenizer + chains on the side stream, range coder on the back stream (default)
+  int intra_open_loop = 0;                     // key frames: open-loop mode decision (k_intra_modes) instead of the closed-loop search
   std::vector<void *> dev_allocs, host_allocs;
 };
 
@@ -242,6 +243,7 @@ int av1mi_gop_open(av1mi_ctx *ctx, const av1mi_gop_config *cfg, av1mi_gop **out)
   if (!g) return AV1MI_E_NOMEM;
   g->ctx = ctx; g->cfg = *cfg;
   g->coder_streams = cfg->coder_streams;
+  if (const char *e = getenv("AV1MI_INTRA_OPEN_LOOP")) g->intra_open_loop = atoi(e) ? 1 : 0;
   if (const char *e = getenv("AV1MI_CODER_STREAMS")) g->coder_streams = !strcmp(e, "side") ? 1 : !strcmp(e, "main") ? 2 : !strcmp(e, "defer") ? 3 : 0;
   const int rc = setup(g);
   if (rc != AV1MI_OK) { av1mi_gop_close(g); return rc; }
@@ -347,6 +349,7 @@ static int submit_batch(av1mi_gop *g, int frame_type, const void *const *dev_src
     j.d_rec_y = g->d_rec[0]; j.d_rec_u = g->d_rec[1]; j.d_rec_v = g->d_rec[2];
     j.d_lev_y = (int16_t *)s.d_lev[0]; j.d_lev_u = (int16_t *)s.d_lev[1]; j.d_lev_v = (int16_t *)s.d_lev[2];
     j.d_modes_y = (uint8_t *)s.d_modes[0]; j.d_modes_uv = (uint8_t *)s.d_modes[1];
+    j.open_loop = g->intra_open_loop;
     G_TRY(av1mi_intra_encode(g->ctx, &j));
   } else {
     av1mi_inter_job j;

@@ -71,10 +71,56 @@ template <typename ES> struct TileCtx {
 #define STAMP_ARGS
 #define STAMP_PASS
 #endif
-template <int B, int GW, typename Pix>
+// one of the 13 modes by its RUN-TIME number (the open-loop pipeline: the mode was decided beforehand, k_intra_modes).  The groups
+// of a wave take their cases one after the other; a case reads only its own group's edge arrays.
+template <int B, typename ES>
+__device__ __forceinline__ void pred_row_of_mode(int mode, const ES *edge, int lane, int bd, int n_top, int n_left, int filter_type, int *out) {
+  switch (mode) {
+#define AV1MI_CASE(M) case M: fast_pred_row<M, B, ES>(edge, lane, bd, n_top, n_left, filter_type, out); break;
+    AV1MI_CASE(DC_PRED) AV1MI_CASE(V_PRED) AV1MI_CASE(H_PRED) AV1MI_CASE(D45_PRED) AV1MI_CASE(D135_PRED) AV1MI_CASE(D113_PRED) AV1MI_CASE(D157_PRED)
+    AV1MI_CASE(D203_PRED) AV1MI_CASE(D67_PRED) AV1MI_CASE(SMOOTH_PRED) AV1MI_CASE(SMOOTH_V_PRED) AV1MI_CASE(SMOOTH_H_PRED)
+    default: fast_pred_row<PAETH_PRED, B, ES>(edge, lane, bd, n_top, n_left, filter_type, out); break;
+#undef AV1MI_CASE
+  }
+}
+
+// the 13 candidates (order == oracle/av1o_pipeline.c:intra_candidates, first minimum wins) scored by SAD against the source row s[]
+// over the GW lanes that share the decision; returns the mode, and the winning prediction row in bp[] when KEEP
+template <int B, int GW, typename ES, bool KEEP>
+__device__ __forceinline__ int search_modes(const ES *edge, int lane, int bd, int n_top, int n_left, int filter_type, const int *s, int *bp) {
+  int best = 0x7fffffff, best_mode = 0;
+  auto eval = [&](auto mode_tag) {
+    constexpr int MODE = decltype(mode_tag)::value;
+    int out[B];
+    fast_pred_row<MODE, B, ES>(edge, lane, bd, n_top, n_left, filter_type, out);
+    int sad = 0;
+#pragma unroll
+    for (int c = 0; c < B; c++) sad += abs(s[c] - out[c]);
+    sad = group_sum<GW>(sad);
+    const bool better = sad < best;
+    best = better ? sad : best; best_mode = better ? MODE : best_mode;
+    if constexpr (KEEP) {
+#pragma unroll
+      for (int c = 0; c < B; c++) bp[c] = better ? out[c] : bp[c];
+    }
+    // keep the scheduler from hoisting the next candidates' LDS reads above this one: that costs ~100 VGPRs and a wave per SIMD
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // candidate order == oracle/av1o_pipeline.c:intra_candidates (first minimum wins)
+  eval(std::integral_constant<int, DC_PRED>{});   eval(std::integral_constant<int, V_PRED>{});
+  eval(std::integral_constant<int, H_PRED>{});    eval(std::integral_constant<int, D45_PRED>{});
+  eval(std::integral_constant<int, D135_PRED>{}); eval(std::integral_constant<int, D113_PRED>{});
+  eval(std::integral_constant<int, D157_PRED>{}); eval(std::integral_constant<int, D203_PRED>{});
+  eval(std::integral_constant<int, D67_PRED>{});  eval(std::integral_constant<int, SMOOTH_PRED>{});
+  eval(std::integral_constant<int, PAETH_PRED>{}); eval(std::integral_constant<int, SMOOTH_V_PRED>{});
+  eval(std::integral_constant<int, SMOOTH_H_PRED>{});
+  return best_mode;
+}
+
+template <int B, int GW, typename Pix, bool OPEN = false>
 __device__ __forceinline__ int code_block(const TileCtx<Pix> &C, int lane, int bx, int by, int n, int n_top, int n_topright, int n_left,
                                           int n_bottomleft, int filter_type, int dc_q, int ac_q, int dc_quant, int ac_quant, const Pix *src_row,
-                                          Pix *rec_row, int16_t *lev_row STAMP_ARGS) {
+                                          Pix *rec_row, int16_t *lev_row, int mode_in STAMP_ARGS) {
   constexpr int bd = sizeof(Pix) == 1 ? 8 : 10;
   using ES = Pix;
   const int x = bx * B, y = by * B;
@@ -88,30 +134,13 @@ __device__ __forceinline__ int code_block(const TileCtx<Pix> &C, int lane, int b
   // all edge variants of the block in two LDS phases, then 13 compile-time-specialised predictions, no hand-offs
   fast_build<B>(C.edge, lane, bd, n_top, n_topright, n_left, n_bottomleft, filter_type, fetch);
   STAMP(1);
-  int best = 0x7fffffff, best_mode = 0;
-  auto eval = [&](auto mode_tag) {
-    constexpr int MODE = decltype(mode_tag)::value;
-    int out[B];
-    fast_pred_row<MODE, B, ES>((const ES *)C.edge, lane, bd, n_top, n_left, filter_type, out);
-    int sad = 0;
-#pragma unroll
-    for (int c = 0; c < B; c++) sad += abs(s[c] - out[c]);
-    sad = group_sum<GW>(sad);
-    const bool better = sad < best;
-    best = better ? sad : best; best_mode = better ? MODE : best_mode;
-#pragma unroll
-    for (int c = 0; c < B; c++) bp[c] = better ? out[c] : bp[c];
-    // keep the scheduler from hoisting the next candidates' LDS reads above this one: that costs ~100 VGPRs and a wave per SIMD
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  // candidate order == oracle/av1o_pipeline.c:intra_candidates (first minimum wins)
-  eval(std::integral_constant<int, DC_PRED>{});   eval(std::integral_constant<int, V_PRED>{});
-  eval(std::integral_constant<int, H_PRED>{});    eval(std::integral_constant<int, D45_PRED>{});
-  eval(std::integral_constant<int, D135_PRED>{}); eval(std::integral_constant<int, D113_PRED>{});
-  eval(std::integral_constant<int, D157_PRED>{}); eval(std::integral_constant<int, D203_PRED>{});
-  eval(std::integral_constant<int, D67_PRED>{});  eval(std::integral_constant<int, SMOOTH_PRED>{});
-  eval(std::integral_constant<int, PAETH_PRED>{}); eval(std::integral_constant<int, SMOOTH_V_PRED>{});
-  eval(std::integral_constant<int, SMOOTH_H_PRED>{});
+  int best_mode;
+  if constexpr (OPEN) {      // the mode is given (decided on the source, k_intra_modes): one prediction
+    best_mode = mode_in;
+    pred_row_of_mode<B, ES>(mode_in, (const ES *)C.edge, lane, bd, n_top, n_left, filter_type, bp);
+  } else {
+    best_mode = search_modes<B, GW, ES, true>((const ES *)C.edge, lane, bd, n_top, n_left, filter_type, s, bp);
+  }
   AV1MI_GROUP_SYNC();
   STAMP(2);
   int rec[B];
@@ -136,7 +165,58 @@ __device__ __forceinline__ int code_block(const TileCtx<Pix> &C, int lane, int b
   return best_mode;
 }
 
+// OPEN-LOOP MODE DECISION (av1mi_intra_job.open_loop, off by default): the 13 candidates of every block predicted from the SOURCE
+// frame's neighbours (edge filter type 0: the neighbours' modes are being decided at the same time), all blocks of all frames in
+// parallel — no tile is a serial chain here.  k_intra_pipe<.., OPEN> then walks the tiles with ONE prediction per block, from the
+// reconstruction, in the mode found here.  Same availability rules as the closed loop (tile = 64x64 superblock).
+// Cost in the oracle (av1o_set_intra_open_loop): +0.0 .. +0.3 % bytes up to q 128, +1 % at q 160, +3.5 % at q 200, PSNR within
+// 0.07 dB.  Gain, measured (round 3): 16 frames of 1080p 8-bit 0.885 -> 0.748 ms (k_intra_modes 0.37 of it), 12 frames of 4K 10-bit
+// 1.61 -> ~1.6 ms: the search is VALU work that this arrangement moves but does not remove, so the closed loop stays the default.
 template <int BS, typename Pix>
+__global__ __launch_bounds__(256) void k_intra_modes(IntraPipeLaunch L) {
+  constexpr int CS = BS / 2, N = 64 / BS, GPW = 256 / BS;
+  using ES = Pix;
+  constexpr int ELY = fast_edge_len(BS), ELC = fast_edge_len(CS);
+  constexpr int EDGE_N = ((ELY > 2 * ELC ? ELY : 2 * ELC) + 15) / 16 * 16 + 8;      // entries per group; + 8: groups start on different banks
+  __shared__ __attribute__((aligned(16))) ES edges[GPW * EDGE_N];
+  constexpr int bd = sizeof(Pix) == 1 ? 8 : 10;
+  const int grp = threadIdx.x / BS, lane = threadIdx.x % BS;
+  const int bw = L.w / BS, bh = L.h / BS;
+  const long long per = (long long)bw * bh, blk_all = (long long)blockIdx.x * GPW + grp;
+  if (blk_all >= per * L.nframes) return;
+  const int f = (int)(blk_all / per), blk = (int)(blk_all - f * per), fy = blk / bw, fx = blk - fy * bw;
+  const unsigned bx = fx % N, by = fy % N, k = morton2(bx, by);
+  const bool have_top = by > 0, have_left = bx > 0;
+  const bool have_tr = have_top && (int)bx + 1 < N && fx + 1 < bw && morton2(bx + 1, by - 1) < k;
+  const bool have_bl = have_left && (int)by + 1 < N && fy + 1 < bh && morton2(bx - 1, by + 1) < k;
+  ES *e = edges + grp * EDGE_N;
+  const int pl = lane / CS, cl = lane % CS;
+  {
+    const Pix *p = reinterpret_cast<const Pix *>(L.src[0]) + (size_t)f * L.h * L.stride_y + row_off(fy * BS, L.stride_y) + (size_t)(fx * BS);
+    const int st = L.stride_y;
+    // fast_build asks for row -1 / column -1 unconditionally and selects afterwards (harmless on the LDS lines of the closed loop):
+    // here those are global addresses, outside the allocation at the frame's first row — answer 0 without a load
+    auto fetch = [&](int yy, int xx) -> int { return ((yy >= 0 || have_top) && (xx >= 0 || have_left)) ? (int)p[(ptrdiff_t)yy * st + xx] : 0; };
+    int s[BS], bp[1];
+    load_row<BS>(p + (size_t)lane * st, s);
+    fast_build<BS>(e, lane, bd, have_top ? BS : 0, have_tr ? BS : 0, have_left ? BS : 0, have_bl ? BS : 0, 0, fetch);
+    const int m = search_modes<BS, BS, ES, false>(e, lane, bd, have_top ? BS : 0, have_left ? BS : 0, 0, s, bp);
+    if (lane == 0) L.modes_y[(size_t)f * per + blk] = (uint8_t)m;
+  }
+  AV1MI_GROUP_SYNC();
+  {
+    const Pix *p = reinterpret_cast<const Pix *>(L.src[1 + pl]) + (size_t)f * (L.h / 2) * L.stride_uv + row_off(fy * CS, L.stride_uv) + (size_t)(fx * CS);
+    const int st = L.stride_uv;
+    auto fetch = [&](int yy, int xx) -> int { return ((yy >= 0 || have_top) && (xx >= 0 || have_left)) ? (int)p[(ptrdiff_t)yy * st + xx] : 0; };
+    int s[CS], bp[1];
+    load_row<CS>(p + (size_t)cl * st, s);
+    fast_build<CS>(e + pl * ELC, cl, bd, have_top ? CS : 0, have_tr ? CS : 0, have_left ? CS : 0, have_bl ? CS : 0, 0, fetch);
+    const int m = search_modes<CS, BS, ES, false>(e + pl * ELC, cl, bd, have_top ? CS : 0, have_left ? CS : 0, 0, s, bp);
+    if (lane == 0) L.modes_uv[(size_t)f * per + blk] = (uint8_t)m;
+  }
+}
+
+template <int BS, typename Pix, bool OPEN = false>
 __global__ __launch_bounds__(256, BS == 8 ? 3 : 1) void k_intra_pipe(IntraPipeLaunch L) {
   constexpr int CS = BS / 2, N = 64 / BS, TPW = 256 / BS;
   using ES = Pix;                                      // LDS sample type: 1 byte for 8-bit content, 2 for 10-bit
@@ -189,6 +269,8 @@ __global__ __launch_bounds__(256, BS == 8 ? 3 : 1) void k_intra_pipe(IntraPipeLa
   unsigned long long av1mi_stamp_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, av1mi_stamp_last;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(av1mi_stamp_last)::"memory");
 #endif
+  // (Measured and dropped, round 3: loading the source rows one block ahead — 1.61 -> 1.92 ms for 12 4K 10-bit frames.  The chain
+  // is bound by the VALU work of the 13-candidate search, not by the latency of these loads.)
   for (unsigned k = 0; k < (unsigned)(N * N); k++) {
     unsigned bx = 0, by = 0;
 #pragma unroll
@@ -203,26 +285,18 @@ __global__ __launch_bounds__(256, BS == 8 ? 3 : 1) void k_intra_pipe(IntraPipeLa
     if (have_left) { const int m = row_my[by], mc = row_mc[by]; ft |= m >= 9 && m <= 11; ftc |= mc >= 9 && mc <= 11; }
     const size_t blk = row_off(fy, bw) + fx;        // 24-bit multiplies: see row_off
     {
-#ifdef AV1MI_EXP_TILED   // timing experiment only (wrong pixels): planes addressed as if block-tiled, 64 contiguous bytes per block
-      const size_t off = blk * BS * BS + lane * BS;
-#else
       const size_t off = row_off(fy * BS + lane, L.stride_y) + (size_t)(fx * BS);
-#endif
-      const int m = code_block<BS, BS, Pix>(Y, lane, bx, by, N, have_top ? BS : 0, have_tr ? BS : 0, have_left ? BS : 0,
-                                             have_bl ? BS : 0, ft, L.dc_q, L.ac_q, L.dc_quant, L.ac_quant, src_y + off, rec_y + off,
-                                             lev_y + blk * BS * BS + lane * BS STAMP_PASS);
-      if (lane == 0) { modes_y[blk] = (uint8_t)m; col_my[bx] = row_my[by] = (uint8_t)m; }
+      const int m = code_block<BS, BS, Pix, OPEN>(Y, lane, bx, by, N, have_top ? BS : 0, have_tr ? BS : 0, have_left ? BS : 0,
+                                                   have_bl ? BS : 0, ft, L.dc_q, L.ac_q, L.dc_quant, L.ac_quant, src_y + off, rec_y + off,
+                                                   lev_y + blk * BS * BS + lane * BS, OPEN ? (int)modes_y[blk] : 0 STAMP_PASS);
+      if (lane == 0) { if (!OPEN) modes_y[blk] = (uint8_t)m; col_my[bx] = row_my[by] = (uint8_t)m; }
     }
     {
-#ifdef AV1MI_EXP_TILED
-      const size_t off = blk * CS * CS + cl * CS;
-#else
       const size_t off = row_off(fy * CS + cl, L.stride_uv) + (size_t)(fx * CS);
-#endif
-      const int m = code_block<CS, BS, Pix>(Cp, cl, bx, by, N, have_top ? CS : 0, have_tr ? CS : 0, have_left ? CS : 0,
-                                             have_bl ? CS : 0, ftc, L.dc_q, L.ac_q, L.dc_quant, L.ac_quant, src_c + off, rec_c + off,
-                                             lev_c + blk * CS * CS + cl * CS STAMP_PASS);
-      if (lane == 0) { modes_uv[blk] = (uint8_t)m; col_mc[bx] = row_mc[by] = (uint8_t)m; }
+      const int m = code_block<CS, BS, Pix, OPEN>(Cp, cl, bx, by, N, have_top ? CS : 0, have_tr ? CS : 0, have_left ? CS : 0,
+                                                   have_bl ? CS : 0, ftc, L.dc_q, L.ac_q, L.dc_quant, L.ac_quant, src_c + off, rec_c + off,
+                                                   lev_c + blk * CS * CS + cl * CS, OPEN ? (int)modes_uv[blk] : 0 STAMP_PASS);
+      if (lane == 0) { if (!OPEN) modes_uv[blk] = (uint8_t)m; col_mc[bx] = row_mc[by] = (uint8_t)m; }
     }
     AV1MI_GROUP_SYNC();
     STAMP(5);
@@ -242,15 +316,28 @@ extern "C" int av1mi_debug_read_stamps(unsigned long long *out) {
 hipError_t launch_intra_pipe(const IntraPipeLaunch &L, int bs, hipStream_t s) {
   const long long tiles = (long long)L.nframes * ((L.w + 63) / 64) * ((L.h + 63) / 64);
   if (tiles <= 0) return hipSuccess;
+  if (bs != 8 && bs != 16) return hipErrorInvalidValue;
   const int tpw = 256 / bs;
   const dim3 grid((unsigned)((tiles + tpw - 1) / tpw));
+  if (L.open_loop) {      // the decision on the source, every block on its own; then the tiles' chains with one prediction per block
+    const long long blocks = (long long)L.nframes * (L.w / bs) * (L.h / bs);
+    const dim3 mgrid((unsigned)((blocks + tpw - 1) / tpw));
+    if (bs == 8) {
+      if (L.bd == 8) { hipLaunchKernelGGL((k_intra_modes<8, uint8_t>), mgrid, dim3(256), 0, s, L); hipLaunchKernelGGL((k_intra_pipe<8, uint8_t, true>), grid, dim3(256), 0, s, L); }
+      else { hipLaunchKernelGGL((k_intra_modes<8, uint16_t>), mgrid, dim3(256), 0, s, L); hipLaunchKernelGGL((k_intra_pipe<8, uint16_t, true>), grid, dim3(256), 0, s, L); }
+    } else {
+      if (L.bd == 8) { hipLaunchKernelGGL((k_intra_modes<16, uint8_t>), mgrid, dim3(256), 0, s, L); hipLaunchKernelGGL((k_intra_pipe<16, uint8_t, true>), grid, dim3(256), 0, s, L); }
+      else { hipLaunchKernelGGL((k_intra_modes<16, uint16_t>), mgrid, dim3(256), 0, s, L); hipLaunchKernelGGL((k_intra_pipe<16, uint16_t, true>), grid, dim3(256), 0, s, L); }
+    }
+    return hipGetLastError();
+  }
   if (bs == 8) {
     if (L.bd == 8) hipLaunchKernelGGL((k_intra_pipe<8, uint8_t>), grid, dim3(256), 0, s, L);
     else hipLaunchKernelGGL((k_intra_pipe<8, uint16_t>), grid, dim3(256), 0, s, L);
-  } else if (bs == 16) {
+  } else {
     if (L.bd == 8) hipLaunchKernelGGL((k_intra_pipe<16, uint8_t>), grid, dim3(256), 0, s, L);
     else hipLaunchKernelGGL((k_intra_pipe<16, uint16_t>), grid, dim3(256), 0, s, L);
-  } else return hipErrorInvalidValue;
+  }
   return hipGetLastError();
 }
 

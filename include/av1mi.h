@@ -257,6 +257,10 @@ typedef struct av1mi_intra_job {
   void *d_rec_y, *d_rec_u, *d_rec_v;       /* reconstruction (output) */
   int16_t *d_lev_y, *d_lev_u, *d_lev_v;    /* quantised levels (output): nframes * width*height (/4 for chroma) */
   uint8_t *d_modes_y, *d_modes_uv;         /* nframes * (width/bs)*(height/bs) each */
+  int open_loop;                           /* mode decision: 0 = closed loop (13 candidates predicted from the reconstruction, inside the
+                                              tile's serial chain), 1 = open loop (decided for all blocks at once from the SOURCE frame's
+                                              neighbours, then one prediction per block in the chain).  The GOP session codes its key frames closed
+                                              loop (AV1MI_INTRA_OPEN_LOOP=1 in the environment switches a session over, for measurements) */
 } av1mi_intra_job;
 int av1mi_intra_encode(av1mi_ctx *ctx, const av1mi_intra_job *job);
 

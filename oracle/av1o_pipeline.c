@@ -74,6 +74,12 @@ static unsigned morton(unsigned x, unsigned y) {
 static int px_get(const void *p, int bd, size_t i) { return bd == 8 ? ((const uint8_t *)p)[i] : ((const uint16_t *)p)[i]; }
 static void px_set(void *p, int bd, size_t i, int v) { if (bd == 8) ((uint8_t *)p)[i] = (uint8_t)v; else ((uint16_t *)p)[i] = (uint16_t)v; }
 
+/* EXPERIMENT switch (tests / measurements only): 1 = OPEN-LOOP mode decision — the 13 candidates are predicted from the SOURCE
+ * planes' neighbours (edge filter type 0), so that the decisions of all blocks are independent of each other; the chosen mode is
+ * then predicted from the reconstruction as always. */
+static int intra_open_loop = 0;
+void av1o_set_intra_open_loop(int on) { intra_open_loop = on; }
+
 /* encode one bs x bs block of nplanes planes sharing one mode (luma: 1 plane; chroma: U and V) */
 static int encode_block(int nplanes, const void *const *src, void *const *rec, int stride, int bd, int bs, int x, int y,
                         int n_top, int n_topright, int n_left, int n_bottomleft, int filter_type, int dc_q, int ac_q,
@@ -86,8 +92,8 @@ static int encode_block(int nplanes, const void *const *src, void *const *rec, i
     const int mode = intra_candidates[ci];
     long sad = 0;
     for (int p = 0; p < nplanes; p++) {
-      av1o_intra_predict((const char *)rec[p] + ((size_t)y * stride + x) * bps, stride, bd, bs, bs, mode, 0, 0, filter_type,
-                         n_top, n_topright, n_left, n_bottomleft, pred[0]);
+      av1o_intra_predict((const char *)(intra_open_loop ? src[p] : (const void *)rec[p]) + ((size_t)y * stride + x) * bps, stride, bd, bs, bs, mode, 0, 0,
+                         intra_open_loop ? 0 : filter_type, n_top, n_topright, n_left, n_bottomleft, pred[0]);
       for (int r = 0; r < bs; r++)
         for (int c = 0; c < bs; c++) sad += labs((long)px_get(src[p], bd, (size_t)(y + r) * stride + x + c) - pred[0][r * bs + c]);
     }

@@ -198,8 +198,15 @@ def deblock_plane(plane, bd, is_chroma, mi, sharpness=0, pass_mask=3):
     return out
 
 
-def intra_encode_frame(Y, U, V, bd, bs, qindex):
+def set_intra_open_loop(on):
+    """process-wide switch of the oracle's key-frame mode decision: open loop (candidates predicted from the SOURCE neighbours, edge
+    filter type 0) or closed loop (from the reconstruction); also used by the GOP oracle's key frames"""
+    lib().av1o_set_intra_open_loop(1 if on else 0)
+
+
+def intra_encode_frame(Y, U, V, bd, bs, qindex, open_loop=False):
     """oracle intra-only encoder loop; returns dict(rec_y, rec_u, rec_v, lev_y, lev_u, lev_v, modes_y, modes_uv)"""
+    set_intra_open_loop(open_loop)
     dt = np.uint8 if bd == 8 else np.uint16
     Y, U, V = (np.ascontiguousarray(a, dt) for a in (Y, U, V))
     h, w = Y.shape

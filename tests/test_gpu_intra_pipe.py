@@ -9,11 +9,11 @@ pytestmark = pytest.mark.gpu
 KEYS = ("modes_y", "modes_uv", "lev_y", "lev_u", "lev_v", "rec_y", "rec_u", "rec_v")
 
 
-def _check(ctx, O, w, h, nf, bd, bs, q, first=0):
+def _check(ctx, O, w, h, nf, bd, bs, q, first=0, open_loop=False):
     Y, U, V = synth.frames(w, h, nf, bd, first)
-    got = ctx.intra_encode_arrays(Y, U, V, bd, bs, q)
+    got = ctx.intra_encode_arrays(Y, U, V, bd, bs, q, open_loop=open_loop)
     for f in range(nf):
-        exp = O.intra_encode_frame(Y[f], U[f], V[f], bd, bs, q)
+        exp = O.intra_encode_frame(Y[f], U[f], V[f], bd, bs, q, open_loop=open_loop)
         for k in KEYS:
             assert (got[k][f] == exp[k]).all(), (k, (w, h), bd, bs, q, f, np.argwhere(got[k][f] != exp[k])[:4])
     return got, (Y, U, V)
@@ -26,6 +26,21 @@ def test_intra_pipe_small_frames(ctx, O, bd, bs):
     _check(ctx, O, 208, 112, 2, bd, bs, 40)      # ragged: partial superblocks on the right and at the bottom
     _check(ctx, O, 64, 64, 1, bd, bs, 255)
     _check(ctx, O, 16, 16, 1, bd, bs, 0)
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+@pytest.mark.parametrize("bs", [8, 16])
+def test_intra_pipe_open_loop_mode_decision(ctx, O, bd, bs):
+    """av1mi_intra_job.open_loop: the modes are decided by k_intra_modes on the SOURCE neighbours, the tiles then code one prediction
+    per block; same oracle with its switch set.  The decisions differ from the closed loop's on real content."""
+    try:
+        got, (Y, U, V) = _check(ctx, O, 256, 192, 2, bd, bs, 128, open_loop=True)
+        _check(ctx, O, 208, 112, 2, bd, bs, 40, open_loop=True)       # ragged
+        _check(ctx, O, 16, 16, 1, bd, bs, 255, open_loop=True)       # one block per plane: nothing to predict from
+        closed = ctx.intra_encode_arrays(Y, U, V, bd, bs, 128)
+        assert (closed["modes_y"] != got["modes_y"]).any()
+    finally:
+        O.set_intra_open_loop(False)
 
 
 def test_intra_pipe_1080p_frame(ctx, O):
