@@ -241,6 +241,8 @@ __global__ __launch_bounds__(64) void k_av1_chains(Av1EntLaunch L, int ntiles_al
 constexpr int kRingOps = 64, kLaneWords = kRingOps * 2 + Coder::kStage + 8;     // uint16 per lane; + 8: the lanes start on different banks
 
 __global__ __launch_bounds__(64) void k_av1_code(Av1EntLaunch L, int ntiles_all) {
+  // (Measured, round 3: s_setprio(3) for these lone latency-bound waves changes nothing, with four or with eight hardware queues —
+  // they do not lose issue slots to co-resident waves; what the streams compete for is residency: LDS and wave slots per CU.)
   __shared__ __attribute__((aligned(16))) uint16_t s_lane[64 * kLaneWords];
   const int lane = threadIdx.x, t = blockIdx.x * 64 + lane;
   const bool live = t < ntiles_all;
@@ -401,7 +403,11 @@ int grow(av1mi_ctx *ctx, void **p, size_t *have, size_t need) {
 
 extern "C" {
 
-uint32_t av1mi_av1_entropy_ops_per_tile(void) { return 24576; }
+// Capacities, sized on the densest content measured (tools: AV1MI_TOK_STATS in host/av1_opstream.cpp; 4K 10-bit noise-dominated key
+// frames at the reference's quality 23: <= 485 records in a block before the tile's restoration / CDEF syntax, which rides on the
+// tile's first block — 512 overflowed there —, <= 22 394 list words in a tile).  Not the syntax's worst case (~820 records per block,
+// ~52 000 words per tile): a tile beyond them raises a status bit and the session hands the batch to the host writer.
+uint32_t av1mi_av1_entropy_ops_per_tile(void) { return 32768; }
 uint32_t av1mi_av1_entropy_slot_bytes(void) { return 16384; }
 
 }  // extern "C"

@@ -123,7 +123,7 @@ typedef uint32_t op_t;
 struct SlotTable { uint16_t off[S_MAX]; uint8_t nsym[(S_MAX + 3) & ~3]; int words; };     // a whole number of dwords
 AV1_HD op_t op_lit(int n, unsigned v) { return (op_t)(0x80000000u | ((unsigned)n << 27) | (v & 0x7FFu)); }
 AV1_HD op_t make_tuple(uint32_t fl, uint32_t fh, int s, int n) { return (op_t)(((unsigned)(n - s) << 19) | ((fl >> 6) << 9) | (fh >> 6)); }
-enum { kBlocksPerTile = 64, kSplitHorz = 14, kSplitVert = 15, kListAlign = 4, kBlockRecords = 512 };     // a slot's entries start on 16 bytes
+enum { kBlocksPerTile = 64, kSplitHorz = 14, kSplitVert = 15, kListAlign = 4, kBlockRecords = 1024 };    // a slot's entries start on 16 bytes
 
 // The tokenizer runs ONCE per block and leaves 16-bit RECORDS, one per syntax element in decoding order:
 //   literal: 1 | n (4 bits, 1..11, << 11) | value (11 bits);     adaptive symbol: 0 | slot (<< 4) | symbol (4 bits)

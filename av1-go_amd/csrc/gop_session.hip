@@ -503,6 +503,9 @@ int av1mi_gop_collect(av1mi_gop *g, av1mi_gop_frame *out) {
     // the payloads are already here: k_av1_gather wrote them into the slot's pinned buffer (a copy enqueued NOW would queue
     // behind the next batches' work, which is already submitted)
     if (status || total > g->ent_cap) {
+      if (getenv("AV1MI_DEBUG"))
+        fprintf(stderr, "[av1mi] batch %ld (frame type %d) falls back to the host coder: status %llx (1 list / records, 2 payload slot, 4 output), %llu bytes of %zu\n",
+                (long)g->collected, s.frame_type, (unsigned long long)status, (unsigned long long)total, g->ent_cap);
       // A tile exceeded the coder's list / record / payload capacity (very fine quantisers on dense content).  The batch is not
       // lost: its symbols are still in the slot's device buffers (the next kernel that overwrites them is kSlots submits away),
       // so they are downloaded now and handed out like in host mode: tile_size stays NULL, the caller entropy-codes this batch.

@@ -3,6 +3,8 @@
 // the host, so that its logic is checked byte for byte against the block-sequential writer of av1_bitstream.cpp on every
 // machine, GPU or not (tests/test_av1_opstream.py).  Also the reference the GPU kernels' output is compared with.
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -67,18 +69,31 @@ bool opstream_tiles(const av1mi_obu_frame &f, std::vector<std::vector<uint8_t>> 
   fill_scan_tables(&scan);
   alignas(16) uint8_t mag[kMagBytes];
   const TokScratch ts = { mag, &scan };
+  // AV1MI_TOK_STATS=1 (diagnostic): the capacities a frame would need — records per block, symbols of one slot in one block, list
+  // words per tile — to stderr; tiles over capacity are skipped instead of failing the call
+  const bool stats = getenv("AV1MI_TOK_STATS") != nullptr;
+  int st_rec = 0, st_cnt = 0, st_ops = 0, st_over = 0; long st_ops_sum = 0;
   for (int sbr = 0; sbr < sbr_n; sbr++)
     for (int sbc = 0; sbc < sbc_n; sbc++) {
       // stage 1, tokenize (the GPU: one thread per block): records + counts, place, replay
       std::fill(cnt.begin(), cnt.end(), 0);
       int first[kBlocksPerTile + 1], nrec[kBlocksPerTile];
       first[0] = 0;
+      bool over = false;
       for (int zi = 0; zi < kBlocksPerTile; zi++) {
         Sink k = { &rec[(size_t)zi * kBlockRecords], cnt.data(), zi, 0, 0, false };
         tok_block(v, k, ts, sbr, sbc, zi);
-        if (k.overflow) { if (err) *err = "a block exceeds the tokenizer's record area"; return false; }
+        if (k.overflow && !stats) { if (err) *err = "a block exceeds the tokenizer's record area"; return false; }
+        over |= k.overflow;
         nrec[zi] = k.nrec;
         first[zi + 1] = first[zi] + k.n;
+        if (k.nrec > st_rec) st_rec = k.nrec;
+      }
+      if (stats) {
+        for (uint8_t c : cnt) if (c > st_cnt) st_cnt = c;
+        if (first[kBlocksPerTile] > st_ops) st_ops = first[kBlocksPerTile];
+        st_ops_sum += first[kBlocksPerTile];
+        if (over) { st_over++; continue; }
       }
       const int nops = first[kBlocksPerTile];
       int base[S_MAX], total[S_MAX], run = 0;
@@ -106,6 +121,9 @@ bool opstream_tiles(const av1mi_obu_frame &f, std::vector<std::vector<uint8_t>> 
       if (n < 0) { if (err) *err = "tile payload overflow"; return false; }
       out.resize((size_t)n);
     }
+  if (stats)
+    fprintf(stderr, "[av1mi tok stats] %d tiles: records per block <= %d (capacity %d), symbols of a slot in a block <= %d (255), list words per tile <= %d, mean %.0f; %d tiles over a block capacity\n",
+            sbr_n * sbc_n, st_rec, (int)kBlockRecords, st_cnt, st_ops, (double)st_ops_sum / (sbr_n * sbc_n), st_over);
   return true;
 }
 
