@@ -99,7 +99,8 @@ static int encode_block(int nplanes, const void *const *src, void *const *rec, i
     }
     if (best < 0 || sad < best) { best = sad; best_mode = mode; }
   }
-  const int tx_type = nplanes == 2 ? av1o_mode_to_txfm[best_mode] : DCT_DCT;   /* chroma: implied by the mode; luma: coded, DCT_DCT */
+  /* chroma: implied by the mode (32x32 transforms have the DCT only, spec 5.11.40 / get_tx_set); luma: coded, DCT_DCT */
+  const int tx_type = nplanes == 2 && bs < 32 ? av1o_mode_to_txfm[best_mode] : DCT_DCT;
   for (int p = 0; p < nplanes; p++) {
     int16_t resid[64 * 64];
     int32_t coef[1024], dq[1024];
@@ -121,14 +122,15 @@ static int encode_block(int nplanes, const void *const *src, void *const *rec, i
 }
 
 /*
- * One frame.  Planes are w x h (luma) and w/2 x h/2 (chroma), w and h multiples of bs (luma block size, 8 or 16).
+ * One frame.  Planes are w x h (luma) and w/2 x h/2 (chroma), w and h multiples of bs (luma block size: 8 or 16 as the GPU pipeline
+ * has them; 32 and 64 for rate-distortion measurements, tools/rd_blocksize.py).
  * Tiles are 64x64 luma superblocks; nothing is predicted across a tile edge.  levels_*: block-contiguous int16 in
  * raster order of blocks; modes_*: one byte per block, raster order (modes_uv shared by U and V).
  */
 int av1o_intra_encode_frame(const void *src_y, const void *src_u, const void *src_v, void *rec_y, void *rec_u, void *rec_v,
                             int w, int h, int stride_y, int stride_uv, int bd, int bs, int qindex, int16_t *lev_y,
                             int16_t *lev_u, int16_t *lev_v, uint8_t *modes_y, uint8_t *modes_uv) {
-  if ((bs != 8 && bs != 16) || (w % bs) || (h % bs) || (bd != 8 && bd != 10)) return -1;
+  if ((bs != 8 && bs != 16 && bs != 32 && bs != 64) || (w % bs) || (h % bs) || (bd != 8 && bd != 10)) return -1;
   const int dc_q = av1o_dc_q(qindex, 0, bd), ac_q = av1o_ac_q(qindex, 0, bd);
   const int n = 64 / bs;                                   /* blocks per superblock side */
   const int bw = w / bs, bh = h / bs;                      /* frame size in blocks */
