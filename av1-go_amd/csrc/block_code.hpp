@@ -48,22 +48,22 @@ template <int N, typename Pix> __device__ __forceinline__ void store_row(Pix *p,
 // 1-D pass that is a DCT or an ADST per BLOCK (lanes of different blocks share the wave): both are evaluated and the lane
 // selects — for the 4-point (default) and 8-point chroma transforms that is cheaper than a divergent branch per group.
 template <int B, int BIT> __device__ __forceinline__ void fwd_dct_or_adst(int32_t *x, bool adst) {
-  static_assert(B == 4 || B == 8, "ADST is only selected for chroma blocks (4x4, or 8x8 with 16x16 luma blocks)");
+  static_assert(B == 4 || B == 8 || B == 16, "ADST is only selected for chroma blocks (4x4, or 8x8 / 16x16 with 16x16 / 32x32 luma blocks)");
   int32_t a[B];
 #pragma unroll
   for (int i = 0; i < B; i++) a[i] = x[i];
   fdct<B, BIT>(x);
-  if constexpr (B == 4) fadst4<BIT>(a); else fadst8<BIT>(a);
+  if constexpr (B == 4) fadst4<BIT>(a); else if constexpr (B == 8) fadst8<BIT>(a); else fadst16<BIT>(a);
 #pragma unroll
   for (int i = 0; i < B; i++) x[i] = adst ? a[i] : x[i];
 }
 template <int B, int RANGE> __device__ __forceinline__ void inv_dct_or_adst(int32_t *x, bool adst) {
-  static_assert(B == 4 || B == 8, "see fwd_dct_or_adst");
+  static_assert(B == 4 || B == 8 || B == 16, "see fwd_dct_or_adst");
   int32_t a[B];
 #pragma unroll
   for (int i = 0; i < B; i++) a[i] = x[i];
   idct<B, RANGE>(x);
-  if constexpr (B == 4) iadst4<12>(a); else iadst8<12, RANGE>(a);
+  if constexpr (B == 4) iadst4<12>(a); else if constexpr (B == 8) iadst8<12, RANGE>(a); else iadst16<12, RANGE>(a);
 #pragma unroll
   for (int i = 0; i < B; i++) x[i] = adst ? a[i] : x[i];
 }
@@ -101,11 +101,12 @@ __device__ __forceinline__ int code_residual(int32_t *T, int lane, const int *s,
     xv[c] = v.x; xv[c + 1] = v.y; xv[c + 2] = v.z; xv[c + 3] = v.w;
   }
   if constexpr (SEL) fwd_dct_or_adst<B, fwd_cos_bit_row(B, B)>(xv, hadst); else fdct<B, fwd_cos_bit_row(B, B)>(xv);
-  // quantise / dequantise this row (libaom quantize_fp; spec 7.12.3), log_scale 0 for B <= 16
+  // quantise / dequantise this row (libaom quantize_fp; spec 7.12.3), log_scale LS: 0 for B <= 16, 1 for 32 x 32 (1024 coefficients)
   // dc_quant / ac_quant = (1 << 16) / step come from the host: written here as a division, the compiler sank the (loop-invariant)
   // division into the conditional block of every coefficient — ~25 scalar or ~30 vector instructions and a divergent branch, 8
   // times per row of every block
-  const int dc_rnd = (64 * dc_q) >> 7, ac_rnd = (AC_ROUND * ac_q) >> 7;
+  constexpr int LS = B >= 32 ? 1 : 0;
+  const int dc_rnd = round2((64 * dc_q) >> 7, LS), ac_rnd = round2((AC_ROUND * ac_q) >> 7, LS);
   const int maxv = (1 << (7 + bd)) - 1, minv = -(1 << (7 + bd));
   int lv[B];
 #pragma unroll
@@ -115,10 +116,11 @@ __device__ __forceinline__ int code_residual(int32_t *T, int lane, const int *s,
     const int v = round2(xv[c], -fwd_shift(B, B, 2));
     const bool neg = v < 0;
     int a = min(neg ? -v : v, 1 << 20), l = 0;
-    l = mul24_pinned(min(a + rnd, 32767), quant) >> 16;    // 15 x 15 bits: a full-rate 24-bit multiply (a 32-bit one is four passes); <= 8191
-    l = (a << 1) >= q ? l : 0;
+    l = mul24_pinned(min(a + rnd, 32767), quant) >> (16 - LS);    // 15 x 15 bits: a full-rate 24-bit multiply (a 32-bit one is four passes); < 2^15 at LS 0
+    if constexpr (LS) l = min(l, 32767);
+    l = (a << (1 + LS)) >= q ? l : 0;
     lv[c] = neg ? -l : l;
-    const int d = mul24_pinned(l, q) & 0xFFFFFF;            // l <= 8191, q < 2^15
+    const int d = (mul24_pinned(l, q) & 0xFFFFFF) >> LS;    // l < 2^15, q < 2^15
     xv[c] = min(max(neg ? -d : d, minv), maxv);
   }
 #pragma unroll

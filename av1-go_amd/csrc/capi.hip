@@ -517,7 +517,8 @@ int av1mi_intra_encode(av1mi_ctx *ctx, const av1mi_intra_job *j) {
   BIND(ctx);
   if (!j) return fail(ctx, AV1MI_E_INVAL, "null job");
   if (j->bit_depth != 8 && j->bit_depth != 10) return fail(ctx, AV1MI_E_INVAL, "bit depth %d not supported (8 or 10)", j->bit_depth);
-  if (j->block_size != 8 && j->block_size != 16) return fail(ctx, AV1MI_E_INVAL, "block_size %d not supported (8 or 16)", j->block_size);
+  if (j->block_size != 8 && j->block_size != 16 && j->block_size != 32) return fail(ctx, AV1MI_E_INVAL, "block_size %d not supported (8, 16 or 32)", j->block_size);
+  if (j->open_loop && j->block_size == 32) return fail(ctx, AV1MI_E_INVAL, "the open-loop mode decision exists for 8x8 and 16x16 blocks");
   if (j->width <= 0 || j->height <= 0 || j->width % j->block_size || j->height % j->block_size || j->width > 16384 || j->height > 16384)
     return fail(ctx, AV1MI_E_INVAL, "frame %dx%d is not a multiple of the block size %d", j->width, j->height, j->block_size);
   if (j->nframes < 0 || j->qindex < 0 || j->qindex > 255) return fail(ctx, AV1MI_E_INVAL, "bad nframes/qindex");

@@ -23,13 +23,14 @@ enum { DC_PRED, V_PRED, H_PRED, D45_PRED, D135_PRED, D113_PRED, D157_PRED, D203_
     __builtin_amdgcn_wave_barrier();                         \
   } while (0)
 
-// Sum over the G (4, 8 or 16) consecutive lanes of a group with DPP cross-lane VALU moves (no LDS round trip, unlike
+// Sum over the G (4, 8, 16 or 32) consecutive lanes of a group with DPP cross-lane VALU moves (no LDS round trip, unlike
 // __shfl_xor's ds_bpermute): quad xor 1, quad xor 2, then half-row / row mirrors pair the quads.  Every lane gets the sum.
 template <int G> __device__ __forceinline__ int group_sum(int v) {
   v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);                       // quad_perm [1,0,3,2]
   v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);                       // quad_perm [2,3,0,1]
   if constexpr (G >= 8) v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);   // row_half_mirror: lane i <-> 7-i
   if constexpr (G >= 16) v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false);  // row_mirror: lane i <-> 15-i
+  if constexpr (G >= 32) v += __shfl_xor(v, 16, 64);                                      // the other 16-lane row of the group (32x32 blocks: key frames only)
   return v;
 }
 template <int G> __device__ __forceinline__ int group_or(int v) {
@@ -37,6 +38,7 @@ template <int G> __device__ __forceinline__ int group_or(int v) {
   v |= __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);
   if constexpr (G >= 8) v |= __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);
   if constexpr (G >= 16) v |= __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false);
+  if constexpr (G >= 32) v |= __shfl_xor(v, 16, 64);
   return v;
 }
 

@@ -316,12 +316,13 @@ extern "C" int av1mi_debug_read_stamps(unsigned long long *out) {
 hipError_t launch_intra_pipe(const IntraPipeLaunch &L, int bs, hipStream_t s) {
   const long long tiles = (long long)L.nframes * ((L.w + 63) / 64) * ((L.h + 63) / 64);
   if (tiles <= 0) return hipSuccess;
-  if (bs != 8 && bs != 16) return hipErrorInvalidValue;
+  if (bs != 8 && bs != 16 && bs != 32) return hipErrorInvalidValue;
   const int tpw = 256 / bs;
   const dim3 grid((unsigned)((tiles + tpw - 1) / tpw));
   if (L.open_loop) {      // the decision on the source, every block on its own; then the tiles' chains with one prediction per block
     const long long blocks = (long long)L.nframes * (L.w / bs) * (L.h / bs);
     const dim3 mgrid((unsigned)((blocks + tpw - 1) / tpw));
+    if (bs == 32) return hipErrorInvalidValue;      // (the open-loop decision exists for 8x8 and 16x16)
     if (bs == 8) {
       if (L.bd == 8) { hipLaunchKernelGGL((k_intra_modes<8, uint8_t>), mgrid, dim3(256), 0, s, L); hipLaunchKernelGGL((k_intra_pipe<8, uint8_t, true>), grid, dim3(256), 0, s, L); }
       else { hipLaunchKernelGGL((k_intra_modes<8, uint16_t>), mgrid, dim3(256), 0, s, L); hipLaunchKernelGGL((k_intra_pipe<8, uint16_t, true>), grid, dim3(256), 0, s, L); }
@@ -334,6 +335,9 @@ hipError_t launch_intra_pipe(const IntraPipeLaunch &L, int bs, hipStream_t s) {
   if (bs == 8) {
     if (L.bd == 8) hipLaunchKernelGGL((k_intra_pipe<8, uint8_t>), grid, dim3(256), 0, s, L);
     else hipLaunchKernelGGL((k_intra_pipe<8, uint16_t>), grid, dim3(256), 0, s, L);
+  } else if (bs == 32) {
+    if (L.bd == 8) hipLaunchKernelGGL((k_intra_pipe<32, uint8_t>), grid, dim3(256), 0, s, L);
+    else hipLaunchKernelGGL((k_intra_pipe<32, uint16_t>), grid, dim3(256), 0, s, L);
   } else {
     if (L.bd == 8) hipLaunchKernelGGL((k_intra_pipe<16, uint8_t>), grid, dim3(256), 0, s, L);
     else hipLaunchKernelGGL((k_intra_pipe<16, uint16_t>), grid, dim3(256), 0, s, L);

@@ -251,7 +251,7 @@ int av1mi_lr_frames_decide(av1mi_ctx *ctx, const void *d_cdef, const void *d_deb
  * diagonals, SMOOTH, PAETH, SMOOTH_V, SMOOTH_H; angle delta 0).  Outputs: reconstruction planes, int16 levels (block-contiguous, raster order of blocks, per plane),
  * one mode byte per block for luma and one for the chroma pair. */
 typedef struct av1mi_intra_job {
-  int width, height, bit_depth, nframes, qindex, block_size;
+  int width, height, bit_depth, nframes, qindex, block_size;   /* block_size 8 (the session), 16 or 32 (32: closed loop only) */
   int stride_y, stride_uv;                 /* samples; multiples of 4 */
   const void *d_src_y, *d_src_u, *d_src_v; /* source frames */
   void *d_rec_y, *d_rec_u, *d_rec_v;       /* reconstruction (output) */

@@ -43,6 +43,17 @@ def test_intra_pipe_open_loop_mode_decision(ctx, O, bd, bs):
         O.set_intra_open_loop(False)
 
 
+@pytest.mark.parametrize("bd", [8, 10])
+def test_intra_pipe_32x32_blocks(ctx, O, bd):
+    """k_intra_pipe<32>: 32x32 luma blocks with the 32-point DCT (quantiser log-scale 1), 16x16 chroma blocks whose transform type
+    follows the mode (16-point ADST).  Not used by the session yet (uniform 32x32 key frames are worth +3.7 dB at equal
+    size on the bench content); parity with the oracle's loop at the same block size."""
+    _check(ctx, O, 256, 192, 2, bd, 32, 128)
+    _check(ctx, O, 320, 160, 1, bd, 32, 24)      # partial superblocks on the right and at the bottom
+    _check(ctx, O, 64, 64, 1, bd, 32, 255)
+    _check(ctx, O, 32, 32, 1, bd, 32, 1)
+
+
 def test_intra_pipe_1080p_frame(ctx, O):
     """BASELINE config 2 size: one 1920x1080 8-bit frame, 8x8 blocks, bit-exact vs the oracle; PSNR sanity"""
     got, (Y, U, V) = _check(ctx, O, 1920, 1080, 1, 8, 8, 128, first=5)
