@@ -101,6 +101,8 @@ int RunBackend(const BackendJob &job, std::string *err) {
     cfg.gpu_entropy = job.gpu_entropy ? 1 : 0;
     CHK(av1mi_gop_open(ctx, &cfg, &gop));
     av1::SequenceParams sp; sp.width = y.w; sp.height = y.h; sp.bit_depth = y.bd;
+    for (const std::string &side : job.tracks)
+      if (!sink.add_side_file(side, err)) { code = 1; goto done; }
     if (!sink.open(job.output, sp, y.fps_n, y.fps_d, err)) { code = 1; goto done; }
     std::vector<std::vector<std::vector<uint8_t>>> units((size_t)S);   // [segment][frame] temporal units of the batch in flight
     const int lag = av1mi_gop_max_in_flight() - 1;      // batches the GPU holds while the host works on the oldest

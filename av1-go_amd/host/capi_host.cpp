@@ -48,6 +48,30 @@ long long av1mi_host_y4m_scan(const char *path, int group, unsigned long long *s
   geometry[0] = y.w; geometry[1] = y.h; geometry[2] = y.bd; geometry[3] = y.fps_n; geometry[4] = y.fps_d;
   return total;
 }
+// StreamSink (mux.hpp) alone, for the CPU tests: n_units byte strings (unit i = bytes [off[i], off[i + 1]) of `units`, standing in for
+// temporal units; unit i is a key frame when i % gop == 0) muxed at fps_n / fps_d together with the tracks of the Matroska side files
+// `sides` (paths separated by '\n').  Returns 0, or -1 with the text in err.
+int av1mi_host_mux_selftest(const char *out_path, int width, int height, int bit_depth, int fps_n, int fps_d, const unsigned char *units,
+                            const long long *off, int n_units, int gop, const char *sides, char *err, int cap) {
+  std::string e;
+  auto fail = [&]() { strncpy(err, e.c_str(), cap - 1); err[cap - 1] = 0; return -1; };
+  StreamSink sink;
+  for (std::string rest = sides ? sides : ""; !rest.empty();) {
+    const size_t nl = rest.find('\n');
+    const std::string one = rest.substr(0, nl);
+    rest = nl == std::string::npos ? "" : rest.substr(nl + 1);
+    if (!one.empty() && !sink.add_side_file(one, &e)) return fail();
+  }
+  av1::SequenceParams sp;
+  sp.width = width; sp.height = height; sp.bit_depth = bit_depth;
+  if (!sink.open(out_path, sp, fps_n, fps_d, &e)) return fail();
+  for (int i = 0; i < n_units; i++) {
+    const std::vector<uint8_t> tu(units + off[i], units + off[i + 1]);
+    if (!sink.write(tu, i % gop == 0, &e)) { sink.abort(); return fail(); }
+  }
+  if (!sink.close(&e)) return fail();
+  return 0;
+}
 // The drop-in for internal/ffmpeg/transcode.go:194 `RunTranscode(ffmpegPath string, args []string) (int, error)`: what the cgo
 // shim of INTEGRATION.md binds.  Returns the exit code of the contract (0 = output written, -1 = could not run, else failed);
 // the error text (<= 800 chars + "...", transcode.go:295-297) goes to err.  Declared in include/av1mi_host.h.

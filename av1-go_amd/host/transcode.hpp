@@ -49,6 +49,8 @@ struct BackendJob {
   int threads = 0;         // host threads for entropy coding; 0 = all cores
   int gpu_entropy = 1;     // 1 = the AV1 tile entropy coder runs on the GPU (the host only assembles frames); 0 = north_star's split:
                            // symbols are downloaded and coded on the host cores.  Same bytes either way.
+  std::vector<std::string> tracks;   // -av1mi_tracks <file.mka> (repeatable): Matroska side files whose audio / subtitle tracks are copied
+                                     // next to the video (the reference's `-c:a copy -c:s copy`, transcode.go:134-137, after an external demux)
 };
 bool ParseBackendJob(const std::vector<std::string> &args, BackendJob *job, std::string *err);
 

@@ -339,6 +339,35 @@ def test_the_public_drop_in_and_streamed_input(host, tmp_path):
 
 
 @pytest.mark.gpu
+def test_run_transcode_copies_the_tracks_of_a_side_file(host, tmp_path):
+    """`-c:a copy -c:s copy` (internal/ffmpeg/transcode.go:134-137) after an external demux: `-av1mi_tracks side.mka` puts the side
+    file's audio and subtitle tracks next to the coded video; the video blocks are those of the video-only run (muxer details:
+    tests/test_mux.py on the CPU)"""
+    import struct
+    import test_mux as M
+    w, h, n, gop = 136, 72, 9, 4
+    src = tmp_path / "clip.y4m"
+    _write_y4m(str(src), w, h, n)
+    side = tmp_path / "side.mka"
+    audio = [(t, bytes([t % 251]) * 50) for t in range(0, 400, 20)]
+    M.side_file(side, [(1, M.AUDIO), (2, M.SUBS)], [(0, [M.simple_block(1, t, d) for t, d in audio] + [M.block_group(2, 120, b"hello", duration=150)])])
+    host.av1mi_run_transcode.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.c_char_p, C.c_size_t]
+    err = C.create_string_buffer(1024)
+    outs = []
+    for extra, name in (([], "plain.mkv"), (["-av1mi_tracks", str(side)], "copied.mkv")):
+        argv = ["-i", str(src), "-global_quality:v:0", "120", "-g", str(gop), "-av1mi_segments", "2"] + extra + [str(tmp_path / name)]
+        arr = (C.c_char_p * len(argv))(*[a.encode() for a in argv])
+        assert host.av1mi_run_transcode(len(argv), arr, err, 1024) == 0, err.value
+        outs.append(M.read_mkv(tmp_path / name))
+    (_, t0, b0), (info, t1, b1) = outs
+    assert sorted(t0) == [1] and sorted(t1) == [1, 2, 3] and t1[2][0x86] == b"A_OPUS" and t1[3][0x86] == b"S_TEXT/UTF8"
+    assert [b for b in b1 if b["track"] == 1] == b0 and len(b0) == n
+    assert [(b["t"], b["data"]) for b in b1 if b["track"] == 2] == audio
+    assert [(b["t"], b["duration"], b["data"]) for b in b1 if b["track"] == 3] == [(120, 150, b"hello")]
+    assert struct.unpack(">d", info[0x4489])[0] >= 380.0
+
+
+@pytest.mark.gpu
 def test_run_transcode_of_dense_content_at_the_reference_quality(host, tmp_path):
     """noise at quality 25 (DetermineQuality of a sub-1080p source) overflows the GPU coder; RunTranscode must still write
     the stream — the same bytes as with the host coder — also when the file holds fewer GOPs than segments x groups (absent segments
