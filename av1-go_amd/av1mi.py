@@ -59,7 +59,8 @@ class IntraJob(C.Structure):
                 ("d_src_y", C.c_void_p), ("d_src_u", C.c_void_p), ("d_src_v", C.c_void_p),
                 ("d_rec_y", C.c_void_p), ("d_rec_u", C.c_void_p), ("d_rec_v", C.c_void_p),
                 ("d_lev_y", C.c_void_p), ("d_lev_u", C.c_void_p), ("d_lev_v", C.c_void_p),
-                ("d_modes_y", C.c_void_p), ("d_modes_uv", C.c_void_p), ("open_loop", C.c_int)]
+                ("d_modes_y", C.c_void_p), ("d_modes_uv", C.c_void_p), ("open_loop", C.c_int), ("frame_rows", C.c_int),
+                ("modes_frame_stride", C.c_int)]
 
 
 class InterJob(C.Structure):
@@ -87,7 +88,7 @@ class LrDecideJob(C.Structure):
 class GopConfig(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("bit_depth", C.c_int), ("base_q_idx", C.c_int), ("gop_length", C.c_int),
                 ("segments", C.c_int), ("search_range", C.c_int), ("gpu_entropy", C.c_int), ("visible_width", C.c_int),
-                ("visible_height", C.c_int), ("coder_streams", C.c_int)]
+                ("visible_height", C.c_int), ("coder_streams", C.c_int), ("key_block_size", C.c_int)]
 
 
 class FrameParams(C.Structure):
@@ -100,7 +101,8 @@ class GopFrame(C.Structure):
     _fields_ = [("params", FrameParams), ("segments", C.c_int), ("blocks_per_frame", C.c_size_t), ("y_mode", C.c_void_p),
                 ("uv_mode", C.c_void_p), ("mv", C.c_void_p), ("skip", C.c_void_p), ("lev_y", C.c_void_p), ("lev_u", C.c_void_p),
                 ("lev_v", C.c_void_p), ("tiles_per_frame", C.c_int), ("tile_size", C.c_void_p), ("tile_payload", C.c_void_p),
-                ("payload_bytes", C.c_uint64), ("lr_on", C.c_void_p)]
+                ("payload_bytes", C.c_uint64), ("lr_on", C.c_void_p), ("key_block_size", C.c_int), ("key_modes_stride", C.c_int),
+                ("key_modes_band", C.c_int)]
 
 
 def policy_frame_params(base_q_idx, bit_depth, frame_type):
@@ -120,11 +122,13 @@ def _view(ptr, shape, dtype):
 class GopSession:
     """av1mi_gop_* (include/av1mi.h): closed GOPs in lockstep, policy and PCIe plumbing inside the library."""
 
-    def __init__(self, ctx, width, height, bit_depth, base_q_idx, gop_length, segments=1, search_range=8, gpu_entropy=0, visible=None, coder_streams=0):
-        """visible: the true (width, height) when width x height is it rounded up to 8 (the caller replicates the source edge)"""
+    def __init__(self, ctx, width, height, bit_depth, base_q_idx, gop_length, segments=1, search_range=8, gpu_entropy=0, visible=None, coder_streams=0,
+                 key_block_size=0):
+        """visible: the true (width, height) when width x height is it rounded up to 8 (the caller replicates the source edge);
+        key_block_size 32: key frames in 32x32 blocks (av1mi_gop_config.key_block_size)"""
         self.ctx, self.w, self.h, self.bd, self.segments = ctx, width, height, bit_depth, segments
         vw, vh = visible if visible is not None else (0, 0)
-        self.cfg = GopConfig(width, height, bit_depth, base_q_idx, gop_length, segments, search_range, gpu_entropy, vw, vh, coder_streams)
+        self.cfg = GopConfig(width, height, bit_depth, base_q_idx, gop_length, segments, search_range, gpu_entropy, vw, vh, coder_streams, key_block_size)
         self.g = C.c_void_p()
         ctx.lib.av1mi_gop_open.argtypes = [C.c_void_p, C.POINTER(GopConfig), C.POINTER(C.c_void_p)]
         ctx._chk(ctx.lib.av1mi_gop_open(ctx.h, C.byref(self.cfg), C.byref(self.g)))
@@ -168,7 +172,23 @@ class GopSession:
         """dict of numpy views (valid until the next submit) + params"""
         f = self.collect_raw()
         S, nb = f.segments, f.blocks_per_frame
-        out = dict(params=f.params, frame_type=f.params.frame_type, lr_on=_view(f.lr_on, (S, 3), np.uint8))      # restoration on / off per segment and plane
+        out = dict(params=f.params, frame_type=f.params.frame_type, lr_on=_view(f.lr_on, (S, 3), np.uint8), raw=f)      # restoration on / off per segment and plane
+        if f.key_block_size == 32:
+            # a key frame in 32x32 blocks: per segment the blocks of the complete superblock rows ("32": modes, levels [n, 32, 32] and the
+            # 16x16 chroma), then the 8x8 blocks of a last partial row ("8")
+            w, h = self.w, self.h
+            hA = h // 64 * 64
+            nA, nB = (hA // 32) * (w // 32), ((h - hA) // 8) * (w // 8)
+            out["key_block_size"] = 32
+            for name, ptr in (("y_mode", f.y_mode), ("uv_mode", f.uv_mode)):
+                m = _view(ptr, (S, f.key_modes_stride), np.uint8)
+                out[name + "32"], out[name + "8"] = m[:, :nA], m[:, f.key_modes_band:f.key_modes_band + nB]
+            for name, ptr, d in (("lev_y", f.lev_y, 1), ("lev_u", f.lev_u, 2), ("lev_v", f.lev_v, 2)):
+                pl = _view(ptr, (S, (h // d) * (w // d)), np.int16)
+                cut = (hA // d) * (w // d)
+                out[name + "32"] = pl[:, :cut].reshape(S, nA, 32 // d, 32 // d)
+                out[name + "8"] = pl[:, cut:].reshape(S, nB, 8 // d, 8 // d)
+            return out
         if f.lev_y:
             out.update(lev_y=_view(f.lev_y, (S, nb, 8, 8), np.int16), lev_u=_view(f.lev_u, (S, nb, 4, 4), np.int16),
                        lev_v=_view(f.lev_v, (S, nb, 4, 4), np.int16))

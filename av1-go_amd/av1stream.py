@@ -188,6 +188,24 @@ def session_frame_unit_gpu(width, height, bit_depth, frame, seg, with_sequence_h
     return assemble_temporal_unit(width, height, bit_depth, p.base_q_idx, pay, sizes, with_sequence_header=sh, **hdr)
 
 
+def session_temporal_unit(width, height, bit_depth, raw_frame, seg, with_sequence_header=True, threads=1, visible=None):
+    """av1mi_session_temporal_unit (include/av1mi_host.h): the temporal unit of segment `seg` of a collected batch, from the raw
+    av1mi_gop_frame (av1mi.GopSession.collect()["raw"]) — whichever coder produced it, whatever the key frames' block size"""
+    h = lib()
+    h.av1mi_session_temporal_unit.restype = C.c_longlong
+    h.av1mi_session_temporal_unit.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_longlong,
+                                              C.c_char_p, C.c_int]
+    cap = width * height * 4 + (1 << 16)
+    out = np.empty(cap, np.uint8)
+    err = C.create_string_buffer(256)
+    vw, vh = visible if visible is not None else (0, 0)
+    n = h.av1mi_session_temporal_unit(C.addressof(raw_frame), int(seg), width, height, bit_depth, int(vw), int(vh), int(with_sequence_header), int(threads),
+                                      out.ctypes.data, cap, err, 256)
+    if n < 0:
+        raise ValueError("av1mi_session_temporal_unit: " + err.value.decode())
+    return out[:n].tobytes()
+
+
 def header_from_params(p, width, height, lr_on=None, visible=None):
     """keyword arguments of temporal_unit() for a frame whose filter parameters are an av1mi_frame_params (GOP session policy);
     lr_on: the encoder's restoration ON / OFF decision per plane (the session's frame["lr_on"][segment]; None = the policy's types);

@@ -71,6 +71,8 @@ struct IntraPipeLaunch {
   int w, h, stride_y, stride_uv, bd, nframes, dc_q, ac_q;
   int dc_quant, ac_quant;   // (1 << 16) / step (libaom quant_fp): computed once by the host, see block_code.hpp
   int open_loop;            // 1: the modes are decided on the source first (k_intra_modes), the chain predicts each block once
+  int frame_rows;           // luma rows between the stacked frames of a plane (= h, or more when the job codes a band of rows of every frame)
+  int modes_stride;         // mode bytes between frames (= blocks of the job, or more)
 };
 hipError_t launch_intra_pipe(const IntraPipeLaunch &L, int bs, hipStream_t s);
 

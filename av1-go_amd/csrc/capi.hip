@@ -536,6 +536,11 @@ int av1mi_intra_encode(av1mi_ctx *ctx, const av1mi_intra_job *j) {
   L.dc_q = av1mi_dc_q(j->qindex, j->bit_depth); L.ac_q = av1mi_ac_q(j->qindex, j->bit_depth);
   L.dc_quant = (1 << 16) / L.dc_q; L.ac_quant = (1 << 16) / L.ac_q;
   L.open_loop = j->open_loop ? 1 : 0;
+  const int blocks = (j->width / j->block_size) * (j->height / j->block_size);
+  if ((j->frame_rows && (j->frame_rows < j->height || (j->frame_rows & 7))) || (j->modes_frame_stride && j->modes_frame_stride < blocks))
+    return fail(ctx, AV1MI_E_INVAL, "bad frame_rows %d / modes_frame_stride %d", j->frame_rows, j->modes_frame_stride);
+  L.frame_rows = j->frame_rows ? j->frame_rows : j->height;
+  L.modes_stride = j->modes_frame_stride ? j->modes_frame_stride : blocks;
   { ProfScope ps(ctx, AV1MI_K_INTRA_PIPE); HIP_TRY(ctx, av1mi::launch_intra_pipe(L, j->block_size, ctx->stream)); }
   return AV1MI_OK;
 }

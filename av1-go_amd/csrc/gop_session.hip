@@ -88,7 +88,9 @@ struct av1mi_gop {
   hipStream_t up = nullptr, down = nullptr;     // with the context's main and side streams: four, one hardware queue each
   Slot slot[kSlots];
   void *d_rec[3] = {}, *d_dbl[3] = {}, *d_cdef[3] = {}, *d_ref[3] = {};
-  void *d_mi[2][2] = {};                       // [key / inter][luma / chroma] deblocking mode-info maps (one frame, shared by the batch)
+  void *d_mi[3][2] = {};                       // [key / inter / key in 32x32 blocks][luma / chroma] deblocking mode-info maps (one frame, shared by the batch)
+  int key32 = 0, key_rows32 = 0;               // key frames in 32x32 blocks over the first key_rows32 luma rows (the complete superblock rows)
+  int key_modes_band = 0, key_modes_stride = 0;  // mode bytes per segment: the 32x32 blocks, then (from key_modes_band) the 8x8 blocks of the last rows
   void *d_cdef_sb[2] = {}, *d_lr[2] = {}, *d_zero_skip = nullptr;
   void *d_lr_scratch = nullptr;                // the restoration decision's partial sums (three planes)
   int vw = 0, vh = 0;                          // the true frame size (== the coded size unless cfg.visible_* say otherwise)
@@ -182,9 +184,14 @@ int setup(av1mi_gop *g) {
   const int nsb = ((w + 63) / 64) * ((h + 63) / 64);
   auto units = [](int n) { const int u = (n + 32) / 64; return u > 1 ? u : 1; };
   const size_t uy = (size_t)units(h) * units(w), uc = (size_t)units(h / 2) * units(w / 2);
-  for (int t = 0; t < 2; t++) {
-    frame_params(c.base_q_idx, c.bit_depth, t, &g->params[t]);
-    const av1mi_frame_params &P = g->params[t];
+  if (c.key_block_size == 32) {
+    g->key32 = 1; g->key_rows32 = (h / 64) * 64;
+    g->key_modes_band = ((g->key_rows32 / 32) * (w / 32) + 7) & ~7;
+    g->key_modes_stride = (g->key_modes_band + ((h - g->key_rows32) / 8) * (w / 8) + 7) & ~7;
+  }
+  for (int t = 0; t < 2 + g->key32; t++) {
+    if (t < 2) frame_params(c.base_q_idx, c.bit_depth, t, &g->params[t]);
+    const av1mi_frame_params &P = g->params[t == 2 ? 0 : t];
     // deblocking mode-info words (av1mi_deblock_plane): 8x8 luma / 4x4 chroma transforms, every block edge a prediction edge
     std::vector<uint32_t> mi(fy / 16, 3u | (3u << 4) | ((uint32_t)P.lf_level[0] << 8) | ((uint32_t)P.lf_level[1] << 16) | (3u << 25));
     std::vector<uint32_t> mic(fc / 16, 2u | (2u << 4) | ((uint32_t)P.lf_level[2] << 8) | ((uint32_t)P.lf_level[2] << 16) | (3u << 25));
@@ -192,6 +199,10 @@ int setup(av1mi_gop *g) {
     // "skipped inter block, no block edge"
     for (int r = 0; r < h / 4; r++) for (int cc = 0; cc < w / 4; cc++) if (4 * r >= g->vh || 4 * cc >= g->vw) mi[(size_t)r * (w / 4) + cc] = 3u | (3u << 4) | (1u << 24);
     for (int r = 0; r < h / 8; r++) for (int cc = 0; cc < w / 8; cc++) if (8 * r >= g->vh || 8 * cc >= g->vw) mic[(size_t)r * (w / 8) + cc] = 2u | (2u << 4) | (1u << 24);
+    if (t == 2) {      // key frames in 32x32 blocks: 32x32 luma / 16x16 chroma transforms over the complete superblock rows (always on screen)
+      for (int r = 0; r < g->key_rows32 / 4; r++) for (int cc = 0; cc < w / 4; cc++) mi[(size_t)r * (w / 4) + cc] = (mi[(size_t)r * (w / 4) + cc] & ~0xFFu) | 5u | (5u << 4);
+      for (int r = 0; r < g->key_rows32 / 8; r++) for (int cc = 0; cc < w / 8; cc++) mic[(size_t)r * (w / 8) + cc] = (mic[(size_t)r * (w / 8) + cc] & ~0xFFu) | 4u | (4u << 4);
+    }
     G_TRY(dev_alloc(g, &g->d_mi[t][0], mi.size() * 4)); G_TRY(av1mi_upload(g->ctx, g->d_mi[t][0], mi.data(), mi.size() * 4));
     G_TRY(dev_alloc(g, &g->d_mi[t][1], mic.size() * 4)); G_TRY(av1mi_upload(g->ctx, g->d_mi[t][1], mic.data(), mic.size() * 4));
   }
@@ -237,6 +248,9 @@ int av1mi_gop_open(av1mi_ctx *ctx, const av1mi_gop_config *cfg, av1mi_gop **out)
   if (cfg->base_q_idx < 1 || cfg->base_q_idx > 255 || cfg->gop_length < 1 || cfg->segments < 1 || cfg->segments > 4096 || cfg->search_range < 0 ||
       cfg->search_range > 15 || cfg->gpu_entropy < 0 || cfg->gpu_entropy > 2 || cfg->coder_streams < 0 || cfg->coder_streams > 3)
     return av1mi::ctx_fail(ctx, AV1MI_E_INVAL, "bad base_q_idx / gop_length / segments / search_range / gpu_entropy");
+  if (cfg->key_block_size != 0 && cfg->key_block_size != 8 && cfg->key_block_size != 32) return av1mi::ctx_fail(ctx, AV1MI_E_INVAL, "key_block_size %d not supported (8 or 32)", cfg->key_block_size);
+  if (cfg->key_block_size == 32 && ((cfg->width & 63) || cfg->gpu_entropy))
+    return av1mi::ctx_fail(ctx, AV1MI_E_INVAL, "key_block_size 32 needs a width that is a multiple of 64 and gpu_entropy 0 (the GPU tile coder codes 8x8 / 4x4 transforms)");
   if (cfg->gpu_entropy && (cfg->width > 4096 || cfg->height > 4096)) return av1mi::ctx_fail(ctx, AV1MI_E_INVAL, "the AV1 tile coder takes frames up to 4096x4096");
   if ((size_t)cfg->height * cfg->segments > 65535u * 8u) return av1mi::ctx_fail(ctx, AV1MI_E_INVAL, "segments x height too large for one launch");
   av1mi_gop *g = new (std::nothrow) av1mi_gop();
@@ -350,7 +364,24 @@ static int submit_batch(av1mi_gop *g, int frame_type, const void *const *dev_src
     j.d_lev_y = (int16_t *)s.d_lev[0]; j.d_lev_u = (int16_t *)s.d_lev[1]; j.d_lev_v = (int16_t *)s.d_lev[2];
     j.d_modes_y = (uint8_t *)s.d_modes[0]; j.d_modes_uv = (uint8_t *)s.d_modes[1];
     j.open_loop = g->intra_open_loop;
-    G_TRY(av1mi_intra_encode(g->ctx, &j));
+    if (!g->key32) {
+      G_TRY(av1mi_intra_encode(g->ctx, &j));
+    } else {
+      // two bands of every frame: the complete superblock rows in 32x32 blocks, a last partial row (if any) in 8x8 blocks.  Tiles are
+      // single superblocks, so the bands share nothing.
+      const int hA = g->key_rows32, hB = h - hA;
+      j.open_loop = 0; j.frame_rows = h; j.modes_frame_stride = g->key_modes_stride;
+      if (hA) { j.height = hA; j.block_size = 32; G_TRY(av1mi_intra_encode(g->ctx, &j)); }
+      if (hB) {
+        const size_t oy = (size_t)hA * w, oc = (size_t)(hA / 2) * (w / 2);
+        j.height = hB; j.block_size = 8;
+        j.d_src_y = (const char *)src[0] + oy * g->bps; j.d_src_u = (const char *)src[1] + oc * g->bps; j.d_src_v = (const char *)src[2] + oc * g->bps;
+        j.d_rec_y = (char *)g->d_rec[0] + oy * g->bps; j.d_rec_u = (char *)g->d_rec[1] + oc * g->bps; j.d_rec_v = (char *)g->d_rec[2] + oc * g->bps;
+        j.d_lev_y = (int16_t *)s.d_lev[0] + oy; j.d_lev_u = (int16_t *)s.d_lev[1] + oc; j.d_lev_v = (int16_t *)s.d_lev[2] + oc;
+        j.d_modes_y = (uint8_t *)s.d_modes[0] + g->key_modes_band; j.d_modes_uv = (uint8_t *)s.d_modes[1] + g->key_modes_band;
+        G_TRY(av1mi_intra_encode(g->ctx, &j));
+      }
+    }
   } else {
     av1mi_inter_job j;
     memset(&j, 0, sizeof(j));
@@ -380,7 +411,7 @@ static int submit_batch(av1mi_gop *g, int frame_type, const void *const *dev_src
   const av1mi_frame_params &P = g->params[frame_type];
   for (int p = 0; p < 3; p++) {
     const int pw = p ? w / 2 : w, ph = p ? h / 2 : h;
-    G_TRY(av1mi_deblock_frames(g->ctx, g->d_rec[p], pw, g->d_dbl[p], pw, pw, ph, bd, p > 0, (const uint32_t *)g->d_mi[frame_type][p > 0], pw / 4, 0,
+    G_TRY(av1mi_deblock_frames(g->ctx, g->d_rec[p], pw, g->d_dbl[p], pw, pw, ph, bd, p > 0, (const uint32_t *)g->d_mi[frame_type == 0 && g->key32 ? 2 : frame_type][p > 0], pw / 4, 0,
                                P.lf_sharpness, S));
   }
   av1mi_cdef_job cj;
@@ -490,6 +521,8 @@ int av1mi_gop_collect(av1mi_gop *g, av1mi_gop_frame *out) {
   out->lr_on = (const uint8_t *)s.h_lr_on;
   out->segments = g->cfg.segments;
   out->blocks_per_frame = g->nb / (size_t)g->cfg.segments;
+  out->key_block_size = s.frame_type == 0 && g->key32 ? 32 : 8;
+  out->key_modes_stride = g->key_modes_stride; out->key_modes_band = g->key_modes_band;
   auto symbols = [&](bool levels) {
     if (s.frame_type == 0) { out->y_mode = (const uint8_t *)s.h_modes[0]; out->uv_mode = (const uint8_t *)s.h_modes[1]; }
     else { out->mv = (const int16_t *)s.h_mv; out->skip = (const uint8_t *)s.h_skip; }

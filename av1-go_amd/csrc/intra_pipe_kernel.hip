@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void k_intra_modes(IntraPipeLaunch L) {
   ES *e = edges + grp * EDGE_N;
   const int pl = lane / CS, cl = lane % CS;
   {
-    const Pix *p = reinterpret_cast<const Pix *>(L.src[0]) + (size_t)f * L.h * L.stride_y + row_off(fy * BS, L.stride_y) + (size_t)(fx * BS);
+    const Pix *p = reinterpret_cast<const Pix *>(L.src[0]) + (size_t)f * L.frame_rows * L.stride_y + row_off(fy * BS, L.stride_y) + (size_t)(fx * BS);
     const int st = L.stride_y;
     // fast_build asks for row -1 / column -1 unconditionally and selects afterwards (harmless on the LDS lines of the closed loop):
     // here those are global addresses, outside the allocation at the frame's first row — answer 0 without a load
@@ -201,18 +201,18 @@ __global__ __launch_bounds__(256) void k_intra_modes(IntraPipeLaunch L) {
     load_row<BS>(p + (size_t)lane * st, s);
     fast_build<BS>(e, lane, bd, have_top ? BS : 0, have_tr ? BS : 0, have_left ? BS : 0, have_bl ? BS : 0, 0, fetch);
     const int m = search_modes<BS, BS, ES, false>(e, lane, bd, have_top ? BS : 0, have_left ? BS : 0, 0, s, bp);
-    if (lane == 0) L.modes_y[(size_t)f * per + blk] = (uint8_t)m;
+    if (lane == 0) L.modes_y[(size_t)f * L.modes_stride + blk] = (uint8_t)m;
   }
   AV1MI_GROUP_SYNC();
   {
-    const Pix *p = reinterpret_cast<const Pix *>(L.src[1 + pl]) + (size_t)f * (L.h / 2) * L.stride_uv + row_off(fy * CS, L.stride_uv) + (size_t)(fx * CS);
+    const Pix *p = reinterpret_cast<const Pix *>(L.src[1 + pl]) + (size_t)f * (L.frame_rows / 2) * L.stride_uv + row_off(fy * CS, L.stride_uv) + (size_t)(fx * CS);
     const int st = L.stride_uv;
     auto fetch = [&](int yy, int xx) -> int { return ((yy >= 0 || have_top) && (xx >= 0 || have_left)) ? (int)p[(ptrdiff_t)yy * st + xx] : 0; };
     int s[CS], bp[1];
     load_row<CS>(p + (size_t)cl * st, s);
     fast_build<CS>(e + pl * ELC, cl, bd, have_top ? CS : 0, have_tr ? CS : 0, have_left ? CS : 0, have_bl ? CS : 0, 0, fetch);
     const int m = search_modes<CS, BS, ES, false>(e + pl * ELC, cl, bd, have_top ? CS : 0, have_left ? CS : 0, 0, s, bp);
-    if (lane == 0) L.modes_uv[(size_t)f * per + blk] = (uint8_t)m;
+    if (lane == 0) L.modes_uv[(size_t)f * L.modes_stride + blk] = (uint8_t)m;
   }
 }
 
@@ -257,13 +257,13 @@ __global__ __launch_bounds__(256, BS == 8 ? 3 : 1) void k_intra_pipe(IntraPipeLa
   // block of its column, the left neighbour the latest of its row (z-order is monotone along both)
   uint8_t *col_my = reinterpret_cast<uint8_t *>(u) + EDGE_BYTES, *row_my = col_my + N, *col_mc = row_my + N, *row_mc = col_mc + N;
 
-  const Pix *src_y = reinterpret_cast<const Pix *>(L.src[0]) + (size_t)f * L.h * L.stride_y;
-  Pix *rec_y = reinterpret_cast<Pix *>(L.rec[0]) + (size_t)f * L.h * L.stride_y;
-  const Pix *src_c = reinterpret_cast<const Pix *>(L.src[1 + pl]) + (size_t)f * (L.h / 2) * L.stride_uv;
-  Pix *rec_c = reinterpret_cast<Pix *>(L.rec[1 + pl]) + (size_t)f * (L.h / 2) * L.stride_uv;
-  int16_t *lev_y = L.lev[0] + (size_t)f * L.w * L.h;
-  int16_t *lev_c = L.lev[1 + pl] + (size_t)f * (L.w / 2) * (L.h / 2);
-  uint8_t *modes_y = L.modes_y + (size_t)f * bw * bh, *modes_uv = L.modes_uv + (size_t)f * bw * bh;
+  const Pix *src_y = reinterpret_cast<const Pix *>(L.src[0]) + (size_t)f * L.frame_rows * L.stride_y;
+  Pix *rec_y = reinterpret_cast<Pix *>(L.rec[0]) + (size_t)f * L.frame_rows * L.stride_y;
+  const Pix *src_c = reinterpret_cast<const Pix *>(L.src[1 + pl]) + (size_t)f * (L.frame_rows / 2) * L.stride_uv;
+  Pix *rec_c = reinterpret_cast<Pix *>(L.rec[1 + pl]) + (size_t)f * (L.frame_rows / 2) * L.stride_uv;
+  int16_t *lev_y = L.lev[0] + (size_t)f * L.w * L.frame_rows;
+  int16_t *lev_c = L.lev[1 + pl] + (size_t)f * (L.w / 2) * (L.frame_rows / 2);
+  uint8_t *modes_y = L.modes_y + (size_t)f * L.modes_stride, *modes_uv = L.modes_uv + (size_t)f * L.modes_stride;
 
 #ifdef AV1MI_STAMPS
   unsigned long long av1mi_stamp_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, av1mi_stamp_last;

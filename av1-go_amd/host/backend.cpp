@@ -53,10 +53,70 @@ void DescribeSessionFrame(const av1mi_gop_frame &fr, int seg, int width, int hei
   if (fr.lev_y) { f.lev_y = fr.lev_y + o * 64; f.lev_u = fr.lev_u + o * 16; f.lev_v = fr.lev_v + o * 16; }     // absent when the tiles were coded on the GPU
 }
 
+// A key frame of a key_block_size 32 session (av1mi_gop_frame.key_block_size == 32): 32x32 blocks over the complete superblock rows,
+// 8x8 blocks in a last partial row — written by the general block writer (av1_blockstream.cpp) from the session's symbols.
+static bool Key32TemporalUnit(const av1mi_gop_frame &fr, int seg, const SessionFrameDesc &desc, int width, int height, bool with_sequence_header,
+                              std::vector<uint8_t> *out, std::string *err) {
+  if (!fr.y_mode || !fr.lev_y) { if (err) *err = "a key frame in 32x32 blocks needs its symbols (gpu_entropy 0)"; return false; }
+  const int hA = (height / 64) * 64, mi_rows = height / 4, mi_cols = width / 4;
+  const size_t ny = (size_t)width * height, nc = ny / 4;
+  const uint8_t *my = fr.y_mode + (size_t)seg * fr.key_modes_stride, *muv = fr.uv_mode + (size_t)seg * fr.key_modes_stride;
+  std::vector<int16_t> lev(ny + 2 * nc);
+  memcpy(lev.data(), fr.lev_y + (size_t)seg * ny, ny * 2);
+  memcpy(lev.data() + ny, fr.lev_u + (size_t)seg * nc, nc * 2);
+  memcpy(lev.data() + ny + nc, fr.lev_v + (size_t)seg * nc, nc * 2);
+  std::vector<uint8_t> parts;
+  std::vector<av1mi_obu_block> blocks;
+  auto block = [&](int r, int c, int bsize, int mode_y, int mode_uv, size_t oy, size_t oc) {
+    av1mi_obu_block b;
+    memset(&b, 0, sizeof(b));
+    b.mi_row = (uint16_t)r; b.mi_col = (uint16_t)c; b.bsize = (uint8_t)bsize; b.y_mode = (uint8_t)mode_y; b.uv_mode = (uint8_t)mode_uv;
+    b.tx_type_off = 0;                                   // every luma transform is DCT_DCT: one shared entry
+    b.lev_off[0] = (uint32_t)oy; b.lev_off[1] = (uint32_t)(ny + oc); b.lev_off[2] = (uint32_t)(ny + nc + oc);
+    blocks.push_back(b);
+  };
+  const int w32 = width / 32, w8 = width / 8;
+  for (int sr = 0; sr * 16 < mi_rows; sr++)
+    for (int sc = 0; sc * 16 < mi_cols; sc++) {
+      if (sr * 64 < hA) {                                // PARTITION_SPLIT at 64x64, four 32x32 blocks
+        parts.push_back(3);
+        for (int k = 0; k < 4; k++) {
+          const int r32 = sr * 2 + (k >> 1), c32 = sc * 2 + (k & 1);
+          const size_t i = (size_t)r32 * w32 + c32;
+          parts.push_back(0);
+          block(r32 * 8, c32 * 8, 9 /* BLOCK_32X32 */, my[i], muv[i], i * 1024, i * 256);
+        }
+      } else {                                           // the last, partial superblock row: split down to 8x8 wherever the frame reaches
+        const size_t oyB = (size_t)hA * width, ocB = oyB / 4;
+        const uint8_t *myB = my + fr.key_modes_band, *muvB = muv + fr.key_modes_band;
+        for (int k = 0; k < 64; k++) {                   // z-order over the superblock's 8x8 blocks; a level's symbol precedes its first block
+          int bx = 0, by = 0;
+          for (int i = 0; i < 3; i++) { bx |= ((k >> (2 * i)) & 1) << i; by |= ((k >> (2 * i + 1)) & 1) << i; }
+          const int r = sr * 16 + by * 2, c = sc * 16 + bx * 2;
+          for (int n8 = 8; n8 >= 2; n8 >>= 1)            // 64, 32, 16: PARTITION_SPLIT at every level that starts here, inside the frame
+            if (!(bx & (n8 - 1)) && !(by & (n8 - 1)) && r < mi_rows && c < mi_cols) parts.push_back(3);
+          if (r >= mi_rows || c >= mi_cols) continue;
+          parts.push_back(0);
+          const size_t i = (size_t)(r / 2 - hA / 8) * w8 + c / 2;
+          block(r, c, 3 /* BLOCK_8X8 */, myB[i], muvB[i], oyB + i * 64, ocB + i * 16);
+        }
+      }
+    }
+  av1mi_obu_blocks d;
+  memset(&d, 0, sizeof(d));
+  d.hdr = desc.f;
+  const uint8_t dct = 0;
+  d.partition = parts.data(); d.n_partition = parts.size(); d.blocks = blocks.data(); d.n_blocks = blocks.size(); d.tx_type = &dct; d.levels = lev.data();
+  std::string werr;
+  if (!av1::blocks_temporal_unit(d, with_sequence_header, out, &werr)) { if (err) *err = "bitstream writer: " + werr; return false; }
+  return true;
+}
+
 bool SessionTemporalUnit(const av1mi_gop_frame &fr, int seg, int width, int height, int bit_depth, int visible_width, int visible_height,
                          bool with_sequence_header, int threads, std::vector<uint8_t> *out, std::string *err) {
   SessionFrameDesc desc;
   DescribeSessionFrame(fr, seg, width, height, bit_depth, &desc, visible_width, visible_height);
+  if (fr.key_block_size == 32) return Key32TemporalUnit(fr, seg, desc, width, height, with_sequence_header, out, err);
   std::string werr;
   if (fr.tile_size) {      // tiles coded on the GPU: frame header + tile group around them
     const uint32_t *sz = fr.tile_size + (size_t)seg * fr.tiles_per_frame;

@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--e2e-host-segments", type=int, default=4, help="segments of the end-to-end leg with entropy coding on the host cores")
     ap.add_argument("--e2e-steps", type=int, default=2)
     ap.add_argument("--e2e-segments", type=int, default=8, help="segments in lockstep of the end-to-end leg (GPU entropy coding)")
+    ap.add_argument("--key-block-size", type=int, default=0, choices=[0, 8, 32],
+                    help="32: ALSO run the host-coder end-to-end leg with key frames in 32x32 blocks (e2e_key32; vs_libaom of that key frame)")
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="no GPU: exercise the rank/sharding/timing/aggregation plumbing with a stand-in step (gloo tests)")
     return ap.parse_args()
@@ -184,12 +186,15 @@ def libaom_leg(planes, bd, qindex, our_bytes, our_rec_y, threads):
 
 # ------------------------------------------------------------------------------------------------------------------ the legs
 def frame_unit(av1stream, W, H, bd, fr, sg, gpu_entropy, threads):
+    if fr.get("key_block_size") == 32:         # a key frame in 32x32 blocks: the library's general block writer (host entropy coding only)
+        return av1stream.session_temporal_unit(W, H, bd, fr["raw"], sg, with_sequence_header=True, threads=threads)
     if gpu_entropy and "tile_size" in fr:      # the tiles were coded on the GPU: the host only wraps them (frame header, tile-size fields)
         return av1stream.session_frame_unit_gpu(W, H, bd, fr, sg)
     return av1stream.session_frame_unit(W, H, bd, fr, sg, threads=threads)
 
 
-def e2e_leg(ctx, src, W, H, bd, qindex, gop, steps=2, warmup_frames=2, gpu_entropy=1, threads=16, compare_libaom=False, check=True, barrier=None):
+def e2e_leg(ctx, src, W, H, bd, qindex, gop, steps=2, warmup_frames=2, gpu_entropy=1, threads=16, compare_libaom=False, check=True, barrier=None,
+            key_block_size=0):
     """END TO END: what the transcode job does per frame (reference: file in -> file out, internal/ffmpeg/transcode.go:194-203):
     source planes from host memory into the session's pinned buffers, H2D upload, block pipeline + in-loop filters on the GPU, then
     either the GPU tile coder (gpu_entropy = 1: the payloads come back, the host adds frame header and tile sizes) or D2H of the
@@ -200,7 +205,7 @@ def e2e_leg(ctx, src, W, H, bd, qindex, gop, steps=2, warmup_frames=2, gpu_entro
     import av1mi
     import av1stream
     segs = src[0].shape[0]
-    sess = av1mi.GopSession(ctx, W, H, bd, qindex, gop, segs, gpu_entropy=gpu_entropy)
+    sess = av1mi.GopSession(ctx, W, H, bd, qindex, gop, segs, gpu_entropy=gpu_entropy, key_block_size=key_block_size)
     pool = ThreadPoolExecutor(max(1, min(threads, 3 * segs)))
     coded = {"bytes": 0, "frames": 0, "t_fill": 0.0, "t_code": 0.0, "t_wait": 0.0}
 
@@ -266,11 +271,14 @@ def e2e_leg(ctx, src, W, H, bd, qindex, gop, steps=2, warmup_frames=2, gpu_entro
     sess.close()
     pool.shutdown()
     if check:
-        out.update(decoder_check(ctx, src, W, H, bd, qindex, gop, gpu_entropy, threads, compare_libaom))
+        out.update(decoder_check(ctx, src, W, H, bd, qindex, gop, gpu_entropy, threads, compare_libaom, key_block_size))
+    if key_block_size == 32:
+        out["key_block_size"] = 32
+        out["what"] += "; KEY FRAMES IN 32x32 BLOCKS (av1mi_gop_config.key_block_size), written by the general block writer on one thread per frame"
     return out
 
 
-def decoder_check(ctx, src, W, H, bd, qindex, gop, gpu_entropy, threads, compare_libaom):
+def decoder_check(ctx, src, W, H, bd, qindex, gop, gpu_entropy, threads, compare_libaom, key_block_size=0):
     """the stream is real: the first two frames of segment 0 decoded by dav1d == the reference frames the GPU keeps"""
     import av1mi
     import av1stream
@@ -280,7 +288,7 @@ def decoder_check(ctx, src, W, H, bd, qindex, gop, gpu_entropy, threads, compare
         import dav1d_ref as D
         if not D.available():
             return {"decoder_check": {"decoder": None}}
-        chk = av1mi.GopSession(ctx, W, H, bd, qindex, gop, 1, gpu_entropy=gpu_entropy)
+        chk = av1mi.GopSession(ctx, W, H, bd, qindex, gop, 1, gpu_entropy=gpu_entropy, key_block_size=key_block_size)
         units, refs = [], []
         for t in range(min(2, src[0].shape[1])):
             planes = chk.input_planes()
@@ -300,7 +308,7 @@ def decoder_check(ctx, src, W, H, bd, qindex, gop, gpu_entropy, threads, compare
                 else:
                     # the image's libaom is an 8-bit build (it refuses 10-bit planes): compare on the 8-bit rendition of the same frame
                     s8 = [np.clip((src[p][0, 0].astype(np.int32) + 2) >> 2, 0, 255).astype(np.uint8) for p in range(3)]
-                    k8 = av1mi.GopSession(ctx, W, H, 8, qindex, 1, 1, gpu_entropy=gpu_entropy)
+                    k8 = av1mi.GopSession(ctx, W, H, 8, qindex, 1, 1, gpu_entropy=gpu_entropy, key_block_size=key_block_size)
                     for dst, a in zip(k8.input_planes(), s8):
                         np.copyto(dst, a)
                     k8.submit(0)
@@ -672,6 +680,10 @@ def main():
                 e = e2e_leg(ctx, [src[p][:hs] for p in range(3)], W, H, bd, args.qindex, gop, steps=1, gpu_entropy=0, threads=threads, compare_libaom=True)
                 out["e2e"] = e                      # north_star's split: entropy coding on the host cores
                 out["e2e_frames_per_s"] = e["frames_per_s"]
+                if args.key_block_size == 32 and W % 64 == 0:
+                    # the same leg with key frames in 32x32 blocks (host entropy coding is the only coder that knows them so far)
+                    out["e2e_key32"] = e2e_leg(ctx, [src[p][:hs] for p in range(3)], W, H, bd, args.qindex, gop, steps=1, gpu_entropy=0, threads=threads,
+                                               compare_libaom=True, key_block_size=32)
     if rank == 0:
         print(json.dumps(out))
     ctx.close()

@@ -261,6 +261,9 @@ typedef struct av1mi_intra_job {
                                               tile's serial chain), 1 = open loop (decided for all blocks at once from the SOURCE frame's
                                               neighbours, then one prediction per block in the chain).  The GOP session codes its key frames closed
                                               loop (AV1MI_INTRA_OPEN_LOOP=1 in the environment switches a session over, for measurements) */
+  int frame_rows;                          /* 0 = height.  Otherwise the job codes a BAND of `height` rows of every frame: the frames of a plane
+                                              are frame_rows luma rows apart (levels likewise), the pointers address the band's first row */
+  int modes_frame_stride;                  /* 0 = the job's blocks per frame; otherwise the mode bytes of consecutive frames are this far apart */
 } av1mi_intra_job;
 int av1mi_intra_encode(av1mi_ctx *ctx, const av1mi_intra_job *job);
 
@@ -357,6 +360,10 @@ typedef struct av1mi_gop_config {
    * behind the filters — slower, but every kernel then runs ALONE on the GPU: the arrangement for per-kernel measurements (bench.py
    * `kernels_isolated`, rocprofv3 passes).  The environment variable AV1MI_CODER_STREAMS = split | side | main overrides it. */
   int coder_streams;
+  int key_block_size;    /* 0 / 8: key frames in 8x8 blocks like every frame.  32: key frames in 32x32 blocks (luma 32x32 DCT, chroma 16x16,
+                            transform type by mode) over every COMPLETE superblock row, 8x8 blocks in a last partial row: +3.7 dB at equal
+                            size on the synthetic key frames at q 128, +1.85 dB at q 24.  Needs width % 64 == 0 and, until the
+                            GPU tile coder knows the larger transforms, gpu_entropy == 0 (av1mi_gop_open refuses otherwise) */
 } av1mi_gop_config;
 
 /* Frame-header parameters chosen by the session's policy for one frame (non-normative encoder choices; the bitstream carries
@@ -393,6 +400,11 @@ typedef struct av1mi_gop_frame {    /* one collected frame batch; host pointers 
   /* restoration ON (1) / OFF (0) per segment and plane, [segment * 3 + plane]: the encoder keeps params.lr_unit_* for a plane only
    * where it lowered the squared error against the source; an OFF plane is signalled with lr_type NONE in the frame header */
   const uint8_t *lr_on;
+  int key_block_size;               /* of this frame: 8, or 32 (key frames of a key_block_size 32 session).  32: y_mode / uv_mode hold, per
+                                       segment (stride key_modes_stride bytes), the modes of the 32x32 blocks of the complete superblock rows in
+                                       raster order, then from byte offset key_modes_band the 8x8 blocks of the last partial row; the levels
+                                       are block-contiguous per region in the same planes (a region's blocks tile its rows of the plane) */
+  int key_modes_stride, key_modes_band;
 } av1mi_gop_frame;
 
 typedef struct av1mi_gop av1mi_gop;

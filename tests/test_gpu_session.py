@@ -10,11 +10,13 @@ import dav1d_ref as D
 pytestmark = pytest.mark.gpu
 
 
-def _oracle_filters(O, r, bd, p, w, h, skip8, src):
+def _oracle_filters(O, r, bd, p, w, h, skip8, src, mi=None):
     """the oracle's filter chain with the session's parameters + its restoration ON / OFF decision against the source planes `src`:
-    returns (the planes the next frame predicts from = what a decoder outputs, [on_y, on_u, on_v])"""
+    returns (the planes the next frame predicts from = what a decoder outputs, [on_y, on_u, on_v]); mi: other deblocking mode-info maps"""
     mi_y = np.full((h // 4, w // 4), int(O.lf_mi(3, 3, p.lf_level[0], p.lf_level[1])), np.uint32)
     mi_c = np.full((h // 8, w // 8), int(O.lf_mi(2, 2, p.lf_level[2], p.lf_level[2])), np.uint32)
+    if mi is not None:
+        mi_y, mi_c = mi
     dbl = [O.deblock_plane(r["rec_y"], bd, 0, mi_y, p.lf_sharpness), O.deblock_plane(r["rec_u"], bd, 1, mi_c, p.lf_sharpness),
            O.deblock_plane(r["rec_v"], bd, 1, mi_c, p.lf_sharpness)]
     nsb = ((h + 63) // 64) * ((w + 63) // 64)
@@ -100,6 +102,99 @@ def test_session_stream_decodes_in_dav1d_to_the_gpu_reference(ctx, av1mi, w, h, 
                     assert (got[t][i] == refs[t][i][sgi * hh:(sgi + 1) * hh]).all(), "segment %d frame %d plane %d: dav1d differs from the GPU" % (sgi, t, i)
     finally:
         s.close()
+
+
+def _oracle_key32(O, Y, U, V, bd, q):
+    """the oracle's key frame the way a key_block_size 32 session codes it: 32x32 blocks over the complete superblock rows, 8x8 blocks
+    in a last partial row (tiles are single superblocks: the two bands share nothing)"""
+    h, w = Y.shape
+    hA = h // 64 * 64
+    a = O.intra_encode_frame(Y[:hA], U[:hA // 2], V[:hA // 2], bd, 32, q) if hA else None
+    b = O.intra_encode_frame(Y[hA:], U[hA // 2:], V[hA // 2:], bd, 8, q) if hA < h else None
+    rec = {k: np.concatenate([x[k] for x in (a, b) if x is not None]) for k in ("rec_y", "rec_u", "rec_v")}
+    return a, b, rec
+
+
+@pytest.mark.skipif(not D.available(), reason="no dav1d in this image")
+@pytest.mark.parametrize("w,h,bd,q,segs", [(192, 128, 8, 110, 2), (256, 168, 10, 60, 2), (1920, 1080, 8, 128, 1)])
+def test_key_frames_in_32x32_blocks(ctx, av1mi, O, w, h, bd, q, segs):
+    """av1mi_gop_config.key_block_size = 32 (host entropy coding for now): key frames in 32x32 blocks over the complete
+    superblock rows + 8x8 in a partial last row.  (1) symbols and reference frames equal the oracle's chain with the same rule,
+    P frames included (they predict from the 32x32-coded key frame); (2) the stream av1mi_session_temporal_unit writes — the general
+    block writer for the key frame, the 8x8 writer for the P frames — decodes in dav1d to the session's reference frames; (3) the
+    key frame is smaller than the 8x8 session's at a PSNR-Y that is no lower than 0.3 dB below it."""
+    import av1stream
+    import synth
+    gop = 3
+    Y, U, V = synth.frames(w, h, segs * gop, bd, 4)
+    hA = h // 64 * 64
+    sizes, psnr = {}, {}
+    for kbs in (32, 8):
+        s = av1mi.GopSession(ctx, w, h, bd, q, gop, segs, key_block_size=kbs)
+        try:
+            ref, streams, refs = [None] * segs, [b""] * segs, []
+            for t in range(gop):
+                planes = s.input_planes()
+                for sgi in range(segs):
+                    f = sgi * gop + t
+                    planes[0][sgi * h:(sgi + 1) * h] = Y[f]
+                    planes[1][sgi * h // 2:(sgi + 1) * h // 2] = U[f]
+                    planes[2][sgi * h // 2:(sgi + 1) * h // 2] = V[f]
+                s.submit()
+                fr = s.collect()
+                got = s.download_reference()
+                refs.append(got)
+                p = fr["params"]
+                for sgi in range(segs):
+                    unit = av1stream.session_temporal_unit(w, h, bd, fr["raw"], sgi, with_sequence_header=(t == 0), threads=4)
+                    streams[sgi] += unit
+                    if t == 0:
+                        sizes.setdefault(kbs, []).append(len(unit))
+                        mse = np.mean((got[0][sgi * h:(sgi + 1) * h].astype(np.float64) - Y[sgi * gop]) ** 2)
+                        psnr.setdefault(kbs, []).append(10 * np.log10(((1 << bd) - 1) ** 2 / mse))
+                    if kbs == 8 or (w * h > 500000 and t > 0):
+                        continue                  # (the oracle's P frames at 1080p take a minute each: the dav1d check below covers them)
+                    f = sgi * gop + t
+                    if t == 0:
+                        assert fr["key_block_size"] == 32
+                        a, b, rec = _oracle_key32(O, Y[f], U[f], V[f], bd, q)
+                        if a is not None:
+                            assert (fr["y_mode32"][sgi] == a["modes_y"]).all() and (fr["uv_mode32"][sgi] == a["modes_uv"]).all()
+                            for k in ("lev_y", "lev_u", "lev_v"):
+                                assert (fr[k + "32"][sgi] == a[k]).all(), (sgi, k)
+                        if b is not None:
+                            assert (fr["y_mode8"][sgi] == b["modes_y"]).all() and (fr["uv_mode8"][sgi] == b["modes_uv"]).all()
+                            for k in ("lev_y", "lev_u", "lev_v"):
+                                assert (fr[k + "8"][sgi] == b[k]).all(), (sgi, k)
+                        r, skip8 = rec, np.zeros((h // 8, w // 8), np.uint8)
+                        # the filters see 32x32 / 16x16 transform edges over the complete superblock rows
+                        mi_y = np.full((h // 4, w // 4), int(O.lf_mi(3, 3, p.lf_level[0], p.lf_level[1])), np.uint32)
+                        mi_c = np.full((h // 8, w // 8), int(O.lf_mi(2, 2, p.lf_level[2], p.lf_level[2])), np.uint32)
+                        mi_y[:hA // 4] = int(O.lf_mi(5, 5, p.lf_level[0], p.lf_level[1]))
+                        mi_c[:hA // 8] = int(O.lf_mi(4, 4, p.lf_level[2], p.lf_level[2]))
+                        ref[sgi], on = _oracle_filters(O, r, bd, p, w, h, skip8, (Y[f], U[f], V[f]), mi=(mi_y, mi_c))
+                    else:
+                        r = O.inter_encode_frame((Y[f], U[f], V[f]), ref[sgi], bd, q, 8)
+                        assert (fr["mv"][sgi] == r["mvs"]).all() and (fr["skip"][sgi] == r["skip"]).all()
+                        for k in ("lev_y", "lev_u", "lev_v"):
+                            assert (fr[k][sgi] == r[k]).all(), (t, sgi, k)
+                        ref[sgi], on = _oracle_filters(O, r, bd, p, w, h, r["skip"].reshape(h // 8, w // 8), (Y[f], U[f], V[f]))
+                    assert fr["lr_on"][sgi].tolist() == on
+                    for g_, e_, hh in ((got[0], ref[sgi][0], h), (got[1], ref[sgi][1], h // 2), (got[2], ref[sgi][2], h // 2)):
+                        assert (g_[sgi * hh:(sgi + 1) * hh] == e_).all(), "frame %d segment %d: reference differs from the oracle chain" % (t, sgi)
+            for sgi in range(segs):
+                dec = D.decode(streams[sgi])
+                assert len(dec) == gop
+                for t in range(gop):
+                    for i, hh in ((0, h), (1, h // 2), (2, h // 2)):
+                        assert (dec[t][i] == refs[t][i][sgi * hh:(sgi + 1) * hh]).all(), "key block size %d, segment %d frame %d plane %d: dav1d differs from the GPU" % (kbs, sgi, t, i)
+        finally:
+            s.close()
+    assert sum(sizes[32]) < sum(sizes[8]) and min(a - b for a, b in zip(psnr[32], psnr[8])) > -0.3, (sizes, psnr)
+    with pytest.raises(av1mi.Av1miError):
+        av1mi.GopSession(ctx, w, h, bd, q, gop, segs, key_block_size=32, gpu_entropy=1)        # the GPU tile coder codes 8x8 / 4x4 transforms
+    with pytest.raises(av1mi.Av1miError):
+        av1mi.GopSession(ctx, 136, 72, bd, q, gop, segs, key_block_size=32)                    # width must be a multiple of 64
 
 
 def test_session_api_misuse_is_reported(ctx, av1mi):
