@@ -46,7 +46,7 @@ _PTR_FIELDS = {"cdef_idx": np.uint8, "y_mode": np.uint8, "angle_y": np.int8, "uv
 def temporal_unit(width, height, bit_depth, base_q_idx, frame_type=0, with_sequence_header=True, threads=1, lf_level=(0, 0, 0, 0),
                   lf_sharpness=0, cdef_damping=3, cdef_bits=0, cdef_y=(0,), cdef_uv=(0,), lr_type=(0, 0, 0), lr_unit_shift=0, lr_uv_shift=0,
                   lr_units=(None, None, None), reduced_tx_set=0, disable_cdf_update=0, tile_cols_log2=-1, tile_rows_log2=-1, opstream=False,
-                  visible=None, **arrays):
+                  visible=None, key_rows32=0, **arrays):
     """arrays: y_mode, angle_y, uv_mode, angle_uv, cfl_alpha, skip, tx_type, is_inter, mv, lev_y, lev_u, lev_v, cdef_idx (numpy, raster
     order over 8x8 blocks; see av1_bitstream.hpp).  visible: (width, height) a decoder outputs when the coded size is the source's rounded up to 8.
     Returns bytes."""
@@ -82,7 +82,11 @@ def temporal_unit(width, height, bit_depth, base_q_idx, frame_type=0, with_seque
     out = np.empty(cap, np.uint8)
     err = C.create_string_buffer(256)
     if opstream:    # the op-stream formulation (the GPU tile coder's CPU twin, host/av1_opstream.cpp): must give the same bytes
-        n = lib().av1mi_host_opstream_temporal_unit(C.byref(f), int(with_sequence_header), out.ctypes.data, cap, err, 256)
+        # key_rows32: a key frame whose first rows are coded in 32x32 blocks, arrays in the session's layout (host/av1_opstream.cpp)
+        h = lib()
+        h.av1mi_host_opstream_key32_temporal_unit.restype = C.c_longlong
+        h.av1mi_host_opstream_key32_temporal_unit.argtypes = [C.POINTER(ObuFrame), C.c_int, C.c_int, C.c_void_p, C.c_longlong, C.c_char_p, C.c_int]
+        n = h.av1mi_host_opstream_key32_temporal_unit(C.byref(f), int(key_rows32), int(with_sequence_header), out.ctypes.data, cap, err, 256)
     else:
         n = lib().av1mi_obu_write_temporal_unit(C.byref(f), int(with_sequence_header), threads, out.ctypes.data, cap, err, 256)
     if n < 0:
@@ -105,7 +109,8 @@ class ObuBlocks(C.Structure):
 
 def blocks_temporal_unit(width, height, bit_depth, base_q_idx, partition, blocks, tx_type, levels, frame_type=0, with_sequence_header=True,
                          tx_mode_select=0, interp_filter=0, high_precision_mv=0, reduced_tx_set=0, disable_cdf_update=0, tile_cols_log2=-1,
-                         tile_rows_log2=-1, lf_level=(0, 0, 0, 0), lf_sharpness=0, cdef_damping=3, cdef_bits=0, cdef_y=(0,), cdef_uv=(0,), cdef_idx=None):
+                         tile_rows_log2=-1, lf_level=(0, 0, 0, 0), lf_sharpness=0, cdef_damping=3, cdef_bits=0, cdef_y=(0,), cdef_uv=(0,), cdef_idx=None,
+                         lr_type=(0, 0, 0), lr_units=(None, None, None), lr_unit_shift=0, lr_uv_shift=0):
     """the general block-structured writer (av1mi_obu_write_blocks_temporal_unit): partition = uint8 partition types in decoding order,
     blocks = array of BLOCK_DTYPE in decoding order, tx_type = uint8 per luma transform block, levels = int16 (see include/av1mi_host.h)"""
     d = ObuBlocks()
@@ -124,6 +129,12 @@ def blocks_temporal_unit(width, height, bit_depth, base_q_idx, partition, blocks
     if cdef_idx is not None:
         keep.append(np.ascontiguousarray(cdef_idx, np.uint8))
         f.cdef_idx = keep[-1].ctypes.data
+    for p in range(3):
+        f.lr_type[p] = int(lr_type[p])
+        if lr_units[p] is not None:
+            keep.append(np.ascontiguousarray(lr_units[p], np.int8))
+            f.lr_units[p] = keep[-1].ctypes.data
+    f.lr_unit_shift, f.lr_uv_shift = lr_unit_shift, lr_uv_shift
     d.tx_mode_select, d.interp_filter, d.high_precision_mv = int(tx_mode_select), int(interp_filter), int(high_precision_mv)
     d.partition, d.n_partition, d.blocks, d.n_blocks = keep[0].ctypes.data, keep[0].size, keep[1].ctypes.data, keep[1].size
     d.tx_type, d.levels = keep[2].ctypes.data, keep[3].ctypes.data

@@ -317,7 +317,7 @@ AV1_HD void inter_mode_decision(const FrameView &f, int r8, int c8, BlockInfo *o
 }
 
 // ------------------------------------------------------------------------------------------------ tokenizer
-AV1_HD void tok_subexp(Sink &k, int num_syms, int kk, int v) {        // decode_subexp_bool (5.11.58)
+template <class K> AV1_HD void tok_subexp(K &k, int num_syms, int kk, int v) {        // decode_subexp_bool (5.11.58)
   int i = 0, mk = 0;
   for (;;) {
     const int b2 = i ? kk + i - 1 : kk, a = 1 << b2;
@@ -334,7 +334,7 @@ AV1_HD void tok_subexp(Sink &k, int num_syms, int kk, int v) {        // decode_
   }
 }
 AV1_HD int tok_recenter(int r, int v) { return v > 2 * r ? v : v >= r ? 2 * (v - r) : 2 * (r - v) - 1; }
-AV1_HD void tok_signed_subexp_ref(Sink &k, int v, int low, int high, int kk, int r) {
+template <class K> AV1_HD void tok_signed_subexp_ref(K &k, int v, int low, int high, int kk, int r) {
   const int mx = high - low;
   v -= low; r -= low;
   tok_subexp(k, mx, kk, (r << 1) <= mx ? tok_recenter(r, v) : tok_recenter(mx - 1 - r, mx - 1 - v));

@@ -1,0 +1,232 @@
+// av1_ops32.hpp — the tile syntax of KEY FRAMES IN 32x32 BLOCKS (av1mi_gop_config.key_block_size = 32) as the same op
+// stream av1_ops.hpp makes of 8x8 blocks: records -> list words + grouped entries, after which the chains, the range coder and the
+// gather of av1_entropy_kernels.hip (and their CPU twins) run unchanged.  A tile is one complete 64x64 superblock: PARTITION_SPLIT, four
+// 32x32 blocks (PARTITION_NONE), luma transform 32x32 (DCT_DCT, not coded: the 32x32 set holds nothing else), chroma 16x16 with the
+// transform type implied by the mode, TX_MODE_LARGEST.  ONE THREAD PER TILE tokenizes serially (key frames are one frame in a GOP; the
+// unit of parallel work that would suit them better is a scan range of a transform block).
+// Shared source: hipcc for the device, g++ for the CPU twin (host/av1_opstream.cpp), verified there byte for byte against the general
+// block writer (host/av1_blockstream.cpp, itself verified by dav1d).
+#pragma once
+#include "av1_ops.hpp"
+
+namespace av1ops {
+
+enum SlotK32 : int {
+  K_SKIP = 0,                    // context 0 (key frames code skip = 0)
+  K_PART32 = 1,                  // context 0: the neighbours inside the tile are 32x32 blocks too
+  K_PART64 = 2,                  // context 0: nothing of the tile lies above or to the left of a superblock
+  K_USE_WIENER = 3,
+  K_TXB_SKIP_Y = 4,              // all_zero, luma: context 0 (the transform covers the block)
+  K_TXB_SKIP_C = 5,              // [3] chroma: contexts 7, 8, 9
+  K_EOB_Y = 8,                   // eob_pt_1024
+  K_EOB_C = 9,                   // eob_pt_256
+  K_EOBX_Y = 10,                 // [9] eob_extra
+  K_EOBX_C = 19,                 // [7]
+  K_DC_SIGN_Y = 26,              // [3]
+  K_DC_SIGN_C = 29,              // [3]
+  K_BASE_EOB_Y = 32,             // [4]
+  K_BASE_EOB_C = 36,             // [4]
+  K_BASE_Y = 40,                 // [26]
+  K_BASE_C = 66,                 // [26]
+  K_BR_Y = 92,                   // [21]
+  K_BR_C = 113,                  // [21]
+  K_KF_Y_MODE = 134,             // [5][5]
+  K_UV_MODE = 159,               // [13] chroma-from-luma allowed (blocks up to 32x32)
+  K_ANGLE = 172,                 // [8]
+  K_END = 180
+};
+static_assert((int)K_END <= (int)S_MAX, "the slot arrays of the coder are sized by S_MAX");
+
+AV1_HD int slot_nsym_k32(int s) {
+  if (s == K_SKIP) return 2;
+  if (s == K_PART32 || s == K_PART64) return 10;
+  if (s < K_EOB_Y) return 2;
+  if (s == K_EOB_Y) return 11;
+  if (s == K_EOB_C) return 9;
+  if (s < K_BASE_EOB_Y) return 2;
+  if (s < K_BASE_Y) return 3;
+  if (s < K_KF_Y_MODE) return 4;
+  if (s < K_UV_MODE) return 13;
+  if (s < K_ANGLE) return 14;
+  return 7;
+}
+AV1_HD void build_slot_table_k32(SlotTable *t) {
+  int o = 0;
+  for (int s = 0; s < S_MAX; s++) {
+    if (s < K_END) {
+      t->nsym[s] = (uint8_t)slot_nsym_k32(s);
+      const int w = slot_words(t->nsym[s]), al = w < 8 ? 4 : 8;
+      o = (o + al - 1) & ~(al - 1);
+      t->off[s] = (uint16_t)o;
+      o += w;
+    } else { t->nsym[s] = 2; t->off[s] = 0; }
+  }
+  t->words = (o + 7) & ~7;
+}
+
+// Default_Scan_16x16 / Default_Scan_32x32 (zig-zag: odd diagonals downwards) and their inverses
+struct ScanTables32 { uint16_t s32[1024], i32[1024]; uint8_t s16[256], i16[256]; };
+AV1_HD void fill_scan_tables32(ScanTables32 *t) {
+  for (int N = 16; N <= 32; N += 16) {
+    int k = 0;
+    for (int d = 0; d < 2 * N - 1; d++)
+      for (int i = 0; i <= d; i++) {
+        const int r = (d & 1) ? i : d - i, c = d - r;
+        if (r >= N || c >= N) continue;
+        if (N == 16) { t->s16[k] = (uint8_t)(r * N + c); t->i16[r * N + c] = (uint8_t)k; }
+        else { t->s32[k] = (uint16_t)(r * N + c); t->i32[r * N + c] = (uint16_t)k; }
+        k++;
+      }
+  }
+}
+enum { kMag32Stride = 36, kMag32Bytes = 36 * 34 };      // (32 + 2) rows of 32 + 2 (+ 2: a whole number of dwords)
+struct TokScratch32 { uint8_t *mag; const ScanTables32 *scan; };
+
+// the sink of a serial tokenizer: records in one run, 16-bit symbol counts per slot
+struct Sink32 {
+  uint16_t *rec; uint16_t *cnt;      // cnt[K_END]
+  int cap, nrec, n;
+  bool overflow;
+  AV1_HD void put(unsigned r) { if (nrec < cap) rec[nrec] = (uint16_t)r; else overflow = true; nrec++; n++; }
+  AV1_HD void sym(int slot, int s) { put(((unsigned)slot << 4) | (unsigned)s); if (cnt[slot] == 65535) overflow = true; else cnt[slot]++; }
+  AV1_HD void lit(unsigned v, int nbits) {
+    while (nbits > 11) { nbits -= 11; put(0x8000u | (11u << 11) | ((v >> nbits) & 0x7FFu)); }
+    if (nbits > 0) put(0x8000u | ((unsigned)nbits << 11) | (v & ((1u << nbits) - 1u)));
+  }
+};
+
+// coeffs() (5.11.39) of one N x N transform block (N = 32 luma / 16 chroma), 2-D class; cul / dc: this block's level summary for its
+// neighbours (min(63, sum |level|); 0 none / 1 negative / 2 positive)
+template <int N> AV1_HD void tok_coeffs_big(Sink32 &k, const TokScratch32 &ts, bool chroma, const int16_t *lev, int above_cul, int above_dc, int left_cul,
+                                            int left_dc, int *cul_out, int *dc_out) {
+  const int nc = N * N, LG = N == 16 ? 4 : 5, MS = kMag32Stride;
+  uint8_t *mag = ts.mag;
+  for (int i = 0; i < (N + 2) * MS / 4; i++) reinterpret_cast<u32a *>(mag)[i] = 0;
+  int eob = 0, cul = 0;
+  for (int r = 0; r < nc / 8; r++) {
+    struct alignas(16) L8 { int16_t v[8]; } q = *reinterpret_cast<const L8 *>(lev + 8 * r);
+    for (int j = 0; j < 8; j++) {
+      const int pos = 8 * r + j, v = q.v[j], a = iabs(v);
+      if (v) { eob = imax(eob, (N == 16 ? (int)ts.scan->i16[pos] : (int)ts.scan->i32[pos]) + 1); cul += a; }
+      mag[(pos >> LG) * MS + (pos & (N - 1))] = (uint8_t)((a > 15 ? 15 : a) | (v < 0 ? 128 : 0));
+    }
+  }
+  *cul_out = imin(cul, 63); *dc_out = lev[0] < 0 ? 1 : lev[0] > 0 ? 2 : 0;
+  k.sym(chroma ? K_TXB_SKIP_C + ((above_cul | above_dc) != 0) + ((left_cul | left_dc) != 0) : K_TXB_SKIP_Y, eob == 0);
+  if (!eob) return;
+  const int eob_pt = eob < 3 ? eob : ilog2((unsigned)(eob - 1)) + 2;
+  k.sym(chroma ? K_EOB_C : K_EOB_Y, eob_pt - 1);
+  if (eob_pt >= 3) {
+    const int off = eob - ((1 << (eob_pt - 2)) + 1), shift = eob_pt - 3;
+    k.sym((chroma ? K_EOBX_C : K_EOBX_Y) + eob_pt - 3, (off >> shift) & 1);
+    if (shift > 0) k.lit((unsigned)(off & ((1 << shift) - 1)), shift);
+  }
+  const int base_eob = chroma ? K_BASE_EOB_C : K_BASE_EOB_Y, base = chroma ? K_BASE_C : K_BASE_Y, br = chroma ? K_BR_C : K_BR_Y;
+  for (int c = eob - 1; c >= 0; c--) {
+    const int pos = N == 16 ? (int)ts.scan->s16[c] : (int)ts.scan->s32[c], row = pos >> LG, col = pos & (N - 1);
+    const uint8_t *m = mag + row * MS + col;
+    const int m0 = m[0] & 15, m1 = m[1] & 15, m2 = m[2] & 15, mb = m[MS] & 15, md = m[MS + 1] & 15, mbb = m[2 * MS] & 15;
+    int a = m0;
+    if (a == 15) a = iabs(lev[pos]);
+    if (c == eob - 1) {
+      k.sym(base_eob + (c == 0 ? 0 : c <= nc / 8 ? 1 : c <= nc / 4 ? 2 : 3), imin(a, 3) - 1);
+    } else {
+      const int mm = imin(m1, 3) + imin(mb, 3) + imin(md, 3) + imin(m2, 3) + imin(mbb, 3);
+      int bctx = imin((mm + 1) >> 1, 4);
+      if (pos == 0) bctx = 0;
+      else bctx += row + col < 2 ? 1 : row + col < 4 ? 6 : 21;
+      k.sym(base + bctx, imin(a, 3));
+    }
+    if (a > 2) {
+      int mm = m1 + mb + md;
+      mm = imin((mm + 1) >> 1, 6);
+      const int rctx = pos == 0 ? mm : (row < 2 && col < 2) ? mm + 7 : mm + 14;
+      int rem = a - 3;
+      for (int i = 0; i < 4; i++) {
+        const int q = imin(rem, 3);
+        k.sym(br + rctx, q);
+        rem -= q;
+        if (q < 3) break;
+      }
+    }
+  }
+  for (int c = 0; c < eob; c++) {
+    const int pos = N == 16 ? (int)ts.scan->s16[c] : (int)ts.scan->s32[c], m = mag[(pos >> LG) * MS + (pos & (N - 1))];
+    if (!m) continue;
+    const int neg = m >> 7;
+    if (c == 0) {
+      const int sg = (above_dc == 2) - (above_dc == 1) + (left_dc == 2) - (left_dc == 1);
+      k.sym((chroma ? K_DC_SIGN_C : K_DC_SIGN_Y) + (sg < 0 ? 1 : sg > 0 ? 2 : 0), neg);
+    } else {
+      k.lit((unsigned)neg, 1);
+    }
+    if ((m & 15) == 15) {
+      const int a = iabs(lev[pos]);
+      if (a > 14) {
+        const unsigned x = (unsigned)(a - 14);
+        const int len = ilog2(x) + 1;
+        k.lit(0, len - 1);
+        k.lit(x, len);
+      }
+    }
+  }
+}
+
+// read_lr for the superblock (av1_ops.hpp tok_lr with this frame kind's slot)
+AV1_HD void tok_lr32(const FrameView &f, Sink32 &k, int sbr, int sbc) {
+  const int mi_r = sbr * 16, mi_c = sbc * 16;
+  for (int p = 0; p < 3; p++) {
+    if (!f.lr_on[p]) continue;
+    const int ss = p ? 1 : 0, us = 64;
+    const int row0 = (mi_r * (4 >> ss) + us - 1) / us, row1 = imin(((mi_r + 16) * (4 >> ss) + us - 1) / us, f.lr_rows[p]);
+    const int col0 = (mi_c * (4 >> ss) + us - 1) / us, col1 = imin(((mi_c + 16) * (4 >> ss) + us - 1) / us, f.lr_cols[p]);
+    const int8_t *u = f.lr_unit[p ? 1 : 0];
+    for (int ur = row0; ur < row1; ur++)
+      for (int uc = col0; uc < col1; uc++) {
+        k.sym(K_USE_WIENER, u[0] == 1);
+        if (u[0] != 1) continue;
+        const int kmin[3] = { -5, -23, -17 }, kmax[3] = { 10, 8, 46 }, kk[3] = { 1, 2, 3 }, mid[3] = { 3, -7, 15 };
+        for (int pass = 0; pass < 2; pass++)
+          for (int j = p ? 1 : 0; j < 3; j++) tok_signed_subexp_ref(k, u[1 + pass * 3 + j], kmin[j], kmax[j] + 1, kk[j], mid[j]);
+      }
+  }
+}
+
+// all ops of the tile = superblock (sbr, sbc) of a key frame's 32x32 band.  f.y_mode / f.uv_mode: the band's modes, one per 32x32 block
+// in raster order (w8 / 4 per row); f.lev_*: block-contiguous over the same grid (1024 luma, 256 + 256 chroma levels per block)
+AV1_HD void tok_tile32(const FrameView &f, Sink32 &k, const TokScratch32 &ts, int sbr, int sbc) {
+  static const uint8_t kCtx[13] = { 0, 1, 2, 3, 4, 4, 4, 4, 3, 0, 1, 2, 0 };     // Intra_Mode_Context
+  const int w32 = f.w8 / 4;
+  tok_lr32(f, k, sbr, sbc);
+  k.sym(K_PART64, 3);                            // PARTITION_SPLIT
+  int cul[4][3], dc[4][3];
+  for (int b = 0; b < 4; b++) {
+    const int by = b >> 1, bx = b & 1;
+    const long i = (long)(sbr * 2 + by) * w32 + sbc * 2 + bx;
+    k.sym(K_PART32, 0);                          // PARTITION_NONE
+    k.sym(K_SKIP, 0);
+    const int ym = f.y_mode[i], uvm = f.uv_mode[i];
+    k.sym(K_KF_Y_MODE + kCtx[by ? f.y_mode[i - w32] : 0] * 5 + kCtx[bx ? f.y_mode[i - 1] : 0], ym);
+    if (ym >= 1 && ym <= 8) k.sym(K_ANGLE + ym - 1, 3);
+    k.sym(K_UV_MODE + ym, uvm);
+    if (uvm >= 1 && uvm <= 8) k.sym(K_ANGLE + uvm - 1, 3);
+    for (int p = 0; p < 3; p++) {
+      const int ac = by ? cul[b - 2][p] : 0, ad = by ? dc[b - 2][p] : 0, lc = bx ? cul[b - 1][p] : 0, ld = bx ? dc[b - 1][p] : 0;
+      if (p == 0) tok_coeffs_big<32>(k, ts, false, f.lev_y + i * 1024, ac, ad, lc, ld, &cul[b][p], &dc[b][p]);
+      else tok_coeffs_big<16>(k, ts, true, (p == 1 ? f.lev_u : f.lev_v) + i * 256, ac, ad, lc, ld, &cul[b][p], &dc[b][p]);
+    }
+  }
+}
+
+// the records of a serially tokenized tile -> list words and grouped entries; pos[K_END]: the slots' running positions
+AV1_HD int replay_tile32(const uint16_t *rec, int nrec, uint16_t *pos, op_t *list, uint32_t *grouped) {
+  int n = 0;
+  for (int i = 0; i < nrec; i++, n++) {
+    const unsigned r = rec[i];
+    if (r & 0x8000u) list[n] = op_lit((int)((r >> 11) & 15), r & 0x7FFu);
+    else { const int sl = (int)(r >> 4); grouped[pos[sl]] = ((uint32_t)n << 4) | (r & 15u); pos[sl]++; }
+  }
+  return n;
+}
+
+}  // namespace av1ops

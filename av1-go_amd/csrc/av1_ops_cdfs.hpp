@@ -3,6 +3,7 @@
 #pragma once
 #include <vector>
 #include "av1_ops.hpp"
+#include "av1_ops32.hpp"
 #include "../host/av1_default_cdfs.inc"
 
 namespace av1ops {
@@ -52,6 +53,33 @@ inline std::vector<uint16_t> default_slot_image(bool key, int qcat, SlotTable *t
     }
     put(S_INTER_TX, Default_Inter_Tx_Type_Set1_Cdf[1], 16);
   }
+  return img;
+}
+
+// the same for the tiles of a key frame's 32x32 band (av1_ops32.hpp): luma 32x32 (transform-size context 3, plane type 0), chroma
+// 16x16 (context 2, plane type 1)
+inline std::vector<uint16_t> default_slot_image_k32(int qcat, SlotTable *t) {
+  build_slot_table_k32(t);
+  std::vector<uint16_t> img((size_t)t->words, 0);
+  auto put = [&](int slot, const uint16_t *spec, int nsym) {
+    for (int i = 0; i < nsym - 1; i++) img[t->off[slot] + i] = (uint16_t)(32768 - spec[i]);
+  };
+  put(K_SKIP, Default_Skip_Cdf[0], 2);
+  put(K_PART32, Default_Partition_W32_Cdf[0], 10); put(K_PART64, Default_Partition_W64_Cdf[0], 10);
+  put(K_USE_WIENER, Default_Use_Wiener_Cdf[0], 2);
+  put(K_TXB_SKIP_Y, Default_Txb_Skip_Cdf[qcat][3][0], 2);
+  for (int i = 0; i < 3; i++) put(K_TXB_SKIP_C + i, Default_Txb_Skip_Cdf[qcat][2][7 + i], 2);
+  put(K_EOB_Y, Default_Eob_Pt_1024_Cdf[qcat][0][0], 11);
+  put(K_EOB_C, Default_Eob_Pt_256_Cdf[qcat][1][0], 9);
+  for (int i = 0; i < 9; i++) put(K_EOBX_Y + i, Default_Eob_Extra_Cdf[qcat][3][0][i], 2);
+  for (int i = 0; i < 7; i++) put(K_EOBX_C + i, Default_Eob_Extra_Cdf[qcat][2][1][i], 2);
+  for (int i = 0; i < 3; i++) { put(K_DC_SIGN_Y + i, Default_Dc_Sign_Cdf[qcat][0][i], 2); put(K_DC_SIGN_C + i, Default_Dc_Sign_Cdf[qcat][1][i], 2); }
+  for (int i = 0; i < 4; i++) { put(K_BASE_EOB_Y + i, Default_Coeff_Base_Eob_Cdf[qcat][3][0][i], 3); put(K_BASE_EOB_C + i, Default_Coeff_Base_Eob_Cdf[qcat][2][1][i], 3); }
+  for (int i = 0; i < 26; i++) { put(K_BASE_Y + i, Default_Coeff_Base_Cdf[qcat][3][0][i], 4); put(K_BASE_C + i, Default_Coeff_Base_Cdf[qcat][2][1][i], 4); }
+  for (int i = 0; i < 21; i++) { put(K_BR_Y + i, Default_Coeff_Br_Cdf[qcat][3][0][i], 4); put(K_BR_C + i, Default_Coeff_Br_Cdf[qcat][2][1][i], 4); }
+  for (int a = 0; a < 5; a++) for (int l = 0; l < 5; l++) put(K_KF_Y_MODE + a * 5 + l, Default_Intra_Frame_Y_Mode_Cdf[a][l], 13);
+  for (int m = 0; m < 13; m++) put(K_UV_MODE + m, Default_Uv_Mode_Cfl_Allowed_Cdf[m], 14);
+  for (int i = 0; i < 8; i++) put(K_ANGLE + i, Default_Angle_Delta_Cdf[i], 7);
   return img;
 }
 

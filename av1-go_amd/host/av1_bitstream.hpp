@@ -54,7 +54,7 @@ bool frame_obu_from_tiles(const av1mi_obu_frame &f, const uint8_t *payloads, con
 // the writer's range coder over a raw list of interval updates (tests: the op-stream coder's lazy byte output against this one)
 std::vector<uint8_t> range_code_raw(const uint32_t *fl, const uint32_t *fh, const uint8_t *sym, const uint8_t *nsym, size_t count);
 bool opstream_supported(const av1mi_obu_frame &f, std::string *why);
-bool opstream_tiles(const av1mi_obu_frame &f, std::vector<std::vector<uint8_t>> *tiles, std::string *err);
+bool opstream_tiles(const av1mi_obu_frame &f, std::vector<std::vector<uint8_t>> *tiles, std::string *err, int key_rows32 = 0);
 // the general block-structured writer (av1_blockstream.cpp, include/av1mi_host.h av1mi_obu_blocks): one temporal unit
 bool blocks_temporal_unit(const av1mi_obu_blocks &d, bool with_sequence_header, std::vector<uint8_t> *out, std::string *err);
 // one temporal unit: delimiter [+ sequence header] + frame

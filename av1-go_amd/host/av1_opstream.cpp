@@ -27,9 +27,13 @@ bool opstream_supported(const av1mi_obu_frame &f, std::string *why) {
 }
 
 // tile payloads (range-coded, finished) of a frame through tokenize + code; tiles in raster order
-bool opstream_tiles(const av1mi_obu_frame &f, std::vector<std::vector<uint8_t>> *tiles, std::string *err) {
+// key_rows32 > 0: a key frame whose first key_rows32 luma rows (whole superblock rows) are coded in 32x32 blocks (av1_ops32.hpp; the
+// symbol arrays in the session's layout: those rows' modes one per 32x32 block from entry 0, levels block-contiguous over the 32x32
+// grid; the rows below in the 8x8 layout at their usual places)
+bool opstream_tiles(const av1mi_obu_frame &f, std::vector<std::vector<uint8_t>> *tiles, std::string *err, int key_rows32) {
   using namespace av1ops;
   if (!opstream_supported(f, err)) return false;
+  if (key_rows32 && (f.frame_type != 0 || (key_rows32 & 63) || key_rows32 > f.height || (f.width & 63))) { if (err) *err = "bad 32x32 band"; return false; }
   FrameView v;
   memset(&v, 0, sizeof(v));
   v.w8 = f.width / 8; v.h8 = f.height / 8; v.key = f.frame_type == 0;
@@ -73,8 +77,44 @@ bool opstream_tiles(const av1mi_obu_frame &f, std::vector<std::vector<uint8_t>> 
   // words per tile — to stderr; tiles over capacity are skipped instead of failing the call
   const bool stats = getenv("AV1MI_TOK_STATS") != nullptr;
   int st_rec = 0, st_cnt = 0, st_ops = 0, st_over = 0; long st_ops_sum = 0;
+  // the 32x32 band's own slot table, default CDFs, scan tables and scratch
+  SlotTable tab32;
+  const std::vector<uint16_t> image32 = key_rows32 ? default_slot_image_k32(qcat, &tab32) : std::vector<uint16_t>();
+  std::vector<uint16_t> rec32(key_rows32 ? (size_t)kBlocksPerTile * kBlockRecords : 0), cnt32(K_END), pos32(K_END);
+  std::vector<ScanTables32> scan32(key_rows32 ? 1 : 0);
+  if (key_rows32) fill_scan_tables32(scan32.data());
+  alignas(16) uint8_t mag32[kMag32Bytes];
   for (int sbr = 0; sbr < sbr_n; sbr++)
     for (int sbc = 0; sbc < sbc_n; sbc++) {
+      if (sbr * 64 < key_rows32) {
+        // a tile of the 32x32 band: tokenized serially (the GPU: one lane per tile), then the same chains and the same range coder
+        std::fill(cnt32.begin(), cnt32.end(), 0);
+        Sink32 k = { rec32.data(), cnt32.data(), (int)rec32.size(), 0, 0, false };
+        const TokScratch32 ts32 = { mag32, scan32.data() };
+        tok_tile32(v, k, ts32, sbr, sbc);
+        if (k.overflow) { if (err) *err = "a tile exceeds the tokenizer's record area"; return false; }
+        int base[K_END], total[K_END], run = 0;
+        for (int sl = 0; sl < K_END; sl++) {
+          base[sl] = run; total[sl] = cnt32[(size_t)sl]; pos32[(size_t)sl] = (uint16_t)run;
+          run = (run + total[sl] + kListAlign - 1) & ~(kListAlign - 1);
+        }
+        if (run > 65535) { if (err) *err = "tile too large for 16-bit entry positions"; return false; }
+        list.assign((size_t)k.n, 0);
+        grouped.assign((size_t)run, 0);
+        const int nops = replay_tile32(rec32.data(), k.nrec, pos32.data(), list.data(), grouped.data());
+        for (int sl = 0; sl < K_END; sl++)
+          if (total[sl]) run_chain(&image32[tab32.off[sl]], tab32.nsym[sl], &grouped[(size_t)base[sl]], total[sl], list.data());
+        std::vector<uint8_t> &out = (*tiles)[(size_t)sbr * sbc_n + sbc];
+        out.resize((size_t)nops * 2 + 64);
+        Coder c;
+        uint16_t stage[Coder::kStage];
+        c.init(out.data(), (int)out.size(), stage);
+        for (int i = 0; i < nops; i++) code_word(c, list[(size_t)i]);
+        const int n = c.finish();
+        if (n < 0) { if (err) *err = "tile payload overflow"; return false; }
+        out.resize((size_t)n);
+        continue;
+      }
       // stage 1, tokenize (the GPU: one thread per block): records + counts, place, replay
       std::fill(cnt.begin(), cnt.end(), 0);
       int first[kBlocksPerTile + 1], nrec[kBlocksPerTile];

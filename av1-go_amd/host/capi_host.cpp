@@ -159,11 +159,14 @@ long long av1mi_obu_assemble_temporal_unit(const av1mi_obu_frame *f, const uint8
   return (long long)b.size();
 }
 // the op-stream path on the host (av1_opstream.cpp): same contract as av1mi_obu_write_temporal_unit; -2 = outside its tool set
-long long av1mi_host_opstream_temporal_unit(const av1mi_obu_frame *f, int with_sequence_header, uint8_t *out, long long cap, char *err, int errcap) {
+// key_rows32 > 0: a key frame whose first key_rows32 luma rows are coded in 32x32 blocks (symbol arrays in the session's layout, see
+// av1_opstream.cpp opstream_tiles)
+long long av1mi_host_opstream_key32_temporal_unit(const av1mi_obu_frame *f, int key_rows32, int with_sequence_header, uint8_t *out, long long cap, char *err,
+                                                  int errcap) {
   std::vector<std::vector<uint8_t>> tiles; std::string e;
   auto fail = [&](long long code) { if (err && errcap > 0) { strncpy(err, e.c_str(), errcap - 1); err[errcap - 1] = 0; } return code; };
   if (!av1::opstream_supported(*f, &e)) return fail(-2);
-  if (!av1::opstream_tiles(*f, &tiles, &e)) return fail(-1);
+  if (!av1::opstream_tiles(*f, &tiles, &e, key_rows32)) return fail(-1);
   std::vector<uint8_t> cat; std::vector<uint32_t> sizes;
   for (auto &t : tiles) { sizes.push_back((uint32_t)t.size()); cat.insert(cat.end(), t.begin(), t.end()); }
   std::vector<uint8_t> fr;
@@ -177,6 +180,9 @@ long long av1mi_host_opstream_temporal_unit(const av1mi_obu_frame *f, int with_s
   b.insert(b.end(), fr.begin(), fr.end());
   if ((long long)b.size() <= cap && out) memcpy(out, b.data(), b.size());
   return (long long)b.size();
+}
+long long av1mi_host_opstream_temporal_unit(const av1mi_obu_frame *f, int with_sequence_header, uint8_t *out, long long cap, char *err, int errcap) {
+  return av1mi_host_opstream_key32_temporal_unit(f, 0, with_sequence_header, out, cap, err, errcap);
 }
 // job record + GPU probe hooks for the CPU tests
 int av1mi_host_job_json(const char *id, const char *source, const char *status, const char *reason, long long orig, long long neu, char *buf, int cap) {

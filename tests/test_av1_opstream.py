@@ -96,3 +96,59 @@ def test_lazy_byte_output_equals_the_eager_coder_including_late_carries():
         assert f(seed, 2000000, ctypes.byref(c)) == 0, "seed %d" % seed
         total += c.value
     assert total >= 1
+
+
+@pytest.mark.parametrize("w,h,bd,q,lr", [(64, 64, 8, 128, False), (192, 128, 8, 60, True), (256, 168, 10, 23, True), (128, 104, 8, 200, False),
+                                         (320, 192, 10, 128, True), (1920, 1080, 8, 128, True)])
+def test_key_frames_in_32x32_blocks_twin_equals_the_block_writer(O, w, h, bd, q, lr):
+    """key frames of a key_block_size 32 session: 32x32 blocks over the complete superblock rows, 8x8 blocks in a last
+    partial row.  The serial tile tokenizer of csrc/av1_ops32.hpp + the unchanged chains and range coder (host/av1_opstream.cpp: what
+    the GPU runs) must give the bytes of the general block writer for the same symbols, and dav1d must decode them to the oracle's
+    reconstruction."""
+    import av1stream
+    import synth
+    import av1_blocks as B
+    import dav1d_ref as D
+    Y, U, V = (a[0] for a in synth.frames(w, h, 1, bd, 3))
+    hA = h // 64 * 64
+    a = O.intra_encode_frame(Y[:hA], U[:hA // 2], V[:hA // 2], bd, 32, q)
+    b = O.intra_encode_frame(Y[hA:], U[hA // 2:], V[hA // 2:], bd, 8, q) if hA < h else None
+    # the general block writer's view of the frame
+    lay = B.Layout(w, h)
+    w32, w8 = w // 32, w // 8
+
+    def chooser(r, c, bsize, allowed):
+        return B.uniform_chooser(9 if r * 4 < hA else 3)(r, c, bsize, allowed)
+    parts, tree = B.build_tree(lay, chooser)
+    blocks = []
+    for r, c, bsize, tb in tree:
+        if r * 4 < hA:
+            o, i = a, (r // 8) * w32 + c // 8
+        else:
+            o, i = b, ((r * 4 - hA) // 8) * w8 + c // 2
+        blocks.append(dict(r=r, c=c, bsize=bsize, tile=tb, skip=0, is_inter=0, y_mode=int(o["modes_y"][i]), uv_mode=int(o["modes_uv"][i]), angle_y=0, angle_uv=0,
+                           cfl=(0, 0), tx_depth=0, filt=0, mv=(0, 0), tx=B.max_tx_rect(bsize), tx_types=[0], levels=[[o["lev_y"][i]], [o["lev_u"][i]], [o["lev_v"][i]]]))
+    hdr = {}
+    if lr:
+        ur = lambda n: max(1, (n + 32) // 64)
+        uy = np.tile(np.array([1, 3, -7, 15, 3, -7, 15, 0], np.int8), (ur(h), ur(w), 1))
+        uc = np.tile(np.array([1, 0, -7, 15, 0, -7, 15, 0], np.int8), (ur(h // 2), ur(w // 2), 1))
+        hdr = dict(lr_type=(1, 0, 1), lr_units=(uy, uc, uc), lf_level=(9, 7, 5, 5), cdef_y=(5,), cdef_uv=(4,), cdef_damping=4)
+    ref = B.encode(lay, bd, q, parts, blocks, **hdr)
+    # the session's layout of the same symbols
+    nb = (h // 8) * w8
+    ym, uvm = np.zeros(nb, np.uint8), np.zeros(nb, np.uint8)
+    ly, lu, lv = np.zeros(h * w, np.int16), np.zeros(h * w // 4, np.int16), np.zeros(h * w // 4, np.int16)
+    nA = (hA // 32) * w32
+    ym[:nA], uvm[:nA] = a["modes_y"], a["modes_uv"]
+    ly[:hA * w], lu[:hA * w // 4], lv[:hA * w // 4] = a["lev_y"].reshape(-1), a["lev_u"].reshape(-1), a["lev_v"].reshape(-1)
+    if b is not None:
+        o8 = (hA // 8) * w8
+        ym[o8:], uvm[o8:] = b["modes_y"], b["modes_uv"]
+        ly[hA * w:], lu[hA * w // 4:], lv[hA * w // 4:] = b["lev_y"].reshape(-1), b["lev_u"].reshape(-1), b["lev_v"].reshape(-1)
+    twin = av1stream.temporal_unit(w, h, bd, q, opstream=True, key_rows32=hA, y_mode=ym, uv_mode=uvm, lev_y=ly, lev_u=lu, lev_v=lv, **hdr)
+    assert twin == ref
+    if D.available():
+        pic = D.decode(twin, inloop_filters=0)[0]
+        rec = np.concatenate([a["rec_y"]] + ([b["rec_y"]] if b is not None else []))
+        assert np.array_equal(np.asarray(pic[0]), rec)
