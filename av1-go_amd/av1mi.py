@@ -174,12 +174,13 @@ class GopSession:
         S, nb = f.segments, f.blocks_per_frame
         out = dict(params=f.params, frame_type=f.params.frame_type, lr_on=_view(f.lr_on, (S, 3), np.uint8), raw=f)      # restoration on / off per segment and plane
         if f.key_block_size == 32:
+            out["key_block_size"] = 32
+        if f.key_block_size == 32 and f.lev_y:
             # a key frame in 32x32 blocks: per segment the blocks of the complete superblock rows ("32": modes, levels [n, 32, 32] and the
             # 16x16 chroma), then the 8x8 blocks of a last partial row ("8")
             w, h = self.w, self.h
             hA = h // 64 * 64
             nA, nB = (hA // 32) * (w // 32), ((h - hA) // 8) * (w // 8)
-            out["key_block_size"] = 32
             for name, ptr in (("y_mode", f.y_mode), ("uv_mode", f.uv_mode)):
                 m = _view(ptr, (S, f.key_modes_stride), np.uint8)
                 out[name + "32"], out[name + "8"] = m[:, :nA], m[:, f.key_modes_band:f.key_modes_band + nB]

@@ -17,6 +17,7 @@
 #include <string.h>
 #include <vector>
 #include "av1_ops_cdfs.hpp"
+#include "av1_ops32.hpp"
 #include "av1mi_internal.hpp"
 
 namespace av1mi {
@@ -38,7 +39,11 @@ struct Av1EntLaunch {
   uint8_t *out; uint64_t out_cap;
   const uint16_t *cdf_image; int cdf_words;   // default slot image of this frame type / q category
   SlotTable tab;
+  const uint16_t *cdf_image32; SlotTable tab32;   // the same for the tiles of a key frame's 32x32 band
   const uint8_t *lr_on_frame;   // optional: [frame * 3 + plane], 0 = restoration of the plane is off in that frame
+  // key frames in 32x32 blocks (av1_ops32.hpp): the first sb_rows32 superblock rows of every frame are tiles of that kind, with their
+  // own slot table and default CDFs; `band` selects which tiles a chains launch walks (0 all, 1 the 32x32 band, 2 the rows below)
+  int sb_rows32, band, nslots;
 };
 
 __device__ __forceinline__ FrameView frame_view(const Av1EntLaunch &L, int f) {
@@ -81,6 +86,7 @@ struct TokLds {
 // counts of its slots in registers across the switch.
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) void k_av1_tokens(Av1EntLaunch L) {
   const int tiles = L.sbr_n * L.sbc_n, t = blockIdx.x, f = t / tiles, tt = t - f * tiles, sbr = tt / L.sbc_n, sbc = tt - sbr * L.sbc_n;
+  if (sbr < L.sb_rows32) return;           // a tile of the 32x32 band: k_av1_tokens32
   const FrameView v = frame_view(L, f);
   const int zi = threadIdx.x, nslots = v.key ? S_KEY_END : S_INTER_END;
   __shared__ TokLds S;
@@ -172,6 +178,44 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) void
   }
 }
 
+// The tiles of a key frame's 32x32 band: ONE LANE PER TILE tokenizes serially (av1_ops32.hpp tok_tile32: 4 blocks of 1024 + 2 x 256
+// coefficients), counts per slot, places the slots and replays its records into the list and the grouped entries — after which the
+// chains, the range coder and the gather treat the tile like any other.  Per lane in LDS: 16-bit counts / positions of the 180 slots
+// and the magnitude map of the transform block at hand.  Key frames are one frame of a GOP; see DESIGN 7-1 for the parallel form.
+__global__ __launch_bounds__(64) void k_av1_tokens32(Av1EntLaunch L, int ntiles_all) {
+  __shared__ ScanTables32 scan;
+  __shared__ uint16_t s_cnt[64 * (K_END + 1)];
+  __shared__ __attribute__((aligned(16))) uint8_t s_mag[64 * kMag32Bytes];
+  if (threadIdx.x == 0) fill_scan_tables32(&scan);
+  __syncthreads();
+  const int tiles = L.sbr_n * L.sbc_n, lane = threadIdx.x, t = blockIdx.x * 64 + lane;
+  if (t >= ntiles_all) return;
+  const int f = t / tiles, tt = t - f * tiles, sbr = tt / L.sbc_n, sbc = tt - sbr * L.sbc_n;
+  if (sbr >= L.sb_rows32) return;
+  const FrameView v = frame_view(L, f);
+  uint16_t *cnt = s_cnt + lane * (K_END + 1);
+  for (int i = 0; i < K_END; i++) cnt[i] = 0;
+  uint16_t *rec = L.rec + (size_t)t * kBlocksPerTile * kBlockRecords;
+  Sink32 k = { rec, cnt, kBlocksPerTile * kBlockRecords, 0, 0, false };
+  const TokScratch32 ts = { s_mag + lane * kMag32Bytes, &scan };
+  tok_tile32(v, k, ts, sbr, sbc);
+  uint16_t *total = L.slot_total + (size_t)t * S_MAX, *base = L.slot_base + (size_t)t * S_MAX;
+  int run = 0;
+  for (int sl = 0; sl < K_END; sl++) {
+    const int n = cnt[sl];
+    total[sl] = (uint16_t)n; base[sl] = (uint16_t)run; cnt[sl] = (uint16_t)run;
+    run += (n + kListAlign - 1) & ~(kListAlign - 1);
+  }
+  for (int sl = K_END; sl < S_MAX; sl++) { total[sl] = 0; base[sl] = 0; }
+  if (k.overflow || (uint32_t)k.n > L.ops_cap || run > 65535) {
+    atomicOr(L.status, 1u);
+    L.nops[t] = 0;
+    for (int sl = 0; sl < K_END; sl++) total[sl] = 0;
+    return;
+  }
+  L.nops[t] = (uint32_t)replay_tile32(rec, k.nrec, cnt, L.ops + (size_t)t * L.ops_cap, L.grouped + (size_t)t * L.grouped_cap);
+}
+
 // CHAINS: workgroup = one CDF slot of 64 consecutive tiles, one lane per tile.  The slot is the same for the whole wave (no
 // divergence between alphabet sizes) and its chains are about equally long in neighbouring tiles, so the lanes stay busy — a
 // tile's own slots differ in length by three orders of magnitude.  Small alphabets keep the CDF in registers, large ones in LDS.
@@ -180,13 +224,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) void
 __global__ __launch_bounds__(64) void k_av1_chains(Av1EntLaunch L, int ntiles_all, int ngroups) {
   // workgroups are dealt to the eight XCDs in turn (id % 8), each with its own L2: all slots of a tile group go to ONE XCD, one
   // after the other, so the 64 lists the group's chains complete word by word stay in that L2 as long as possible
-  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, nslots = L.fv.key ? S_KEY_END : S_INTER_END;
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, nslots = L.nslots;
   const int g = (j / nslots) * 8 + xcd, sl = j - (j / nslots) * nslots, lane = threadIdx.x, t = g * 64 + lane;
   if (g >= ngroups) return;
   __shared__ __attribute__((aligned(16))) uint16_t s_big[64 * 16];
   const int n = L.tab.nsym[sl], off = L.tab.off[sl];
   int cnt = 0, base = 0;
-  if (t < ntiles_all) { cnt = L.slot_total[(size_t)t * S_MAX + sl]; base = L.slot_base[(size_t)t * S_MAX + sl]; }
+  bool mine = t < ntiles_all;
+  if (mine && L.band) { const int tiles = L.sbr_n * L.sbc_n, sbr = (t % tiles) / L.sbc_n; mine = (sbr < L.sb_rows32) == (L.band == 1); }
+  if (mine) { cnt = L.slot_total[(size_t)t * S_MAX + sl]; base = L.slot_base[(size_t)t * S_MAX + sl]; }
   if (!__any(cnt > 0)) return;
   const size_t tt = t < ntiles_all ? (size_t)t : 0;
   op_t *list = L.ops + tt * L.ops_cap;
@@ -352,10 +398,17 @@ hipError_t launch_av1_front(av1mi_ctx *ctx, const Av1EntLaunch &L, hipStream_t s
   const int ntiles_all = L.sbr_n * L.sbc_n * L.nframes, ngroups = (ntiles_all + 63) / 64;
   ProfToken t = ctx_prof_begin(ctx, AV1MI_K_ENTROPY_TOKENS, s);
   hipLaunchKernelGGL(k_av1_info, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, L);
-  hipLaunchKernelGGL(k_av1_tokens, dim3((unsigned)ntiles_all), dim3(64), 0, s, L);
+  if (L.sb_rows32 < L.sbr_n) hipLaunchKernelGGL(k_av1_tokens, dim3((unsigned)ntiles_all), dim3(64), 0, s, L);
+  if (L.sb_rows32) hipLaunchKernelGGL(k_av1_tokens32, dim3((unsigned)ngroups), dim3(64), 0, s, L, ntiles_all);
   ctx_prof_end(ctx, t, s);
   t = ctx_prof_begin(ctx, AV1MI_K_ENTROPY_CHAINS, s);
-  hipLaunchKernelGGL(k_av1_chains, dim3((unsigned)(((ngroups + 7) / 8) * 8 * (L.fv.key ? S_KEY_END : S_INTER_END))), dim3(64), 0, s, L, ntiles_all, ngroups);
+  Av1EntLaunch C = L;
+  C.nslots = L.fv.key ? S_KEY_END : S_INTER_END; C.band = L.sb_rows32 ? 2 : 0;
+  if (L.sb_rows32 < L.sbr_n) hipLaunchKernelGGL(k_av1_chains, dim3((unsigned)(((ngroups + 7) / 8) * 8 * C.nslots)), dim3(64), 0, s, C, ntiles_all, ngroups);
+  if (L.sb_rows32) {       // the 32x32 band's tiles: their slot table and default CDFs
+    C.nslots = K_END; C.band = 1; C.tab = L.tab32; C.cdf_image = L.cdf_image32;
+    hipLaunchKernelGGL(k_av1_chains, dim3((unsigned)(((ngroups + 7) / 8) * 8 * C.nslots)), dim3(64), 0, s, C, ntiles_all, ngroups);
+  }
   ctx_prof_end(ctx, t, s);
   return hipGetLastError();
 }
@@ -386,6 +439,8 @@ struct av1mi_av1ent_state {      // per-context scratch of the coder, grown on d
   bool pending_valid[2] = { false, false };
   size_t last_tiles = 0;          // tiles of the most recent job (av1mi_av1_entropy_last_list_words)
   uint16_t *d_image[2][4] = {};   // [key][qcat] default CDF images
+  uint16_t *d_image32[4] = {};    // [qcat] the 32x32 band's
+  av1ops::SlotTable tab32;
   int image_words[2] = { 0, 0 };
   av1ops::SlotTable tab[2];
 };
@@ -435,8 +490,18 @@ int av1mi::av1_entropy_front(av1mi_ctx *ctx, const av1mi_av1_entropy_job *j, hip
         hipMemcpy(st->d_image[key][qcat], img.data(), img.size() * 2, hipMemcpyHostToDevice) != hipSuccess)
       return av1mi::ctx_fail(ctx, AV1MI_E_DEVICE, "uploading the default CDF image failed");
   }
+  if (j->key_rows32 && (!key || (j->key_rows32 & 63) || j->key_rows32 > j->height || (j->width & 63)))
+    return av1mi::ctx_fail(ctx, AV1MI_E_INVAL, "key_rows32 %d: whole superblock rows of a key frame whose width is a multiple of 64", j->key_rows32);
+  if (j->key_rows32 && !st->d_image32[qcat]) {
+    const std::vector<uint16_t> img = av1ops::default_slot_image_k32(qcat, &st->tab32);
+    if (hipMalloc((void **)&st->d_image32[qcat], img.size() * 2) != hipSuccess ||
+        hipMemcpy(st->d_image32[qcat], img.data(), img.size() * 2, hipMemcpyHostToDevice) != hipSuccess)
+      return av1mi::ctx_fail(ctx, AV1MI_E_DEVICE, "uploading the default CDF image failed");
+  }
   av1mi::Av1EntLaunch L;
   memset(&L, 0, sizeof(L));
+  L.sb_rows32 = j->key_rows32 / 64;
+  if (j->key_rows32) { av1ops::build_slot_table_k32(&L.tab32); L.cdf_image32 = st->d_image32[qcat]; }
   L.fv.w8 = j->width / 8; L.fv.h8 = j->height / 8; L.fv.key = key;
   L.fv.y_mode = j->d_modes_y; L.fv.uv_mode = j->d_modes_uv; L.fv.mv = j->d_mvs; L.fv.skip = j->d_skip;
   L.fv.lev_y = j->d_lev_y; L.fv.lev_u = j->d_lev_u; L.fv.lev_v = j->d_lev_v;

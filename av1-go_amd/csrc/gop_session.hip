@@ -186,8 +186,9 @@ int setup(av1mi_gop *g) {
   const size_t uy = (size_t)units(h) * units(w), uc = (size_t)units(h / 2) * units(w / 2);
   if (c.key_block_size == 32) {
     g->key32 = 1; g->key_rows32 = (h / 64) * 64;
-    g->key_modes_band = ((g->key_rows32 / 32) * (w / 32) + 7) & ~7;
-    g->key_modes_stride = (g->key_modes_band + ((h - g->key_rows32) / 8) * (w / 8) + 7) & ~7;
+    // mode bytes of a frame: the 32x32 blocks from entry 0, the 8x8 blocks of the last rows where the 8x8 grid has them anyway
+    g->key_modes_band = (g->key_rows32 / 8) * (w / 8);
+    g->key_modes_stride = (h / 8) * (w / 8);
   }
   for (int t = 0; t < 2 + g->key32; t++) {
     if (t < 2) frame_params(c.base_q_idx, c.bit_depth, t, &g->params[t]);
@@ -249,8 +250,8 @@ int av1mi_gop_open(av1mi_ctx *ctx, const av1mi_gop_config *cfg, av1mi_gop **out)
       cfg->search_range > 15 || cfg->gpu_entropy < 0 || cfg->gpu_entropy > 2 || cfg->coder_streams < 0 || cfg->coder_streams > 3)
     return av1mi::ctx_fail(ctx, AV1MI_E_INVAL, "bad base_q_idx / gop_length / segments / search_range / gpu_entropy");
   if (cfg->key_block_size != 0 && cfg->key_block_size != 8 && cfg->key_block_size != 32) return av1mi::ctx_fail(ctx, AV1MI_E_INVAL, "key_block_size %d not supported (8 or 32)", cfg->key_block_size);
-  if (cfg->key_block_size == 32 && ((cfg->width & 63) || cfg->gpu_entropy))
-    return av1mi::ctx_fail(ctx, AV1MI_E_INVAL, "key_block_size 32 needs a width that is a multiple of 64 and gpu_entropy 0 (the GPU tile coder codes 8x8 / 4x4 transforms)");
+  if (cfg->key_block_size == 32 && (cfg->width & 63))
+    return av1mi::ctx_fail(ctx, AV1MI_E_INVAL, "key_block_size 32 needs a width that is a multiple of 64");
   if (cfg->gpu_entropy && (cfg->width > 4096 || cfg->height > 4096)) return av1mi::ctx_fail(ctx, AV1MI_E_INVAL, "the AV1 tile coder takes frames up to 4096x4096");
   if ((size_t)cfg->height * cfg->segments > 65535u * 8u) return av1mi::ctx_fail(ctx, AV1MI_E_INVAL, "segments x height too large for one launch");
   av1mi_gop *g = new (std::nothrow) av1mi_gop();
@@ -475,6 +476,7 @@ static int submit_batch(av1mi_gop *g, int frame_type, const void *const *dev_src
     ej.lr_on[0] = P.lr_unit_y[0] == 1; ej.lr_on[1] = ej.lr_on[2] = P.lr_unit_uv[0] == 1;
     ej.d_lr_on = (const uint8_t *)s.d_lr_on;
     ej.visible_width = g->vw; ej.visible_height = g->vh;
+    ej.key_rows32 = frame_type == 0 && g->key32 ? g->key_rows32 : 0;
     memcpy(ej.lr_unit_y, P.lr_unit_y, 8); memcpy(ej.lr_unit_uv, P.lr_unit_uv, 8);
     ej.d_out = (uint8_t *)s.h_ent_out; ej.out_cap = g->ent_cap; ej.d_tile_size = (uint32_t *)s.d_tile_size; ej.d_total = (uint64_t *)s.d_total;
     if (g->coder_streams == 3) {

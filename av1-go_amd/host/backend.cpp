@@ -116,7 +116,6 @@ bool SessionTemporalUnit(const av1mi_gop_frame &fr, int seg, int width, int heig
                          bool with_sequence_header, int threads, std::vector<uint8_t> *out, std::string *err) {
   SessionFrameDesc desc;
   DescribeSessionFrame(fr, seg, width, height, bit_depth, &desc, visible_width, visible_height);
-  if (fr.key_block_size == 32) return Key32TemporalUnit(fr, seg, desc, width, height, with_sequence_header, out, err);
   std::string werr;
   if (fr.tile_size) {      // tiles coded on the GPU: frame header + tile group around them
     const uint32_t *sz = fr.tile_size + (size_t)seg * fr.tiles_per_frame;
@@ -129,6 +128,7 @@ bool SessionTemporalUnit(const av1mi_gop_frame &fr, int seg, int width, int heig
     out->insert(out->end(), frame.begin(), frame.end());
     return true;
   }
+  if (fr.key_block_size == 32) return Key32TemporalUnit(fr, seg, desc, width, height, with_sequence_header, out, err);      // symbols of a key frame in 32x32 blocks
   if (!av1::temporal_unit(desc.f, with_sequence_header, threads, out, &werr)) { if (err) *err = "bitstream writer: " + werr; return false; }
   return true;
 }

@@ -312,6 +312,9 @@ typedef struct av1mi_av1_entropy_job {
   const uint8_t *d_lr_on;                      /* optional: [frame * 3 + plane] 0 switches lr_on[plane] off for that frame */
   int visible_width, visible_height;           /* the true frame size when width / height are it rounded up to 8 (the restoration units
                                                   a tile codes tile the TRUE frame); 0 = width / height */
+  int key_rows32;                              /* key = 1: the first key_rows32 luma rows (whole superblock rows; width % 64 == 0) are coded in
+                                                  32x32 blocks: their modes one per 32x32 block from entry 0 of d_modes_*, their levels
+                                                  block-contiguous over the 32x32 grid; the rows below in 8x8 blocks at their usual places */
 } av1mi_av1_entropy_job;
 int av1mi_av1_entropy_encode(av1mi_ctx *ctx, const av1mi_av1_entropy_job *job);
 /* the same on another HIP stream of the caller's (hipStream_t passed as void *; NULL = the context's stream) */
@@ -362,8 +365,7 @@ typedef struct av1mi_gop_config {
   int coder_streams;
   int key_block_size;    /* 0 / 8: key frames in 8x8 blocks like every frame.  32: key frames in 32x32 blocks (luma 32x32 DCT, chroma 16x16,
                             transform type by mode) over every COMPLETE superblock row, 8x8 blocks in a last partial row: +3.7 dB at equal
-                            size on the synthetic key frames at q 128, +1.85 dB at q 24.  Needs width % 64 == 0 and, until the
-                            GPU tile coder knows the larger transforms, gpu_entropy == 0 (av1mi_gop_open refuses otherwise) */
+                            size on the synthetic key frames at q 128, +1.85 dB at q 24.  Needs width % 64 == 0 */
 } av1mi_gop_config;
 
 /* Frame-header parameters chosen by the session's policy for one frame (non-normative encoder choices; the bitstream carries
@@ -402,7 +404,8 @@ typedef struct av1mi_gop_frame {    /* one collected frame batch; host pointers 
   const uint8_t *lr_on;
   int key_block_size;               /* of this frame: 8, or 32 (key frames of a key_block_size 32 session).  32: y_mode / uv_mode hold, per
                                        segment (stride key_modes_stride bytes), the modes of the 32x32 blocks of the complete superblock rows in
-                                       raster order, then from byte offset key_modes_band the 8x8 blocks of the last partial row; the levels
+                                       raster order from entry 0, and from byte offset key_modes_band (their place in the 8x8 grid) the 8x8
+                                       blocks of the last partial row; the levels
                                        are block-contiguous per region in the same planes (a region's blocks tile its rows of the plane) */
   int key_modes_stride, key_modes_band;
 } av1mi_gop_frame;

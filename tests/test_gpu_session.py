@@ -182,6 +182,8 @@ def test_key_frames_in_32x32_blocks(ctx, av1mi, O, w, h, bd, q, segs):
                     assert fr["lr_on"][sgi].tolist() == on
                     for g_, e_, hh in ((got[0], ref[sgi][0], h), (got[1], ref[sgi][1], h // 2), (got[2], ref[sgi][2], h // 2)):
                         assert (g_[sgi * hh:(sgi + 1) * hh] == e_).all(), "frame %d segment %d: reference differs from the oracle chain" % (t, sgi)
+            if kbs == 32:
+                key32_streams = list(streams)
             for sgi in range(segs):
                 dec = D.decode(streams[sgi])
                 assert len(dec) == gop
@@ -191,8 +193,25 @@ def test_key_frames_in_32x32_blocks(ctx, av1mi, O, w, h, bd, q, segs):
         finally:
             s.close()
     assert sum(sizes[32]) < sum(sizes[8]) and min(a - b for a, b in zip(psnr[32], psnr[8])) > -0.3, (sizes, psnr)
-    with pytest.raises(av1mi.Av1miError):
-        av1mi.GopSession(ctx, w, h, bd, q, gop, segs, key_block_size=32, gpu_entropy=1)        # the GPU tile coder codes 8x8 / 4x4 transforms
+    # (4) the GPU tile coder (k_av1_tokens32 for the 32x32 band's tiles, then the usual chains / range coder): the same bytes
+    s = av1mi.GopSession(ctx, w, h, bd, q, gop, segs, key_block_size=32, gpu_entropy=1)
+    try:
+        coded = [b""] * segs
+        for t in range(gop):
+            planes = s.input_planes()
+            for sgi in range(segs):
+                f = sgi * gop + t
+                planes[0][sgi * h:(sgi + 1) * h] = Y[f]
+                planes[1][sgi * h // 2:(sgi + 1) * h // 2] = U[f]
+                planes[2][sgi * h // 2:(sgi + 1) * h // 2] = V[f]
+            s.submit()
+            fr = s.collect()
+            assert "tile_size" in fr and s.entropy_fallbacks() == 0
+            for sgi in range(segs):
+                coded[sgi] += av1stream.session_temporal_unit(w, h, bd, fr["raw"], sgi, with_sequence_header=(t == 0), threads=4)
+        assert coded == key32_streams
+    finally:
+        s.close()
     with pytest.raises(av1mi.Av1miError):
         av1mi.GopSession(ctx, 136, 72, bd, q, gop, segs, key_block_size=32)                    # width must be a multiple of 64
 
