@@ -178,42 +178,57 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) void
   }
 }
 
-// The tiles of a key frame's 32x32 band: ONE LANE PER TILE tokenizes serially (av1_ops32.hpp tok_tile32: 4 blocks of 1024 + 2 x 256
-// coefficients), counts per slot, places the slots and replays its records into the list and the grouped entries — after which the
-// chains, the range coder and the gather treat the tile like any other.  Per lane in LDS: 16-bit counts / positions of the 180 slots
-// and the magnitude map of the transform block at hand.  Key frames are one frame of a GOP; see DESIGN 7-1 for the parallel form.
+// The tiles of a key frame's 32x32 band: ONE LANE PER 32x32 BLOCK (16 tiles per workgroup) tokenizes serially (av1_ops32.hpp
+// tok_block32: 1024 + 2 x 256 coefficients), the four lanes of a tile then place the slots and replay their records into the list
+// and the grouped entries — after which the chains, the range coder and the gather treat the tile like any other.  In LDS: per tile
+// the 16-bit counts / positions of its 180 slots x 4 blocks and the blocks' level summaries, per lane the magnitude map of the
+// transform block at hand.  Key frames are one frame of a GOP; see DESIGN 7-1 for a finer-grained form.
+constexpr int kTiles32 = 16;      // per workgroup
 __global__ __launch_bounds__(64) void k_av1_tokens32(Av1EntLaunch L, int ntiles_all) {
   __shared__ ScanTables32 scan;
-  __shared__ uint16_t s_cnt[64 * (K_END + 1)];
+  __shared__ uint16_t s_cnt[kTiles32 * (K_END * kBlocks32 + 2)];      // + 2: the tiles' rows start on different banks
   __shared__ __attribute__((aligned(16))) uint8_t s_mag[64 * kMag32Bytes];
-  if (threadIdx.x == 0) fill_scan_tables32(&scan);
+  __shared__ Sum32 s_sum[kTiles32][kBlocks32];
+  __shared__ int s_n[kTiles32][kBlocks32], s_nrec[kTiles32][kBlocks32], s_bad[kTiles32];
+  const int tiles = L.sbr_n * L.sbc_n, tl = threadIdx.x >> 2, b = threadIdx.x & 3, t = blockIdx.x * kTiles32 + tl;
+  bool live = t < ntiles_all;
+  int f = 0, sbr = 0, sbc = 0;
+  if (live) { f = t / tiles; const int tt = t - f * tiles; sbr = tt / L.sbc_n; sbc = tt - sbr * L.sbc_n; live = sbr < L.sb_rows32; }
+  fill_scan_tables32(&scan, (int)threadIdx.x, 64);
+  uint16_t *cnt = s_cnt + tl * (K_END * kBlocks32 + 2);
+  for (int i = b; i < K_END * kBlocks32; i += kBlocks32) cnt[i] = 0;
+  if (b == 0) s_bad[tl] = 0;
+  const FrameView v = frame_view(L, live ? f : 0);
+  if (live) block_sums32(v, block_index32(v, sbr, sbc, b), &s_sum[tl][b]);
   __syncthreads();
-  const int tiles = L.sbr_n * L.sbc_n, lane = threadIdx.x, t = blockIdx.x * 64 + lane;
-  if (t >= ntiles_all) return;
-  const int f = t / tiles, tt = t - f * tiles, sbr = tt / L.sbc_n, sbc = tt - sbr * L.sbc_n;
-  if (sbr >= L.sb_rows32) return;
-  const FrameView v = frame_view(L, f);
-  uint16_t *cnt = s_cnt + lane * (K_END + 1);
-  for (int i = 0; i < K_END; i++) cnt[i] = 0;
-  uint16_t *rec = L.rec + (size_t)t * kBlocksPerTile * kBlockRecords;
-  Sink32 k = { rec, cnt, kBlocksPerTile * kBlockRecords, 0, 0, false };
-  const TokScratch32 ts = { s_mag + lane * kMag32Bytes, &scan };
-  tok_tile32(v, k, ts, sbr, sbc);
-  uint16_t *total = L.slot_total + (size_t)t * S_MAX, *base = L.slot_base + (size_t)t * S_MAX;
-  int run = 0;
-  for (int sl = 0; sl < K_END; sl++) {
-    const int n = cnt[sl];
-    total[sl] = (uint16_t)n; base[sl] = (uint16_t)run; cnt[sl] = (uint16_t)run;
-    run += (n + kListAlign - 1) & ~(kListAlign - 1);
+  uint16_t *rec = L.rec + ((size_t)(live ? t : 0) * kBlocks32 + b) * kBlockRecords32;
+  if (live) {
+    Sink32 k = { rec, cnt, b, (int)kBlockRecords32, 0, 0, false, 0, 0, 0, 0 };
+    const TokScratch32 ts = { s_mag + threadIdx.x * kMag32Bytes, &scan };
+    tok_block32(v, k, ts, sbr, sbc, b, s_sum[tl]);
+    s_n[tl][b] = k.n; s_nrec[tl][b] = k.nrec;
+    if (k.overflow) atomicOr(&s_bad[tl], 1);
   }
-  for (int sl = K_END; sl < S_MAX; sl++) { total[sl] = 0; base[sl] = 0; }
-  if (k.overflow || (uint32_t)k.n > L.ops_cap || run > 65535) {
-    atomicOr(L.status, 1u);
-    L.nops[t] = 0;
-    for (int sl = 0; sl < K_END; sl++) total[sl] = 0;
-    return;
+  __syncthreads();
+  if (live && b == 0) {       // place: the tile's first lane (180 slots x 4 blocks: nothing beside the tokenizing)
+    uint16_t *total = L.slot_total + (size_t)t * S_MAX, *base = L.slot_base + (size_t)t * S_MAX;
+    const int run = place_tile32(cnt, total, base);
+    for (int sl = K_END; sl < S_MAX; sl++) { total[sl] = 0; base[sl] = 0; }
+    const int n = s_n[tl][0] + s_n[tl][1] + s_n[tl][2] + s_n[tl][3];
+    if (s_bad[tl] || (uint32_t)n > L.ops_cap || run > 65535) {
+      s_bad[tl] = 1;
+      atomicOr(L.status, 1u);
+      L.nops[t] = 0;
+      for (int sl = 0; sl < K_END; sl++) total[sl] = 0;
+    } else {
+      L.nops[t] = (uint32_t)n;
+    }
   }
-  L.nops[t] = (uint32_t)replay_tile32(rec, k.nrec, cnt, L.ops + (size_t)t * L.ops_cap, L.grouped + (size_t)t * L.grouped_cap);
+  __syncthreads();
+  if (!live || s_bad[tl]) return;
+  int first = 0;
+  for (int q = 0; q < b; q++) first += s_n[tl][q];
+  replay_block32(rec, s_nrec[tl][b], cnt, b, first, L.ops + (size_t)t * L.ops_cap, L.grouped + (size_t)t * L.grouped_cap);
 }
 
 // CHAINS: workgroup = one CDF slot of 64 consecutive tiles, one lane per tile.  The slot is the same for the whole wave (no
@@ -399,7 +414,7 @@ hipError_t launch_av1_front(av1mi_ctx *ctx, const Av1EntLaunch &L, hipStream_t s
   ProfToken t = ctx_prof_begin(ctx, AV1MI_K_ENTROPY_TOKENS, s);
   hipLaunchKernelGGL(k_av1_info, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, L);
   if (L.sb_rows32 < L.sbr_n) hipLaunchKernelGGL(k_av1_tokens, dim3((unsigned)ntiles_all), dim3(64), 0, s, L);
-  if (L.sb_rows32) hipLaunchKernelGGL(k_av1_tokens32, dim3((unsigned)ngroups), dim3(64), 0, s, L, ntiles_all);
+  if (L.sb_rows32) hipLaunchKernelGGL(k_av1_tokens32, dim3((unsigned)((ntiles_all + kTiles32 - 1) / kTiles32)), dim3(64), 0, s, L, ntiles_all);
   ctx_prof_end(ctx, t, s);
   t = ctx_prof_begin(ctx, AV1MI_K_ENTROPY_CHAINS, s);
   Av1EntLaunch C = L;

@@ -2,8 +2,9 @@
 // stream av1_ops.hpp makes of 8x8 blocks: records -> list words + grouped entries, after which the chains, the range coder and the
 // gather of av1_entropy_kernels.hip (and their CPU twins) run unchanged.  A tile is one complete 64x64 superblock: PARTITION_SPLIT, four
 // 32x32 blocks (PARTITION_NONE), luma transform 32x32 (DCT_DCT, not coded: the 32x32 set holds nothing else), chroma 16x16 with the
-// transform type implied by the mode, TX_MODE_LARGEST.  ONE THREAD PER TILE tokenizes serially (key frames are one frame in a GOP; the
-// unit of parallel work that would suit them better is a scan range of a transform block).
+// transform type implied by the mode, TX_MODE_LARGEST.  ONE THREAD PER 32x32 BLOCK tokenizes its 1024 + 2 x 256 coefficients serially
+// (key frames are one frame in a GOP; the unit of parallel work that would suit them better is a scan range of a transform block,
+// DESIGN 7-1); what a block needs of its neighbours — their level summaries — is computed beforehand from the levels alone.
 // Shared source: hipcc for the device, g++ for the CPU twin (host/av1_opstream.cpp), verified there byte for byte against the general
 // block writer (host/av1_blockstream.cpp, itself verified by dav1d).
 #pragma once
@@ -66,29 +67,47 @@ AV1_HD void build_slot_table_k32(SlotTable *t) {
 
 // Default_Scan_16x16 / Default_Scan_32x32 (zig-zag: odd diagonals downwards) and their inverses
 struct ScanTables32 { uint16_t s32[1024], i32[1024]; uint8_t s16[256], i16[256]; };
-AV1_HD void fill_scan_tables32(ScanTables32 *t) {
-  for (int N = 16; N <= 32; N += 16) {
-    int k = 0;
-    for (int d = 0; d < 2 * N - 1; d++)
-      for (int i = 0; i <= d; i++) {
-        const int r = (d & 1) ? i : d - i, c = d - r;
-        if (r >= N || c >= N) continue;
-        if (N == 16) { t->s16[k] = (uint8_t)(r * N + c); t->i16[r * N + c] = (uint8_t)k; }
-        else { t->s32[k] = (uint16_t)(r * N + c); t->i32[r * N + c] = (uint16_t)k; }
-        k++;
-      }
-  }
+// thread `tid` of `nthreads` fills its share: the scan index of a position has a closed form (the diagonals before its own, then its
+// place on the diagonal), so no thread walks the scan
+AV1_HD void fill_scan_tables32(ScanTables32 *t, int tid = 0, int nthreads = 1) {
+  for (int N = 16; N <= 32; N += 16)
+    for (int pos = tid; pos < N * N; pos += nthreads) {
+      const int r = pos / N, c = pos % N, d = r + c;
+      const int before = d < N ? d * (d + 1) / 2 : N * N - (2 * N - 1 - d) * (2 * N - d) / 2;
+      const int rmin = imax(0, d - N + 1), rmax = imin(d, N - 1);
+      const int k = before + ((d & 1) ? r - rmin : rmax - r);
+      if (N == 16) { t->s16[k] = (uint8_t)pos; t->i16[pos] = (uint8_t)k; }
+      else { t->s32[k] = (uint16_t)pos; t->i32[pos] = (uint16_t)k; }
+    }
 }
 enum { kMag32Stride = 36, kMag32Bytes = 36 * 34 };      // (32 + 2) rows of 32 + 2 (+ 2: a whole number of dwords)
 struct TokScratch32 { uint8_t *mag; const ScanTables32 *scan; };
 
-// the sink of a serial tokenizer: records in one run, 16-bit symbol counts per slot
+// the sink of a block's tokenizer: records in one run, 16-bit symbol counts per (slot, block of the tile)
+enum { kBlocks32 = 4, kBlockRecords32 = kBlocksPerTile * kBlockRecords / kBlocks32 };      // the tile's record area, a quarter per block
 struct Sink32 {
-  uint16_t *rec; uint16_t *cnt;      // cnt[K_END]
-  int cap, nrec, n;
+  uint16_t *rec; uint16_t *cnt;      // cnt[K_END][kBlocks32]; this block's column is `blk`
+  int blk, cap, nrec, n;
   bool overflow;
-  AV1_HD void put(unsigned r) { if (nrec < cap) rec[nrec] = (uint16_t)r; else overflow = true; nrec++; n++; }
-  AV1_HD void sym(int slot, int s) { put(((unsigned)slot << 4) | (unsigned)s); if (cnt[slot] == 65535) overflow = true; else cnt[slot]++; }
+  uint32_t w0, w1, w2, w3;           // the records on their way out, eight per 16-byte store (rec is 16-byte aligned; call flush() at the end)
+  AV1_HD void put(unsigned r) {
+    const int j = nrec & 7;
+    const uint32_t v = (r & 0xFFFFu) << (16 * (j & 1));
+    if (j < 2) w0 = j ? w0 | v : v; else if (j < 4) w1 = j & 1 ? w1 | v : v; else if (j < 6) w2 = j & 1 ? w2 | v : v; else w3 = j & 1 ? w3 | v : v;
+    nrec++; n++;
+    if (j == 7) store8();
+  }
+  AV1_HD void store8() {              // the eight records before nrec (rounded up)
+    const int at = (nrec - 1) & ~7;
+    if (at + 8 <= cap) { struct alignas(16) R8 { uint32_t w[4]; } q = { { w0, w1, w2, w3 } }; *reinterpret_cast<R8 *>(rec + at) = q; }
+    else overflow = true;
+  }
+  AV1_HD void flush() { if (nrec & 7) store8(); }
+  AV1_HD void sym(int slot, int s) {
+    put(((unsigned)slot << 4) | (unsigned)s);
+    uint16_t &c = cnt[slot * kBlocks32 + blk];
+    if (c == 65535) overflow = true; else c++;
+  }
   AV1_HD void lit(unsigned v, int nbits) {
     while (nbits > 11) { nbits -= 11; put(0x8000u | (11u << 11) | ((v >> nbits) & 0x7FFu)); }
     if (nbits > 0) put(0x8000u | ((unsigned)nbits << 11) | (v & ((1u << nbits) - 1u)));
@@ -98,20 +117,19 @@ struct Sink32 {
 // coeffs() (5.11.39) of one N x N transform block (N = 32 luma / 16 chroma), 2-D class; cul / dc: this block's level summary for its
 // neighbours (min(63, sum |level|); 0 none / 1 negative / 2 positive)
 template <int N> AV1_HD void tok_coeffs_big(Sink32 &k, const TokScratch32 &ts, bool chroma, const int16_t *lev, int above_cul, int above_dc, int left_cul,
-                                            int left_dc, int *cul_out, int *dc_out) {
+                                            int left_dc) {
   const int nc = N * N, LG = N == 16 ? 4 : 5, MS = kMag32Stride;
   uint8_t *mag = ts.mag;
   for (int i = 0; i < (N + 2) * MS / 4; i++) reinterpret_cast<u32a *>(mag)[i] = 0;
-  int eob = 0, cul = 0;
+  int eob = 0;
   for (int r = 0; r < nc / 8; r++) {
     struct alignas(16) L8 { int16_t v[8]; } q = *reinterpret_cast<const L8 *>(lev + 8 * r);
     for (int j = 0; j < 8; j++) {
       const int pos = 8 * r + j, v = q.v[j], a = iabs(v);
-      if (v) { eob = imax(eob, (N == 16 ? (int)ts.scan->i16[pos] : (int)ts.scan->i32[pos]) + 1); cul += a; }
+      if (v) eob = imax(eob, (N == 16 ? (int)ts.scan->i16[pos] : (int)ts.scan->i32[pos]) + 1);
       mag[(pos >> LG) * MS + (pos & (N - 1))] = (uint8_t)((a > 15 ? 15 : a) | (v < 0 ? 128 : 0));
     }
   }
-  *cul_out = imin(cul, 63); *dc_out = lev[0] < 0 ? 1 : lev[0] > 0 ? 2 : 0;
   k.sym(chroma ? K_TXB_SKIP_C + ((above_cul | above_dc) != 0) + ((left_cul | left_dc) != 0) : K_TXB_SKIP_Y, eob == 0);
   if (!eob) return;
   const int eob_pt = eob < 3 ? eob : ilog2((unsigned)(eob - 1)) + 2;
@@ -192,41 +210,75 @@ AV1_HD void tok_lr32(const FrameView &f, Sink32 &k, int sbr, int sbc) {
   }
 }
 
-// all ops of the tile = superblock (sbr, sbc) of a key frame's 32x32 band.  f.y_mode / f.uv_mode: the band's modes, one per 32x32 block
-// in raster order (w8 / 4 per row); f.lev_*: block-contiguous over the same grid (1024 luma, 256 + 256 chroma levels per block)
-AV1_HD void tok_tile32(const FrameView &f, Sink32 &k, const TokScratch32 &ts, int sbr, int sbc) {
+// what the neighbours of a transform block read of it: min(63, sum |level|) and the DC's sign class (0 none / 1 negative / 2 positive)
+struct Sum32 { uint8_t cul[3], dc[3]; };
+AV1_HD void block_sums32(const FrameView &f, long i, Sum32 *o) {
+  for (int p = 0; p < 3; p++) {
+    const int n = p ? 256 : 1024;
+    const int16_t *lev = (p == 0 ? f.lev_y : p == 1 ? f.lev_u : f.lev_v) + i * n;
+    int cul = 0;
+    for (int r = 0; r < n / 8; r++) {
+      struct alignas(16) L8 { int16_t v[8]; } q = *reinterpret_cast<const L8 *>(lev + 8 * r);
+      for (int j = 0; j < 8; j++) cul += iabs(q.v[j]);
+    }
+    o->cul[p] = (uint8_t)imin(cul, 63);
+    o->dc[p] = (uint8_t)(lev[0] < 0 ? 1 : lev[0] > 0 ? 2 : 0);
+  }
+}
+AV1_HD long block_index32(const FrameView &f, int sbr, int sbc, int b) { return (long)(sbr * 2 + (b >> 1)) * (f.w8 / 4) + sbc * 2 + (b & 1); }
+
+// all ops of block b (0..3, raster = decoding order) of the tile = superblock (sbr, sbc) of a key frame's 32x32 band; sums[4]: the
+// tile's block summaries.  f.y_mode / f.uv_mode: the band's modes, one per 32x32 block in raster order (w8 / 4 per row); f.lev_*:
+// block-contiguous over the same grid (1024 luma, 256 + 256 chroma levels per block)
+AV1_HD void tok_block32(const FrameView &f, Sink32 &k, const TokScratch32 &ts, int sbr, int sbc, int b, const Sum32 *sums) {
   static const uint8_t kCtx[13] = { 0, 1, 2, 3, 4, 4, 4, 4, 3, 0, 1, 2, 0 };     // Intra_Mode_Context
-  const int w32 = f.w8 / 4;
-  tok_lr32(f, k, sbr, sbc);
-  k.sym(K_PART64, 3);                            // PARTITION_SPLIT
-  int cul[4][3], dc[4][3];
-  for (int b = 0; b < 4; b++) {
-    const int by = b >> 1, bx = b & 1;
-    const long i = (long)(sbr * 2 + by) * w32 + sbc * 2 + bx;
-    k.sym(K_PART32, 0);                          // PARTITION_NONE
-    k.sym(K_SKIP, 0);
-    const int ym = f.y_mode[i], uvm = f.uv_mode[i];
-    k.sym(K_KF_Y_MODE + kCtx[by ? f.y_mode[i - w32] : 0] * 5 + kCtx[bx ? f.y_mode[i - 1] : 0], ym);
-    if (ym >= 1 && ym <= 8) k.sym(K_ANGLE + ym - 1, 3);
-    k.sym(K_UV_MODE + ym, uvm);
-    if (uvm >= 1 && uvm <= 8) k.sym(K_ANGLE + uvm - 1, 3);
-    for (int p = 0; p < 3; p++) {
-      const int ac = by ? cul[b - 2][p] : 0, ad = by ? dc[b - 2][p] : 0, lc = bx ? cul[b - 1][p] : 0, ld = bx ? dc[b - 1][p] : 0;
-      if (p == 0) tok_coeffs_big<32>(k, ts, false, f.lev_y + i * 1024, ac, ad, lc, ld, &cul[b][p], &dc[b][p]);
-      else tok_coeffs_big<16>(k, ts, true, (p == 1 ? f.lev_u : f.lev_v) + i * 256, ac, ad, lc, ld, &cul[b][p], &dc[b][p]);
+  const int w32 = f.w8 / 4, by = b >> 1, bx = b & 1;
+  const long i = block_index32(f, sbr, sbc, b);
+  if (b == 0) {
+    tok_lr32(f, k, sbr, sbc);
+    k.sym(K_PART64, 3);                          // PARTITION_SPLIT
+  }
+  k.sym(K_PART32, 0);                            // PARTITION_NONE
+  k.sym(K_SKIP, 0);
+  const int ym = f.y_mode[i], uvm = f.uv_mode[i];
+  k.sym(K_KF_Y_MODE + kCtx[by ? f.y_mode[i - w32] : 0] * 5 + kCtx[bx ? f.y_mode[i - 1] : 0], ym);
+  if (ym >= 1 && ym <= 8) k.sym(K_ANGLE + ym - 1, 3);
+  k.sym(K_UV_MODE + ym, uvm);
+  if (uvm >= 1 && uvm <= 8) k.sym(K_ANGLE + uvm - 1, 3);
+  for (int p = 0; p < 3; p++) {
+    const int ac = by ? sums[b - 2].cul[p] : 0, ad = by ? sums[b - 2].dc[p] : 0, lc = bx ? sums[b - 1].cul[p] : 0, ld = bx ? sums[b - 1].dc[p] : 0;
+    if (p == 0) tok_coeffs_big<32>(k, ts, false, f.lev_y + i * 1024, ac, ad, lc, ld);
+    else tok_coeffs_big<16>(k, ts, true, (p == 1 ? f.lev_u : f.lev_v) + i * 256, ac, ad, lc, ld);
+  }
+  k.flush();
+}
+
+// a block's records -> list words (from index `first`) and grouped entries; pos[K_END][kBlocks32]: the running positions of the
+// tile's (slot, block) pairs
+AV1_HD void replay_block32(const uint16_t *rec, int nrec, uint16_t *pos, int blk, int first, op_t *list, uint32_t *grouped) {
+  int n = first;
+  for (int i0 = 0; i0 < nrec; i0 += 8) {        // eight records per load (a dependent 2-byte load per record is a memory round trip each)
+    struct alignas(16) R8 { uint32_t w[4]; } q = *reinterpret_cast<const R8 *>(rec + i0);
+    AV1_UNROLL
+    for (int j = 0; j < 8; j++, n++) {
+      if (i0 + j >= nrec) break;
+      const unsigned r = (q.w[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
+      if (r & 0x8000u) list[n] = op_lit((int)((r >> 11) & 15), r & 0x7FFu);
+      else { uint16_t &p = pos[(int)(r >> 4) * kBlocks32 + blk]; grouped[p] = ((uint32_t)n << 4) | (r & 15u); p++; }
     }
   }
 }
-
-// the records of a serially tokenized tile -> list words and grouped entries; pos[K_END]: the slots' running positions
-AV1_HD int replay_tile32(const uint16_t *rec, int nrec, uint16_t *pos, op_t *list, uint32_t *grouped) {
-  int n = 0;
-  for (int i = 0; i < nrec; i++, n++) {
-    const unsigned r = rec[i];
-    if (r & 0x8000u) list[n] = op_lit((int)((r >> 11) & 15), r & 0x7FFu);
-    else { const int sl = (int)(r >> 4); grouped[pos[sl]] = ((uint32_t)n << 4) | (r & 15u); pos[sl]++; }
+// counts[K_END][kBlocks32] -> the positions of every (slot, block)'s first entry (in place), the slots' totals and bases; returns the
+// entries incl. the slots' padding to kListAlign
+AV1_HD int place_tile32(uint16_t *cnt, uint16_t *total, uint16_t *base) {
+  int run = 0;
+  for (int sl = 0; sl < K_END; sl++) {
+    int p = run, n = 0;
+    for (int b = 0; b < kBlocks32; b++) { const int c = cnt[sl * kBlocks32 + b]; cnt[sl * kBlocks32 + b] = (uint16_t)imin(p, 65535); p += c; n += c; }
+    total[sl] = (uint16_t)imin(n, 65535); base[sl] = (uint16_t)imin(run, 65535);
+    run += (n + kListAlign - 1) & ~(kListAlign - 1);
   }
-  return n;
+  return run;
 }
 
 }  // namespace av1ops

@@ -80,7 +80,7 @@ bool opstream_tiles(const av1mi_obu_frame &f, std::vector<std::vector<uint8_t>> 
   // the 32x32 band's own slot table, default CDFs, scan tables and scratch
   SlotTable tab32;
   const std::vector<uint16_t> image32 = key_rows32 ? default_slot_image_k32(qcat, &tab32) : std::vector<uint16_t>();
-  std::vector<uint16_t> rec32(key_rows32 ? (size_t)kBlocksPerTile * kBlockRecords : 0), cnt32(K_END), pos32(K_END);
+  std::vector<uint16_t> rec32(key_rows32 ? (size_t)kBlocksPerTile * kBlockRecords : 0), cnt32((size_t)K_END * kBlocks32);
   std::vector<ScanTables32> scan32(key_rows32 ? 1 : 0);
   if (key_rows32) fill_scan_tables32(scan32.data());
   alignas(16) uint8_t mag32[kMag32Bytes];
@@ -89,19 +89,24 @@ bool opstream_tiles(const av1mi_obu_frame &f, std::vector<std::vector<uint8_t>> 
       if (sbr * 64 < key_rows32) {
         // a tile of the 32x32 band: tokenized serially (the GPU: one lane per tile), then the same chains and the same range coder
         std::fill(cnt32.begin(), cnt32.end(), 0);
-        Sink32 k = { rec32.data(), cnt32.data(), (int)rec32.size(), 0, 0, false };
         const TokScratch32 ts32 = { mag32, scan32.data() };
-        tok_tile32(v, k, ts32, sbr, sbc);
-        if (k.overflow) { if (err) *err = "a tile exceeds the tokenizer's record area"; return false; }
-        int base[K_END], total[K_END], run = 0;
-        for (int sl = 0; sl < K_END; sl++) {
-          base[sl] = run; total[sl] = cnt32[(size_t)sl]; pos32[(size_t)sl] = (uint16_t)run;
-          run = (run + total[sl] + kListAlign - 1) & ~(kListAlign - 1);
+        Sum32 sums[kBlocks32];
+        for (int b = 0; b < kBlocks32; b++) block_sums32(v, block_index32(v, sbr, sbc, b), &sums[b]);
+        int nrec[kBlocks32], first[kBlocks32 + 1];
+        first[0] = 0;
+        for (int b = 0; b < kBlocks32; b++) {        // (the GPU: one lane per block)
+          Sink32 k = { &rec32[(size_t)b * kBlockRecords32], cnt32.data(), b, (int)kBlockRecords32, 0, 0, false, 0, 0, 0, 0 };
+          tok_block32(v, k, ts32, sbr, sbc, b, sums);
+          if (k.overflow) { if (err) *err = "a block exceeds the tokenizer's record area"; return false; }
+          nrec[b] = k.nrec; first[b + 1] = first[b] + k.n;
         }
+        uint16_t base[K_END], total[K_END];
+        const int run = place_tile32(cnt32.data(), total, base);
         if (run > 65535) { if (err) *err = "tile too large for 16-bit entry positions"; return false; }
-        list.assign((size_t)k.n, 0);
+        const int nops = first[kBlocks32];
+        list.assign((size_t)nops, 0);
         grouped.assign((size_t)run, 0);
-        const int nops = replay_tile32(rec32.data(), k.nrec, pos32.data(), list.data(), grouped.data());
+        for (int b = 0; b < kBlocks32; b++) replay_block32(&rec32[(size_t)b * kBlockRecords32], nrec[b], cnt32.data(), b, first[b], list.data(), grouped.data());
         for (int sl = 0; sl < K_END; sl++)
           if (total[sl]) run_chain(&image32[tab32.off[sl]], tab32.nsym[sl], &grouped[(size_t)base[sl]], total[sl], list.data());
         std::vector<uint8_t> &out = (*tiles)[(size_t)sbr * sbc_n + sbc];

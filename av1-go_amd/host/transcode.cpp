@@ -65,9 +65,10 @@ bool ParseBackendJob(const std::vector<std::string> &args, BackendJob *job, std:
     else if (args[i] == "-threads") job->threads = std::atoi(args[i + 1].c_str());
     else if (args[i] == "-av1mi_gpu_entropy") job->gpu_entropy = std::atoi(args[i + 1].c_str()) != 0;
     else if (args[i] == "-av1mi_tracks") job->tracks.push_back(args[i + 1]);
+    else if (args[i] == "-av1mi_key_block_size") job->key_block_size = std::atoi(args[i + 1].c_str());
   }
   if (!have_in) { if (err) *err = "Invalid argument: no input (-i) given"; return false; }
-  if (job->quality < 0 || job->quality > 255 || job->gop < 1 || job->gop > 256 || job->segments < 1 || job->segments > 256 || job->threads < 0) { if (err) *err = "Invalid argument: quality/gop out of range"; return false; }
+  if (job->quality < 0 || job->quality > 255 || job->gop < 1 || job->gop > 256 || job->segments < 1 || job->segments > 256 || job->threads < 0 || (job->key_block_size != 8 && job->key_block_size != 32)) { if (err) *err = "Invalid argument: quality/gop/key block size out of range"; return false; }
   return true;
 }
 

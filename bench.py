@@ -45,15 +45,16 @@ def parse():
     ap.add_argument("--e2e-host-segments", type=int, default=4, help="segments of the end-to-end leg with entropy coding on the host cores")
     ap.add_argument("--e2e-steps", type=int, default=2)
     ap.add_argument("--e2e-segments", type=int, default=8, help="segments in lockstep of the end-to-end leg (GPU entropy coding)")
-    ap.add_argument("--key-block-size", type=int, default=0, choices=[0, 8, 32],
-                    help="32: ALSO run the host-coder end-to-end leg with key frames in 32x32 blocks (e2e_key32; vs_libaom of that key frame)")
+    ap.add_argument("--key-block-size", type=int, default=32, choices=[8, 32],
+                    help="32 (default, what the product's command line uses): key frames in 32x32 blocks (av1mi_gop_config.key_block_size) where "
+                         "the width is a multiple of 64; 8: every frame in 8x8 blocks")
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="no GPU: exercise the rank/sharding/timing/aggregation plumbing with a stand-in step (gloo tests)")
     return ap.parse_args()
 
 
 # ------------------------------------------------------------------------------------------------------------------ baselines
-def cpu_baseline_gop(src, W, H, bd, qindex, gop, search_range=8, p_frames=2):
+def cpu_baseline_gop(src, W, H, bd, qindex, gop, search_range=8, p_frames=2, key_block_size=0):
     """The oracle chain (own CPU restatement, kind "port": the reference's CPU path does not exist in its tree) on this box's host
     cores, one GOP per worker thread, each coding the key frame and the first `p_frames` P frames of its GOP through the same stages
     as the GPU step (encoder loop + deblocking + CDEF + loop restoration + its decision; the P frames reference the worker's own
@@ -68,8 +69,26 @@ def cpu_baseline_gop(src, W, H, bd, qindex, gop, search_range=8, p_frames=2):
     segs = src[0].shape[0]
     pol = [pipeline.policy_arrays(qindex, bd, ft, W, H) for ft in (0, 1)]
 
+    hA = H // 64 * 64 if key_block_size == 32 else 0
+    mi32 = None
+    if hA:       # key frames in 32x32 blocks over the complete superblock rows: 32x32 / 16x16 transform edges there
+        mi32 = (pol[0]["mi_y"].copy(), pol[0]["mi_c"].copy())
+        mi32[0][:hA // 4] = (mi32[0][:hA // 4] & ~np.uint32(0xFF)) | np.uint32(5 | (5 << 4))
+        mi32[1][:hA // 8] = (mi32[1][:hA // 8] & ~np.uint32(0xFF)) | np.uint32(4 | (4 << 4))
+
+    def key_frame(s):
+        if not hA:
+            return O.intra_encode_frame(s[0], s[1], s[2], bd, 8, qindex)
+        a = O.intra_encode_frame(s[0][:hA], s[1][:hA // 2], s[2][:hA // 2], bd, 32, qindex)
+        if hA == H:
+            return a
+        b = O.intra_encode_frame(s[0][hA:], s[1][hA // 2:], s[2][hA // 2:], bd, 8, qindex)
+        return {k: np.concatenate([a[k], b[k]]) for k in ("rec_y", "rec_u", "rec_v")}
+
     def filters(r, skip8, ft, s):
         a = pol[ft]
+        if ft == 0 and mi32 is not None:
+            a = dict(a, mi_y=mi32[0], mi_c=mi32[1])
         dbl = [O.deblock_plane(r["rec_y"], bd, 0, a["mi_y"]), O.deblock_plane(r["rec_u"], bd, 1, a["mi_c"]), O.deblock_plane(r["rec_v"], bd, 1, a["mi_c"])]
         cdef = O.cdef_frame(dbl[0], dbl[1], dbl[2], bd, a["cdef_damping"], a["cdef_sb"], skip8)
         lr = [O.lr_plane(cdef[0], dbl[0], bd, 0, a["lr_unit"], a["lr_units_y"]), O.lr_plane(cdef[1], dbl[1], bd, 1, a["lr_unit"], a["lr_units_c"]),
@@ -80,7 +99,7 @@ def cpu_baseline_gop(src, W, H, bd, qindex, gop, search_range=8, p_frames=2):
         sg = worker % segs
         t0 = time.perf_counter()
         s = [src[p][sg, 0] for p in range(3)]
-        ref = filters(O.intra_encode_frame(s[0], s[1], s[2], bd, 8, qindex), np.zeros((H // 8, W // 8), np.uint8), 0, s)
+        ref = filters(key_frame(s), np.zeros((H // 8, W // 8), np.uint8), 0, s)
         t1 = time.perf_counter()
         n = min(p_frames, gop - 1)
         for t in range(1, 1 + n):
@@ -274,7 +293,7 @@ def e2e_leg(ctx, src, W, H, bd, qindex, gop, steps=2, warmup_frames=2, gpu_entro
         out.update(decoder_check(ctx, src, W, H, bd, qindex, gop, gpu_entropy, threads, compare_libaom, key_block_size))
     if key_block_size == 32:
         out["key_block_size"] = 32
-        out["what"] += "; KEY FRAMES IN 32x32 BLOCKS (av1mi_gop_config.key_block_size), written by the general block writer on one thread per frame"
+        out["what"] += "; key frames in 32x32 blocks (av1mi_gop_config.key_block_size)" + ("" if gpu_entropy else ", written by the general block writer on one thread per frame")
     return out
 
 
@@ -496,7 +515,8 @@ def main():
     src = [a.reshape(segs, batches, *a.shape[1:]) for a in (Y, U, V)]
     d_src = [[ctx.to_device(np.ascontiguousarray(src[p][:, t])) for p in range(3)] for t in range(batches)]
     t_gen = time.perf_counter() - t_gen
-    sess = av1mi.GopSession(ctx, W, H, bd, args.qindex, gop, segs, gpu_entropy=1)
+    kbs = 32 if (args.key_block_size == 32 and W % 64 == 0) else 0
+    sess = av1mi.GopSession(ctx, W, H, bd, args.qindex, gop, segs, gpu_entropy=1, key_block_size=kbs)
     stat = {"payload": 0, "frames": 0}
 
     def collect():
@@ -564,7 +584,7 @@ def main():
                                "`e2e_gpu_entropy_frames_per_s` adds the upload (pinned host source); `e2e_frames_per_s` is north_star's split with entropy "
                                "coding on the host cores; `block_pipeline_frames_per_s` is the round-1/2 definition of `value` (kernels of the main "
                                "stream only, no entropy coding), derived from this run's kernel times",
-                   "frames_per_step": frames, "segments": segs, "qindex": args.qindex, "entropy_fallbacks": fallbacks,
+                   "frames_per_step": frames, "segments": segs, "qindex": args.qindex, "key_block_size": kbs or 8, "entropy_fallbacks": fallbacks,
                    "coded_bytes_per_frame": stat["payload"] / max(stat["frames"], 1),
                    "sharding": "closed-GOP segment per GPU, no collective", "device": ctx.device_name,
                    "source_generation_s": t_gen},
@@ -611,7 +631,7 @@ def main():
                                    "wall time).  `kernels_isolated` / `roofline_isolated` are the same kernels with the coder serialised on the main "
                                    "stream (av1mi_gop_config.coder_streams = 2): every kernel alone on the GPU")
         # the same batches once more with every kernel ALONE on the GPU: the numbers to judge a kernel by
-        iso = av1mi.GopSession(ctx, W, H, bd, args.qindex, gop, segs, gpu_entropy=1, coder_streams=2)
+        iso = av1mi.GopSession(ctx, W, H, bd, args.qindex, gop, segs, gpu_entropy=1, coder_streams=2, key_block_size=kbs)
         for rep in range(2):
             if rep == 1:
                 ctx.prof_reset()
@@ -653,7 +673,7 @@ def main():
                           "note": "last frames of the step; fixed qindex, no rate control; the comparison with libaom on the same key frame is under e2e.vs_libaom"}
         out["baseline_tools"] = probe_baseline_tools()
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline_gop(src, W, H, bd, args.qindex, gop)
+            out["cpu_baseline"] = cpu_baseline_gop(src, W, H, bd, args.qindex, gop, key_block_size=kbs)
         else:
             out["cpu_baseline"] = None
     sess.close()
@@ -666,7 +686,7 @@ def main():
         es = min(args.e2e_segments, segs)
         esrc = [src[p][:es] for p in range(3)]
         g = e2e_leg(ctx, esrc, W, H, bd, args.qindex, gop, steps=args.e2e_steps if gop_wl else 8, warmup_frames=2 if gop_wl else 1, gpu_entropy=1,
-                    threads=threads, check=rank == 0, barrier=barrier)
+                    threads=threads, check=rank == 0, barrier=barrier, key_block_size=kbs)
         e_dt = aggregate(dist, g["seconds"], sync_t.device if dist is not None else None)
         e_frames = aggregate(dist, float(g["frames"]), sync_t.device if dist is not None else None, "sum")
         if rank == 0:
@@ -677,13 +697,11 @@ def main():
             out["e2e_gpu_entropy_frames_per_s"] = g["frames_per_s"]
             if world == 1 and gop_wl:
                 hs = min(args.e2e_host_segments, segs)
-                e = e2e_leg(ctx, [src[p][:hs] for p in range(3)], W, H, bd, args.qindex, gop, steps=1, gpu_entropy=0, threads=threads, compare_libaom=True)
+                e = e2e_leg(ctx, [src[p][:hs] for p in range(3)], W, H, bd, args.qindex, gop, steps=1, gpu_entropy=0, threads=threads, compare_libaom=True,
+                            key_block_size=kbs)
                 out["e2e"] = e                      # north_star's split: entropy coding on the host cores
                 out["e2e_frames_per_s"] = e["frames_per_s"]
-                if args.key_block_size == 32 and W % 64 == 0:
-                    # the same leg with key frames in 32x32 blocks (host entropy coding is the only coder that knows them so far)
-                    out["e2e_key32"] = e2e_leg(ctx, [src[p][:hs] for p in range(3)], W, H, bd, args.qindex, gop, steps=1, gpu_entropy=0, threads=threads,
-                                               compare_libaom=True, key_block_size=32)
+
     if rank == 0:
         print(json.dumps(out))
     ctx.close()

@@ -113,7 +113,7 @@ def test_job_edge_cases_and_error_behaviour(ctx, av1mi):
     ctx.intra_encode(job(nframes=0))                                   # empty segment: accepted, nothing written
     ctx.sync()
     assert (rec[0].download((64,), np.uint8) == 0xAB).all() and (modes[0].download((64,), np.uint8) == 0xAB).all()
-    for bad, what in ((job(bd=12), "bit depth"), (job(width=60), "multiple"), (job(q=256), "qindex"), (job(bs=32), "block"), (job(nframes=-1), "nframes")):
+    for bad, what in ((job(bd=12), "bit depth"), (job(width=60), "multiple"), (job(q=256), "qindex"), (job(bs=64), "block"), (job(nframes=-1), "nframes")):
         rc = ctx.lib.av1mi_intra_encode(ctx.h, __import__("ctypes").byref(bad))
         msg = ctx.lib.av1mi_last_error(ctx.h).decode()
         assert rc < 0 and msg, (what, rc, msg)

@@ -224,14 +224,24 @@ def test_run_transcode_and_process_job_on_gpu(host, tmp_path, O):
         for i in range(n):
             key = i % gop == 0
             p = av1mi.policy_frame_params(q, 8, 0 if key else 1)
-            if key:
+            from test_gpu_session import _oracle_filters, _oracle_key32
+            mi = None
+            if key and w % 64 == 0:
+                # the command line's default (-av1mi_key_block_size 32): key frames in 32x32 blocks over the complete superblock rows
+                _, _, r = _oracle_key32(O, Y[i], U[i], V[i], 8, q)
+                hA = h // 64 * 64
+                mi = (np.full((h // 4, w // 4), int(O.lf_mi(3, 3, p.lf_level[0], p.lf_level[1])), np.uint32),
+                      np.full((h // 8, w // 8), int(O.lf_mi(2, 2, p.lf_level[2], p.lf_level[2])), np.uint32))
+                mi[0][:hA // 4] = int(O.lf_mi(5, 5, p.lf_level[0], p.lf_level[1]))
+                mi[1][:hA // 8] = int(O.lf_mi(4, 4, p.lf_level[2], p.lf_level[2]))
+                skip8 = np.zeros((h // 8, w // 8), np.uint8)
+            elif key:
                 r = O.intra_encode_frame(Y[i], U[i], V[i], 8, 8, q)
                 skip8 = np.zeros((h // 8, w // 8), np.uint8)
             else:
                 r = O.inter_encode_frame((Y[i], U[i], V[i]), ref, 8, q, 8)
                 skip8 = r["skip"].reshape(h // 8, w // 8)
-            from test_gpu_session import _oracle_filters
-            ref, _ = _oracle_filters(O, r, 8, p, w, h, skip8, (Y[i], U[i], V[i]))
+            ref, _ = _oracle_filters(O, r, 8, p, w, h, skip8, (Y[i], U[i], V[i]), mi=mi)
             for pl in range(3):
                 assert (got[i][pl] == ref[pl]).all(), "frame %d plane %d: the decoded file differs from the oracle chain" % (i, pl)
     # lifecycle: tight ratio -> skipped with markers; generous ratio -> success, and the SOURCE IS KEPT (video-only output)
