@@ -132,7 +132,7 @@ long long av1mi_obu_write_blocks_temporal_unit(const av1mi_obu_blocks *f, int wi
 
 /* The drop-in for RunTranscode (transcode.go:194-315): argv as TranscodeArgs (transcode.go:17) builds it — the backend reads
  * "-i <input.y4m>", "-global_quality:v:0 <q>" and the output path (last argument), plus its own "-g", "-av1mi_device",
- * "-av1mi_segments", "-av1mi_gpu_entropy", "-threads"; everything else is accepted and ignored.  Returns 0 and leaves the output file in place on
+ * "-av1mi_segments", "-av1mi_gpu_entropy", "-av1mi_key_block_size", "-av1mi_tracks", "-threads"; everything else is accepted and ignored.  Returns 0 and leaves the output file in place on
  * success; -1 when the backend could not run at all (no HIP device: transcode.go:311); another non-zero code on failure.
  * err receives the reference-shaped text ("av1mi failed with exit code N: ...", at most 800 characters + "..."). */
 int av1mi_run_transcode(int argc, const char *const *argv, char *err, size_t errcap);
