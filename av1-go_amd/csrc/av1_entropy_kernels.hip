@@ -184,10 +184,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) void
 // the 16-bit counts / positions of its 180 slots x 4 blocks and the blocks' level summaries, per lane the magnitude map of the
 // transform block at hand.  Key frames are one frame of a GOP; see DESIGN 7-1 for a finer-grained form.
 constexpr int kTiles32 = 16;      // per workgroup
+static_assert(kBlocks32 * kMag32Bytes >= K_END * kBlocks32 * 2 && kMag32Bytes % 8 == 0, "a tile's counters live where its four magnitude maps were");
 __global__ __launch_bounds__(64) void k_av1_tokens32(Av1EntLaunch L, int ntiles_all) {
   __shared__ ScanTables32 scan;
-  __shared__ uint16_t s_cnt[kTiles32 * (K_END * kBlocks32 + 2)];      // + 2: the tiles' rows start on different banks
-  __shared__ __attribute__((aligned(16))) uint8_t s_mag[64 * kMag32Bytes];
+  __shared__ __attribute__((aligned(16))) uint8_t s_mag[64 * kMag32Bytes];      // 47 KB: three workgroups per CU
   __shared__ Sum32 s_sum[kTiles32][kBlocks32];
   __shared__ int s_n[kTiles32][kBlocks32], s_nrec[kTiles32][kBlocks32], s_bad[kTiles32];
   const int tiles = L.sbr_n * L.sbc_n, tl = threadIdx.x >> 2, b = threadIdx.x & 3, t = blockIdx.x * kTiles32 + tl;
@@ -195,20 +195,25 @@ __global__ __launch_bounds__(64) void k_av1_tokens32(Av1EntLaunch L, int ntiles_
   int f = 0, sbr = 0, sbc = 0;
   if (live) { f = t / tiles; const int tt = t - f * tiles; sbr = tt / L.sbc_n; sbc = tt - sbr * L.sbc_n; live = sbr < L.sb_rows32; }
   fill_scan_tables32(&scan, (int)threadIdx.x, 64);
-  uint16_t *cnt = s_cnt + tl * (K_END * kBlocks32 + 2);
-  for (int i = b; i < K_END * kBlocks32; i += kBlocks32) cnt[i] = 0;
   if (b == 0) s_bad[tl] = 0;
   const FrameView v = frame_view(L, live ? f : 0);
   if (live) block_sums32(v, block_index32(v, sbr, sbc, b), &s_sum[tl][b]);
   __syncthreads();
   uint16_t *rec = L.rec + ((size_t)(live ? t : 0) * kBlocks32 + b) * kBlockRecords32;
+  int nrec = 0;
   if (live) {
-    Sink32 k = { rec, cnt, b, (int)kBlockRecords32, 0, 0, false, 0, 0, 0, 0 };
+    Sink32 k = { rec, nullptr, b, (int)kBlockRecords32, 0, 0, false, 0, 0, 0, 0 };
     const TokScratch32 ts = { s_mag + threadIdx.x * kMag32Bytes, &scan };
     tok_block32(v, k, ts, sbr, sbc, b, s_sum[tl]);
-    s_n[tl][b] = k.n; s_nrec[tl][b] = k.nrec;
+    s_n[tl][b] = k.n; s_nrec[tl][b] = nrec = k.nrec;
     if (k.overflow) atomicOr(&s_bad[tl], 1);
   }
+  __syncthreads();
+  // the magnitude maps are dead: the tile's 180 x 4 counters take their place
+  uint16_t *cnt = reinterpret_cast<uint16_t *>(s_mag + tl * kBlocks32 * kMag32Bytes);
+  for (int i = b; i < K_END * kBlocks32; i += kBlocks32) cnt[i] = 0;
+  __syncthreads();
+  if (live && !count_block32(rec, nrec, cnt, b)) atomicOr(&s_bad[tl], 1);
   __syncthreads();
   if (live && b == 0) {       // place: the tile's first lane (180 slots x 4 blocks: nothing beside the tokenizing)
     uint16_t *total = L.slot_total + (size_t)t * S_MAX, *base = L.slot_base + (size_t)t * S_MAX;
@@ -228,7 +233,7 @@ __global__ __launch_bounds__(64) void k_av1_tokens32(Av1EntLaunch L, int ntiles_
   if (!live || s_bad[tl]) return;
   int first = 0;
   for (int q = 0; q < b; q++) first += s_n[tl][q];
-  replay_block32(rec, s_nrec[tl][b], cnt, b, first, L.ops + (size_t)t * L.ops_cap, L.grouped + (size_t)t * L.grouped_cap);
+  replay_block32(rec, nrec, cnt, b, first, L.ops + (size_t)t * L.ops_cap, L.grouped + (size_t)t * L.grouped_cap);
 }
 
 // CHAINS: workgroup = one CDF slot of 64 consecutive tiles, one lane per tile.  The slot is the same for the whole wave (no

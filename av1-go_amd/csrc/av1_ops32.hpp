@@ -80,7 +80,10 @@ AV1_HD void fill_scan_tables32(ScanTables32 *t, int tid = 0, int nthreads = 1) {
       else { t->s32[k] = (uint16_t)pos; t->i32[pos] = (uint16_t)k; }
     }
 }
-enum { kMag32Stride = 36, kMag32Bytes = 36 * 34 };      // (32 + 2) rows of 32 + 2 (+ 2: a whole number of dwords)
+// a thread's scratch: min(|level|, 15) of the transform block at hand, FOUR BITS each, rows of 32 + 4 entries (18 bytes), 32 + 2 rows
+// (the context templates reach two rows / columns beyond a level), then one sign bit per level.  (A byte per level was 1.2 KB per
+// lane: with the counters 107 KB per 64 lanes, one wave per CU.)
+enum { kMag32Stride = 36, kMag32Nibbles = 36 * 34 / 2, kMag32Bytes = kMag32Nibbles + 32 * 32 / 8 + 4 };      // 612 + 128 (+ 4: 16-byte multiples)
 struct TokScratch32 { uint8_t *mag; const ScanTables32 *scan; };
 
 // the sink of a block's tokenizer: records in one run, 16-bit symbol counts per (slot, block of the tile)
@@ -103,11 +106,7 @@ struct Sink32 {
     else overflow = true;
   }
   AV1_HD void flush() { if (nrec & 7) store8(); }
-  AV1_HD void sym(int slot, int s) {
-    put(((unsigned)slot << 4) | (unsigned)s);
-    uint16_t &c = cnt[slot * kBlocks32 + blk];
-    if (c == 65535) overflow = true; else c++;
-  }
+  AV1_HD void sym(int slot, int s) { put(((unsigned)slot << 4) | (unsigned)s); }      // counted afterwards: count_block32
   AV1_HD void lit(unsigned v, int nbits) {
     while (nbits > 11) { nbits -= 11; put(0x8000u | (11u << 11) | ((v >> nbits) & 0x7FFu)); }
     if (nbits > 0) put(0x8000u | ((unsigned)nbits << 11) | (v & ((1u << nbits) - 1u)));
@@ -119,16 +118,24 @@ struct Sink32 {
 template <int N> AV1_HD void tok_coeffs_big(Sink32 &k, const TokScratch32 &ts, bool chroma, const int16_t *lev, int above_cul, int above_dc, int left_cul,
                                             int left_dc) {
   const int nc = N * N, LG = N == 16 ? 4 : 5, MS = kMag32Stride;
-  uint8_t *mag = ts.mag;
-  for (int i = 0; i < (N + 2) * MS / 4; i++) reinterpret_cast<u32a *>(mag)[i] = 0;
+  uint8_t *mag = ts.mag, *sgn = ts.mag + kMag32Nibbles;
+  for (int i = 0; i < (N + 2) * MS / 8; i++) reinterpret_cast<u32a *>(mag)[i] = 0;        // (N + 2) rows of 18 bytes: a whole number of dwords for N = 16, 32
+  auto nib = [&](int idx) { return (mag[idx >> 1] >> ((idx & 1) << 2)) & 15; };          // idx = row * MS + col
   int eob = 0;
   for (int r = 0; r < nc / 8; r++) {
     struct alignas(16) L8 { int16_t v[8]; } q = *reinterpret_cast<const L8 *>(lev + 8 * r);
+    unsigned packed = 0, signs = 0;
     for (int j = 0; j < 8; j++) {
       const int pos = 8 * r + j, v = q.v[j], a = iabs(v);
       if (v) eob = imax(eob, (N == 16 ? (int)ts.scan->i16[pos] : (int)ts.scan->i32[pos]) + 1);
-      mag[(pos >> LG) * MS + (pos & (N - 1))] = (uint8_t)((a > 15 ? 15 : a) | (v < 0 ? 128 : 0));
+      packed |= (unsigned)(a > 15 ? 15 : a) << (4 * j);
+      signs |= (unsigned)(v < 0) << j;
     }
+    // eight levels of one row, from an even column on: two 16-bit stores (a row of 18 bytes starts on an even address only)
+    const int at = (((8 * r) >> LG) * MS + ((8 * r) & (N - 1))) >> 1;
+    *reinterpret_cast<uint16_t *>(mag + at) = (uint16_t)packed;
+    *reinterpret_cast<uint16_t *>(mag + at + 2) = (uint16_t)(packed >> 16);
+    sgn[r] = (uint8_t)signs;
   }
   k.sym(chroma ? K_TXB_SKIP_C + ((above_cul | above_dc) != 0) + ((left_cul | left_dc) != 0) : K_TXB_SKIP_Y, eob == 0);
   if (!eob) return;
@@ -142,8 +149,8 @@ template <int N> AV1_HD void tok_coeffs_big(Sink32 &k, const TokScratch32 &ts, b
   const int base_eob = chroma ? K_BASE_EOB_C : K_BASE_EOB_Y, base = chroma ? K_BASE_C : K_BASE_Y, br = chroma ? K_BR_C : K_BR_Y;
   for (int c = eob - 1; c >= 0; c--) {
     const int pos = N == 16 ? (int)ts.scan->s16[c] : (int)ts.scan->s32[c], row = pos >> LG, col = pos & (N - 1);
-    const uint8_t *m = mag + row * MS + col;
-    const int m0 = m[0] & 15, m1 = m[1] & 15, m2 = m[2] & 15, mb = m[MS] & 15, md = m[MS + 1] & 15, mbb = m[2 * MS] & 15;
+    const int at = row * MS + col;
+    const int m0 = nib(at), m1 = nib(at + 1), m2 = nib(at + 2), mb = nib(at + MS), md = nib(at + MS + 1), mbb = nib(at + 2 * MS);
     int a = m0;
     if (a == 15) a = iabs(lev[pos]);
     if (c == eob - 1) {
@@ -169,16 +176,16 @@ template <int N> AV1_HD void tok_coeffs_big(Sink32 &k, const TokScratch32 &ts, b
     }
   }
   for (int c = 0; c < eob; c++) {
-    const int pos = N == 16 ? (int)ts.scan->s16[c] : (int)ts.scan->s32[c], m = mag[(pos >> LG) * MS + (pos & (N - 1))];
+    const int pos = N == 16 ? (int)ts.scan->s16[c] : (int)ts.scan->s32[c], m = nib((pos >> LG) * MS + (pos & (N - 1)));
     if (!m) continue;
-    const int neg = m >> 7;
+    const int neg = (sgn[pos >> 3] >> (pos & 7)) & 1;
     if (c == 0) {
       const int sg = (above_dc == 2) - (above_dc == 1) + (left_dc == 2) - (left_dc == 1);
       k.sym((chroma ? K_DC_SIGN_C : K_DC_SIGN_Y) + (sg < 0 ? 1 : sg > 0 ? 2 : 0), neg);
     } else {
       k.lit((unsigned)neg, 1);
     }
-    if ((m & 15) == 15) {
+    if (m == 15) {
       const int a = iabs(lev[pos]);
       if (a > 14) {
         const unsigned x = (unsigned)(a - 14);
@@ -267,6 +274,21 @@ AV1_HD void replay_block32(const uint16_t *rec, int nrec, uint16_t *pos, int blk
       else { uint16_t &p = pos[(int)(r >> 4) * kBlocks32 + blk]; grouped[p] = ((uint32_t)n << 4) | (r & 15u); p++; }
     }
   }
+}
+// a block's records -> its column of the tile's symbol counts (a pass of its own: the counters then share their LDS with the
+// magnitude maps, which are dead by then)
+AV1_HD bool count_block32(const uint16_t *rec, int nrec, uint16_t *cnt, int blk) {
+  bool ok = true;
+  for (int i0 = 0; i0 < nrec; i0 += 8) {
+    struct alignas(16) R8 { uint32_t w[4]; } q = *reinterpret_cast<const R8 *>(rec + i0);
+    AV1_UNROLL
+    for (int j = 0; j < 8; j++) {
+      if (i0 + j >= nrec) break;
+      const unsigned r = (q.w[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
+      if (!(r & 0x8000u)) { uint16_t &c = cnt[(int)(r >> 4) * kBlocks32 + blk]; if (c == 65535) ok = false; else c++; }
+    }
+  }
+  return ok;
 }
 // counts[K_END][kBlocks32] -> the positions of every (slot, block)'s first entry (in place), the slots' totals and bases; returns the
 // entries incl. the slots' padding to kListAlign

@@ -100,6 +100,8 @@ bool opstream_tiles(const av1mi_obu_frame &f, std::vector<std::vector<uint8_t>> 
           if (k.overflow) { if (err) *err = "a block exceeds the tokenizer's record area"; return false; }
           nrec[b] = k.nrec; first[b + 1] = first[b] + k.n;
         }
+        for (int b = 0; b < kBlocks32; b++)
+          if (!count_block32(&rec32[(size_t)b * kBlockRecords32], nrec[b], cnt32.data(), b)) { if (err) *err = "too many symbols of one slot in a block"; return false; }
         uint16_t base[K_END], total[K_END];
         const int run = place_tile32(cnt32.data(), total, base);
         if (run > 65535) { if (err) *err = "tile too large for 16-bit entry positions"; return false; }
