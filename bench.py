@@ -360,8 +360,11 @@ def pmc_numbers(kind, workload, frames_per_launch):
         prof = json.load(open(path))
     except (OSError, ValueError):
         return None, None, None
-    for name, d in prof["kernels"].items():
-        if name.startswith(PMC_KERNEL.get(kind, "?")):
+    key = PMC_KERNEL.get(kind, "?")
+    # the kernel of that name (not k_av1_tokens32 for k_av1_tokens); of a template's instantiations the one that moves the most bytes
+    hits = sorted(((n, d) for n, d in prof["kernels"].items() if n == key or n.startswith(key + "<")), key=lambda nd: -(nd[1]["fetch_bytes_uncorrected"] + nd[1]["write_bytes"]))
+    for name, d in hits[:1]:
+        if True:
             corr = (prof.get("calibration") or {}).get("read_correction_8B_per_lane") or 2.0
             traffic = (d["fetch_bytes_uncorrected"] * corr + d["write_bytes"]) * frames_per_launch / prof["frames_per_step"]
             sq = d.get("sq_counters_per_launch") or {}

@@ -216,6 +216,44 @@ def test_key_frames_in_32x32_blocks(ctx, av1mi, O, w, h, bd, q, segs):
         av1mi.GopSession(ctx, 136, 72, bd, q, gop, segs, key_block_size=32)                    # width must be a multiple of 64
 
 
+@pytest.mark.skipif(not D.available(), reason="no dav1d in this image")
+@pytest.mark.parametrize("vw,vh,bd,q", [(190, 131, 8, 100), (252, 70, 10, 40)])
+def test_key_frames_in_32x32_blocks_of_a_cropped_frame(ctx, av1mi, vw, vh, bd, q):
+    """key_block_size 32 with a true size that is not a multiple of 8 (coded size rounded up, width a multiple of 64): the 32x32 band
+    reaches over the cropped edge like the 8x8 blocks do; the GPU-coded and the host-coded streams are the same bytes and dav1d
+    outputs vw x vh frames that equal the session's references cropped"""
+    import av1stream
+    import synth
+    import test_av1_conformance as T
+    gop, w, h = 3, (vw + 7) // 8 * 8, (vh + 7) // 8 * 8
+    cvw, cvh = (vw + 1) // 2, (vh + 1) // 2
+    Yc, Uc, Vc = synth.frames(w + 8, h + 8, gop, bd, 6)
+    out = {}
+    for mode in (1, 0):
+        s = av1mi.GopSession(ctx, w, h, bd, q, gop, 1, gpu_entropy=mode, visible=(vw, vh), key_block_size=32)
+        try:
+            stream, refs = b"", []
+            for t in range(gop):
+                planes = s.input_planes()
+                planes[0][:] = T._pad(Yc[t][:vh, :vw], h, w)
+                planes[1][:] = T._pad(Uc[t][:cvh, :cvw], h // 2, w // 2)
+                planes[2][:] = T._pad(Vc[t][:cvh, :cvw], h // 2, w // 2)
+                s.submit()
+                fr = s.collect()
+                refs.append(s.download_reference())
+                stream += av1stream.session_temporal_unit(w, h, bd, fr["raw"], 0, with_sequence_header=(t == 0), threads=4, visible=(vw, vh))
+            assert s.entropy_fallbacks() == 0
+            out[mode] = (stream, refs)
+        finally:
+            s.close()
+    assert out[1][0] == out[0][0]
+    got = D.decode(out[1][0])
+    assert len(got) == gop
+    for t in range(gop):
+        for i, (ch, cw) in enumerate(((vh, vw), (cvh, cvw), (cvh, cvw))):
+            assert got[t][i].shape == (ch, cw) and (got[t][i] == out[1][1][t][i][:ch, :cw]).all(), "frame %d plane %d: dav1d differs from the GPU" % (t, i)
+
+
 def test_session_api_misuse_is_reported(ctx, av1mi):
     s = av1mi.GopSession(ctx, 64, 64, 8, 100, 2, 1)
     try:
