@@ -56,7 +56,8 @@ std::vector<uint8_t> range_code_raw(const uint32_t *fl, const uint32_t *fh, cons
 bool opstream_supported(const av1mi_obu_frame &f, std::string *why);
 bool opstream_tiles(const av1mi_obu_frame &f, std::vector<std::vector<uint8_t>> *tiles, std::string *err, int key_rows32 = 0);
 // the general block-structured writer (av1_blockstream.cpp, include/av1mi_host.h av1mi_obu_blocks): one temporal unit
-bool blocks_temporal_unit(const av1mi_obu_blocks &d, bool with_sequence_header, std::vector<uint8_t> *out, std::string *err);
+bool blocks_temporal_unit(const av1mi_obu_blocks &d, bool with_sequence_header, std::vector<uint8_t> *out, std::string *err, int threads = 1,
+                          const size_t (*tile_start)[2] = nullptr);
 // one temporal unit: delimiter [+ sequence header] + frame
 bool temporal_unit(const av1mi_obu_frame &f, bool with_sequence_header, int threads, std::vector<uint8_t> *out, std::string *err);
 

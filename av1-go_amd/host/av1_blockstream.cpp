@@ -6,6 +6,7 @@
 // oracle (tests/test_av1_blocks.py) reaches every size north_star names ("DCT/ADST 4x4-64x64", every intra / MC block size).
 // Written from the AV1 Bitstream & Decoding Process Specification; section numbers in the comments are the specification's.
 #include <map>
+#include <thread>
 
 #include "av1_bitstream_core.hpp"
 
@@ -62,7 +63,7 @@ int tx_set_of(int tx, bool is_inter, bool reduced) {
 
 // get_scan (5.11.41): positions pos = row * tw + col of the (at most 32 x 32) coded area; kind 0 default, 1 row-major (mrow), 2 column-major (mcol)
 const std::vector<uint16_t> &scan_of(int tw, int th, int kind) {
-  static std::map<int, std::vector<uint16_t>> cache;      // (single-threaded writer)
+  static thread_local std::map<int, std::vector<uint16_t>> cache;      // (per thread: tiles are written by several)
   const int key = (tw << 16) | (th << 4) | kind;
   auto it = cache.find(key);
   if (it != cache.end()) return it->second;
@@ -639,7 +640,11 @@ struct BlockWriter {
 
 }  // namespace
 
-bool blocks_temporal_unit(const av1mi_obu_blocks &d, bool with_sequence_header, std::vector<uint8_t> *out, std::string *err) {
+// tile_start (optional): for every tile (+ one entry past the last) the index of its first block and of its first partition symbol —
+// a caller that built the lists tile by tile knows them, and the tiles can then be written by `threads` threads (each with its own
+// writer state; a tile reads nothing of another tile)
+bool blocks_temporal_unit(const av1mi_obu_blocks &d, bool with_sequence_header, std::vector<uint8_t> *out, std::string *err, int threads,
+                          const size_t (*tile_start)[2]) {
   using namespace core;
   if (!check(d.hdr, err, false)) return false;
   auto bad = [&](const char *m) { if (err) *err = m; return false; };
@@ -648,9 +653,30 @@ bool blocks_temporal_unit(const av1mi_obu_blocks &d, bool with_sequence_header, 
   BlockWriter bw(d, err);
   const int ntiles = bw.fi.tile_cols * bw.fi.tile_rows;
   std::vector<std::vector<uint8_t>> tiles((size_t)ntiles);
-  for (int t = 0; t < ntiles && !bw.failed; t++) {
-    bw.tile(t / bw.fi.tile_cols, t % bw.fi.tile_cols);
-    tiles[(size_t)t].swap(bw.ec.out);
+  if (tile_start && threads > 1 && ntiles > 1) {
+    const int nt = std::min(threads, ntiles);
+    std::vector<std::string> errs((size_t)nt);
+    std::vector<char> ok((size_t)nt, 1);
+    std::vector<std::thread> pool;
+    for (int i = 0; i < nt; i++)
+      pool.emplace_back([&, i]() {
+        BlockWriter w(d, &errs[(size_t)i]);
+        for (int t = i; t < ntiles && !w.failed; t += nt) {
+          w.next_block = tile_start[t][0]; w.next_part = tile_start[t][1];
+          w.tile(t / w.fi.tile_cols, t % w.fi.tile_cols);
+          if (!w.failed && (w.next_block != tile_start[t + 1][0] || w.next_part != tile_start[t + 1][1])) w.fail("a tile's block / partition lists do not end where the next tile's begin");
+          tiles[(size_t)t].swap(w.ec.out);
+        }
+        ok[(size_t)i] = !w.failed;
+      });
+    for (auto &th : pool) th.join();
+    for (int i = 0; i < nt; i++) if (!ok[(size_t)i]) { if (err) *err = errs[(size_t)i]; return false; }
+    bw.next_block = tile_start[ntiles][0]; bw.next_part = tile_start[ntiles][1];
+  } else {
+    for (int t = 0; t < ntiles && !bw.failed; t++) {
+      bw.tile(t / bw.fi.tile_cols, t % bw.fi.tile_cols);
+      tiles[(size_t)t].swap(bw.ec.out);
+    }
   }
   if (bw.failed) return false;
   if (bw.next_block != d.n_blocks || bw.next_part != d.n_partition) return bad("block / partition list longer than the frame");

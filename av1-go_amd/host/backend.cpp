@@ -55,7 +55,7 @@ void DescribeSessionFrame(const av1mi_gop_frame &fr, int seg, int width, int hei
 
 // A key frame of a key_block_size 32 session (av1mi_gop_frame.key_block_size == 32): 32x32 blocks over the complete superblock rows,
 // 8x8 blocks in a last partial row — written by the general block writer (av1_blockstream.cpp) from the session's symbols.
-static bool Key32TemporalUnit(const av1mi_gop_frame &fr, int seg, const SessionFrameDesc &desc, int width, int height, bool with_sequence_header,
+static bool Key32TemporalUnit(const av1mi_gop_frame &fr, int seg, const SessionFrameDesc &desc, int width, int height, bool with_sequence_header, int threads,
                               std::vector<uint8_t> *out, std::string *err) {
   if (!fr.y_mode || !fr.lev_y) { if (err) *err = "a key frame in 32x32 blocks needs its symbols (gpu_entropy 0)"; return false; }
   const int hA = (height / 64) * 64, mi_rows = height / 4, mi_cols = width / 4;
@@ -76,8 +76,10 @@ static bool Key32TemporalUnit(const av1mi_gop_frame &fr, int seg, const SessionF
     blocks.push_back(b);
   };
   const int w32 = width / 32, w8 = width / 8;
+  std::vector<size_t> starts;          // per tile (= superblock): its first block, its first partition symbol; the writer's threads start there
   for (int sr = 0; sr * 16 < mi_rows; sr++)
     for (int sc = 0; sc * 16 < mi_cols; sc++) {
+      starts.push_back(blocks.size()); starts.push_back(parts.size());
       if (sr * 64 < hA) {                                // PARTITION_SPLIT at 64x64, four 32x32 blocks
         parts.push_back(3);
         for (int k = 0; k < 4; k++) {
@@ -107,8 +109,12 @@ static bool Key32TemporalUnit(const av1mi_gop_frame &fr, int seg, const SessionF
   d.hdr = desc.f;
   const uint8_t dct = 0;
   d.partition = parts.data(); d.n_partition = parts.size(); d.blocks = blocks.data(); d.n_blocks = blocks.size(); d.tx_type = &dct; d.levels = lev.data();
+  starts.push_back(blocks.size()); starts.push_back(parts.size());
   std::string werr;
-  if (!av1::blocks_temporal_unit(d, with_sequence_header, out, &werr)) { if (err) *err = "bitstream writer: " + werr; return false; }
+  if (!av1::blocks_temporal_unit(d, with_sequence_header, out, &werr, threads, reinterpret_cast<const size_t (*)[2]>(starts.data()))) {
+    if (err) *err = "bitstream writer: " + werr;
+    return false;
+  }
   return true;
 }
 
@@ -128,7 +134,7 @@ bool SessionTemporalUnit(const av1mi_gop_frame &fr, int seg, int width, int heig
     out->insert(out->end(), frame.begin(), frame.end());
     return true;
   }
-  if (fr.key_block_size == 32) return Key32TemporalUnit(fr, seg, desc, width, height, with_sequence_header, out, err);      // symbols of a key frame in 32x32 blocks
+  if (fr.key_block_size == 32) return Key32TemporalUnit(fr, seg, desc, width, height, with_sequence_header, threads, out, err);      // symbols of a key frame in 32x32 blocks
   if (!av1::temporal_unit(desc.f, with_sequence_header, threads, out, &werr)) { if (err) *err = "bitstream writer: " + werr; return false; }
   return true;
 }

@@ -293,7 +293,7 @@ def e2e_leg(ctx, src, W, H, bd, qindex, gop, steps=2, warmup_frames=2, gpu_entro
         out.update(decoder_check(ctx, src, W, H, bd, qindex, gop, gpu_entropy, threads, compare_libaom, key_block_size))
     if key_block_size == 32:
         out["key_block_size"] = 32
-        out["what"] += "; key frames in 32x32 blocks (av1mi_gop_config.key_block_size)" + ("" if gpu_entropy else ", written by the general block writer on one thread per frame")
+        out["what"] += "; key frames in 32x32 blocks (av1mi_gop_config.key_block_size)" + ("" if gpu_entropy else ", written by the general block writer")
     return out
 
 
