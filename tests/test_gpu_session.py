@@ -116,7 +116,8 @@ def _oracle_key32(O, Y, U, V, bd, q):
 
 
 @pytest.mark.skipif(not D.available(), reason="no dav1d in this image")
-@pytest.mark.parametrize("w,h,bd,q,segs", [(192, 128, 8, 110, 2), (256, 168, 10, 60, 2), (1920, 1080, 8, 128, 1)])
+@pytest.mark.parametrize("w,h,bd,q,segs", [(192, 128, 8, 110, 2), (256, 168, 10, 60, 2), (64, 64, 8, 1, 1), (128, 72, 10, 255, 1), (1920, 1080, 8, 128, 1),
+                                         (3840, 2160, 10, 23, 1)])
 def test_key_frames_in_32x32_blocks(ctx, av1mi, O, w, h, bd, q, segs):
     """av1mi_gop_config.key_block_size = 32 (host entropy coding for now): key frames in 32x32 blocks over the complete
     superblock rows + 8x8 in a partial last row.  (1) symbols and reference frames equal the oracle's chain with the same rule,
@@ -192,7 +193,8 @@ def test_key_frames_in_32x32_blocks(ctx, av1mi, O, w, h, bd, q, segs):
                         assert (dec[t][i] == refs[t][i][sgi * hh:(sgi + 1) * hh]).all(), "key block size %d, segment %d frame %d plane %d: dav1d differs from the GPU" % (kbs, sgi, t, i)
         finally:
             s.close()
-    assert sum(sizes[32]) < sum(sizes[8]) and min(a - b for a, b in zip(psnr[32], psnr[8])) > -0.3, (sizes, psnr)
+    if 20 <= q <= 200:      # (at the ends of the quantiser range the two block sizes trade bytes for PSNR differently)
+        assert sum(sizes[32]) < sum(sizes[8]) and min(a - b for a, b in zip(psnr[32], psnr[8])) > -0.3, (sizes, psnr)
     # (4) the GPU tile coder (k_av1_tokens32 for the 32x32 band's tiles, then the usual chains / range coder): the same bytes
     s = av1mi.GopSession(ctx, w, h, bd, q, gop, segs, key_block_size=32, gpu_entropy=1)
     try:
