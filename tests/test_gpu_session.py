@@ -257,6 +257,55 @@ def test_key_frames_in_32x32_blocks_of_a_cropped_frame(ctx, av1mi, vw, vh, bd, q
             assert got[t][i].shape == (ch, cw) and (got[t][i] == out[1][1][t][i][:ch, :cw]).all(), "frame %d plane %d: dav1d differs from the GPU" % (t, i)
 
 
+@pytest.mark.skipif(not D.available(), reason="no dav1d in this image")
+def test_the_bench_configuration_at_full_size(ctx, av1mi):
+    """BASELINE configs[3] exactly as bench.py runs it: 3840x2160 10-bit, 12 closed GOPs of 30 frames in lockstep, q 128, key frames in
+    32x32 blocks, GPU tile coder, three batches in flight.  No batch falls back; the first and the last segment's streams (60 frames)
+    decode in dav1d to the reference frames the session kept at the time."""
+    import av1stream
+    import synth
+    w, h, bd, q, gop, segs = 3840, 2160, 10, 128, 30, 12
+    check = (0, segs - 1)
+    Y, U, V = synth.frames(w, h, segs * gop, bd, 0)          # 9 GB of source, like the bench's
+    s = av1mi.GopSession(ctx, w, h, bd, q, gop, segs, gpu_entropy=1, key_block_size=32)
+    try:
+        streams, refs, nbytes = {sg: b"" for sg in check}, {sg: [] for sg in check}, 0
+        lag = s.max_in_flight() - 1
+
+        def collect():
+            nonlocal nbytes
+            fr = s.collect()
+            assert "tile_size" in fr
+            nbytes += int(fr["tile_size"].sum(dtype=np.uint64))
+            for sg in check:
+                streams[sg] += av1stream.session_temporal_unit(w, h, bd, fr["raw"], sg, with_sequence_header=(fr["frame_type"] == 0))
+        for t in range(gop):
+            planes = s.input_planes()
+            for sg in range(segs):
+                f = sg * gop + t
+                planes[0][sg * h:(sg + 1) * h] = Y[f]
+                planes[1][sg * h // 2:(sg + 1) * h // 2] = U[f]
+                planes[2][sg * h // 2:(sg + 1) * h // 2] = V[f]
+            s.submit()
+            got = s.download_reference()      # (waits for this batch's filters: the reference the NEXT frame predicts from)
+            for sg in check:
+                refs[sg].append([got[0][sg * h:(sg + 1) * h].copy(), got[1][sg * h // 2:(sg + 1) * h // 2].copy(), got[2][sg * h // 2:(sg + 1) * h // 2].copy()])
+            if t >= lag:
+                collect()
+        while s.pending():
+            collect()
+        assert s.entropy_fallbacks() == 0
+        assert 200e3 < nbytes / (gop * segs) < 800e3          # ~457 KB per frame at q 128
+        for sg in check:
+            dec = D.decode(streams[sg])
+            assert len(dec) == gop
+            for t in range(gop):
+                for i in range(3):
+                    assert (dec[t][i] == refs[sg][t][i]).all(), "segment %d frame %d plane %d: dav1d differs from the GPU" % (sg, t, i)
+    finally:
+        s.close()
+
+
 def test_session_api_misuse_is_reported(ctx, av1mi):
     s = av1mi.GopSession(ctx, 64, 64, 8, 100, 2, 1)
     try:
