@@ -144,10 +144,11 @@ __device__ __forceinline__ int code_block(const TileCtx<Pix> &C, int lane, int b
   AV1MI_GROUP_SYNC();
   STAMP(2);
   int rec[B];
+  constexpr int AC_ROUND = GW == 32 ? kAcRoundKey32 : kAcRoundIntra;      // GW = the luma block size
   if constexpr (GW != B)   // the U+V pair: transform type implied by the mode (luma types are coded in the bitstream: DCT_DCT)
-    code_residual<B, Pix, true>(C.tbuf, lane, s, bp, dc_q, ac_q, dc_quant, ac_quant, lev_row, rec, (kModeVertAdst >> best_mode) & 1, (kModeHorzAdst >> best_mode) & 1);
+    code_residual<B, Pix, true, AC_ROUND>(C.tbuf, lane, s, bp, dc_q, ac_q, dc_quant, ac_quant, lev_row, rec, (kModeVertAdst >> best_mode) & 1, (kModeHorzAdst >> best_mode) & 1);
   else
-    code_residual<B, Pix>(C.tbuf, lane, s, bp, dc_q, ac_q, dc_quant, ac_quant, lev_row, rec);
+    code_residual<B, Pix, false, AC_ROUND>(C.tbuf, lane, s, bp, dc_q, ac_q, dc_quant, ac_quant, lev_row, rec);
   STAMP(3);
   store_row<B>(rec_row, rec);
   // neighbour context for the blocks to come
