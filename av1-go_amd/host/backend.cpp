@@ -165,8 +165,8 @@ int RunBackend(const BackendJob &job, std::string *err) {
     cfg.width = w; cfg.height = h; cfg.bit_depth = y.bd; cfg.base_q_idx = job.quality < 1 ? 1 : job.quality; cfg.gop_length = G; cfg.segments = S;
     cfg.search_range = 8;
     cfg.gpu_entropy = job.gpu_entropy ? 1 : 0;
-    // key frames in 32x32 blocks where the frame allows it (whole superblock columns, no cropped edge)
-    cfg.key_block_size = (job.key_block_size == 32 && (w & 63) == 0 && w == y.w && h == y.h) ? 32 : 8;
+    // key frames in 32x32 blocks where the frame allows it (whole superblock columns of the coded frame)
+    cfg.key_block_size = (job.key_block_size == 32 && (w & 63) == 0) ? 32 : 8;
     CHK(av1mi_gop_open(ctx, &cfg, &gop));
     av1::SequenceParams sp; sp.width = y.w; sp.height = y.h; sp.bit_depth = y.bd;
     for (const std::string &side : job.tracks)

@@ -349,6 +349,41 @@ def test_the_public_drop_in_and_streamed_input(host, tmp_path):
 
 
 @pytest.mark.gpu
+def test_run_transcode_of_a_cropped_source_with_key_frames_in_32x32_blocks(host, tmp_path):
+    """a 250x70 source is coded at 256x72: the width is a multiple of 64, so the command line's default codes its key frames in 32x32
+    blocks over the first superblock row (8x8 below) — the GPU coder and the host coder write the same file, dav1d outputs 250x70
+    frames close to the source"""
+    import dav1d_ref as D
+    if not D.available():
+        pytest.skip("no dav1d in this image")
+    sys_path_synth()
+    import synth
+    vw, vh, n, q, gop = 250, 70, 5, 100, 3
+    Yc, Uc, Vc = synth.frames(264, 80, n, 8, 3)
+    src = tmp_path / "crop.y4m"
+    with open(str(src), "wb") as f:
+        f.write(("YUV4MPEG2 W%d H%d F30:1 Ip A1:1 C420jpeg\n" % (vw, vh)).encode())
+        for i in range(n):
+            f.write(b"FRAME\n")
+            for pl in (Yc[i][:vh, :vw], Uc[i][:vh // 2, :vw // 2], Vc[i][:vh // 2, :vw // 2]):
+                f.write(np.ascontiguousarray(pl).tobytes())
+    buf = C.create_string_buffer(1024)
+    outs = []
+    for gpu_entropy, kbs in (("1", "32"), ("0", "32"), ("1", "8")):
+        out = tmp_path / ("crop_%s_%s.obu" % (gpu_entropy, kbs))
+        args = "\n".join(["-i", str(src), "-global_quality:v:0", str(q), "-g", str(gop), "-av1mi_segments", "2", "-av1mi_gpu_entropy", gpu_entropy,
+                          "-av1mi_key_block_size", kbs, str(out)])
+        assert host.av1mi_host_run_transcode(args.encode(), buf, 1024) == 0 and buf.value == b"", buf.value
+        outs.append(out.read_bytes())
+    assert outs[0] == outs[1] and outs[0] != outs[2] and len(outs[0]) < len(outs[2])
+    got = D.decode(outs[0])
+    assert len(got) == n and got[0][0].shape == (vh, vw)
+    for i in range(n):
+        mse = np.mean((got[i][0].astype(np.float64) - Yc[i][:vh, :vw]) ** 2)
+        assert 10 * np.log10(255 ** 2 / mse) > 30
+
+
+@pytest.mark.gpu
 def test_run_transcode_copies_the_tracks_of_a_side_file(host, tmp_path):
     """`-c:a copy -c:s copy` (internal/ffmpeg/transcode.go:134-137) after an external demux: `-av1mi_tracks side.mka` puts the side
     file's audio and subtitle tracks next to the coded video; the video blocks are those of the video-only run (muxer details:
