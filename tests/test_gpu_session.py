@@ -306,6 +306,48 @@ def test_the_bench_configuration_at_full_size(ctx, av1mi):
         s.close()
 
 
+@pytest.mark.skipif(not D.available(), reason="no dav1d in this image")
+def test_key_frames_in_32x32_blocks_over_many_sizes(ctx, av1mi):
+    """sizes around the band rule (no complete superblock row, exactly whole rows, one to seven 8x8 rows below), both depths, the whole
+    quantiser range, one to three segments: the GPU-coded stream equals the host-coded one and dav1d decodes it to the session's references"""
+    import av1stream
+    import synth
+    rng = np.random.default_rng(2024)
+    for case in range(24):
+        w = int(rng.choice([64, 128, 192, 320]))
+        h = int(rng.choice([8, 40, 56, 64, 72, 120, 128, 136, 184, 200]))
+        bd, q, segs, gop = int(rng.choice([8, 10])), int(rng.integers(12, 240)), int(rng.integers(1, 4)), 2
+        Y, U, V = synth.frames(w, h, segs * gop, bd, case)
+        out = {}
+        for mode in (1, 0):
+            s = av1mi.GopSession(ctx, w, h, bd, q, gop, segs, gpu_entropy=mode, key_block_size=32)
+            try:
+                streams, refs = [b""] * segs, []
+                for t in range(gop):
+                    planes = s.input_planes()
+                    for sg in range(segs):
+                        f = sg * gop + t
+                        planes[0][sg * h:(sg + 1) * h] = Y[f]
+                        planes[1][sg * h // 2:(sg + 1) * h // 2] = U[f]
+                        planes[2][sg * h // 2:(sg + 1) * h // 2] = V[f]
+                    s.submit()
+                    fr = s.collect()
+                    refs.append(s.download_reference())
+                    for sg in range(segs):
+                        streams[sg] += av1stream.session_temporal_unit(w, h, bd, fr["raw"], sg, with_sequence_header=(t == 0), threads=2)
+                out[mode] = (streams, refs, s.entropy_fallbacks())
+            finally:
+                s.close()
+        assert out[1][0] == out[0][0], (case, w, h, bd, q, segs)
+        assert out[1][2] == 0, (case, w, h, bd, q)
+        for sg in range(segs):
+            dec = D.decode(out[1][0][sg])
+            assert len(dec) == gop
+            for t in range(gop):
+                for i, hh in ((0, h), (1, h // 2), (2, h // 2)):
+                    assert (dec[t][i] == out[1][1][t][i][sg * hh:(sg + 1) * hh]).all(), (case, w, h, bd, q, sg, t, i)
+
+
 def test_session_api_misuse_is_reported(ctx, av1mi):
     s = av1mi.GopSession(ctx, 64, 64, 8, 100, 2, 1)
     try:
