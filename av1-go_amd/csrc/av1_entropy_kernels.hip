@@ -197,11 +197,13 @@ __global__ __launch_bounds__(64) void k_av1_tokens32(Av1EntLaunch L, int ntiles_
   fill_scan_tables32(&scan, (int)threadIdx.x, 64);
   if (b == 0) s_bad[tl] = 0;
   const FrameView v = frame_view(L, live ? f : 0);
-  if (live) block_sums32(v, block_index32(v, sbr, sbc, b), &s_sum[tl][b]);
+  const bool inside = live && !((b & 1) && sbc * 8 + 4 >= v.w8);      // width % 64 == 32: a last column of half superblocks
+  if (inside) block_sums32(v, block_index32(v, sbr, sbc, b), &s_sum[tl][b]);
   __syncthreads();
   uint16_t *rec = L.rec + ((size_t)(live ? t : 0) * kBlocks32 + b) * kBlockRecords32;
   int nrec = 0;
-  if (live) {
+  if (live) { s_n[tl][b] = 0; s_nrec[tl][b] = 0; }
+  if (inside) {
     Sink32 k = { rec, nullptr, b, (int)kBlockRecords32, 0, 0, false, 0, 0, 0, 0 };
     const TokScratch32 ts = { s_mag + threadIdx.x * kMag32Bytes, &scan };
     tok_block32(v, k, ts, sbr, sbc, b, s_sum[tl]);
@@ -510,8 +512,8 @@ int av1mi::av1_entropy_front(av1mi_ctx *ctx, const av1mi_av1_entropy_job *j, hip
         hipMemcpy(st->d_image[key][qcat], img.data(), img.size() * 2, hipMemcpyHostToDevice) != hipSuccess)
       return av1mi::ctx_fail(ctx, AV1MI_E_DEVICE, "uploading the default CDF image failed");
   }
-  if (j->key_rows32 && (!key || (j->key_rows32 & 63) || j->key_rows32 > j->height || (j->width & 63)))
-    return av1mi::ctx_fail(ctx, AV1MI_E_INVAL, "key_rows32 %d: whole superblock rows of a key frame whose width is a multiple of 64", j->key_rows32);
+  if (j->key_rows32 && (!key || (j->key_rows32 & 63) || j->key_rows32 > j->height || (j->width & 31)))
+    return av1mi::ctx_fail(ctx, AV1MI_E_INVAL, "key_rows32 %d: whole superblock rows of a key frame whose width is a multiple of 32", j->key_rows32);
   if (j->key_rows32 && !st->d_image32[qcat]) {
     const std::vector<uint16_t> img = av1ops::default_slot_image_k32(qcat, &st->tab32);
     if (hipMalloc((void **)&st->d_image32[qcat], img.size() * 2) != hipSuccess ||

@@ -107,6 +107,7 @@ struct Sink32 {
   }
   AV1_HD void flush() { if (nrec & 7) store8(); }
   AV1_HD void sym(int slot, int s) { put(((unsigned)slot << 4) | (unsigned)s); }      // counted afterwards: count_block32
+  AV1_HD void split(int kind, int slot) { sym(slot, kind ? kSplitVert : kSplitHorz); }   // split_or_horz / split_or_vert = 1 at a frame edge
   AV1_HD void lit(unsigned v, int nbits) {
     while (nbits > 11) { nbits -= 11; put(0x8000u | (11u << 11) | ((v >> nbits) & 0x7FFu)); }
     if (nbits > 0) put(0x8000u | ((unsigned)nbits << 11) | (v & ((1u << nbits) - 1u)));
@@ -235,16 +236,19 @@ AV1_HD void block_sums32(const FrameView &f, long i, Sum32 *o) {
 AV1_HD long block_index32(const FrameView &f, int sbr, int sbc, int b) { return (long)(sbr * 2 + (b >> 1)) * (f.w8 / 4) + sbc * 2 + (b & 1); }
 
 // all ops of block b (0..3, raster = decoding order) of the tile = superblock (sbr, sbc) of a key frame's 32x32 band; sums[4]: the
-// tile's block summaries.  f.y_mode / f.uv_mode: the band's modes, one per 32x32 block in raster order (w8 / 4 per row); f.lev_*:
+// tile's block summaries (of the blocks inside the frame).  f.y_mode / f.uv_mode: the band's modes, one per 32x32 block in raster order (w8 / 4 per row); f.lev_*:
 // block-contiguous over the same grid (1024 luma, 256 + 256 chroma levels per block)
 AV1_HD void tok_block32(const FrameView &f, Sink32 &k, const TokScratch32 &ts, int sbr, int sbc, int b, const Sum32 *sums) {
   static const uint8_t kCtx[13] = { 0, 1, 2, 3, 4, 4, 4, 4, 3, 0, 1, 2, 0 };     // Intra_Mode_Context
   const int w32 = f.w8 / 4, by = b >> 1, bx = b & 1;
   const long i = block_index32(f, sbr, sbc, b);
+  const bool half = sbc * 8 + 4 >= f.w8;         // the frame ends after the superblock's left 32 columns (width % 64 == 32)
   if (b == 0) {
     tok_lr32(f, k, sbr, sbc);
-    k.sym(K_PART64, 3);                          // PARTITION_SPLIT
+    if (half) k.split(1, K_PART64);              // no room for a 64-wide block: split_or_vert = 1 (the band's rows are always complete)
+    else k.sym(K_PART64, 3);                     // PARTITION_SPLIT
   }
+  if (half && bx) return;                        // outside the frame: not coded
   k.sym(K_PART32, 0);                            // PARTITION_NONE
   k.sym(K_SKIP, 0);
   const int ym = f.y_mode[i], uvm = f.uv_mode[i];

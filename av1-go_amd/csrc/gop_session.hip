@@ -250,8 +250,8 @@ int av1mi_gop_open(av1mi_ctx *ctx, const av1mi_gop_config *cfg, av1mi_gop **out)
       cfg->search_range > 15 || cfg->gpu_entropy < 0 || cfg->gpu_entropy > 2 || cfg->coder_streams < 0 || cfg->coder_streams > 3)
     return av1mi::ctx_fail(ctx, AV1MI_E_INVAL, "bad base_q_idx / gop_length / segments / search_range / gpu_entropy");
   if (cfg->key_block_size != 0 && cfg->key_block_size != 8 && cfg->key_block_size != 32) return av1mi::ctx_fail(ctx, AV1MI_E_INVAL, "key_block_size %d not supported (8 or 32)", cfg->key_block_size);
-  if (cfg->key_block_size == 32 && (cfg->width & 63))
-    return av1mi::ctx_fail(ctx, AV1MI_E_INVAL, "key_block_size 32 needs a width that is a multiple of 64");
+  if (cfg->key_block_size == 32 && (cfg->width & 31))
+    return av1mi::ctx_fail(ctx, AV1MI_E_INVAL, "key_block_size 32 needs a width that is a multiple of 32");
   if (cfg->gpu_entropy && (cfg->width > 4096 || cfg->height > 4096)) return av1mi::ctx_fail(ctx, AV1MI_E_INVAL, "the AV1 tile coder takes frames up to 4096x4096");
   if ((size_t)cfg->height * cfg->segments > 65535u * 8u) return av1mi::ctx_fail(ctx, AV1MI_E_INVAL, "segments x height too large for one launch");
   av1mi_gop *g = new (std::nothrow) av1mi_gop();

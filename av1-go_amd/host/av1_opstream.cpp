@@ -33,7 +33,7 @@ bool opstream_supported(const av1mi_obu_frame &f, std::string *why) {
 bool opstream_tiles(const av1mi_obu_frame &f, std::vector<std::vector<uint8_t>> *tiles, std::string *err, int key_rows32) {
   using namespace av1ops;
   if (!opstream_supported(f, err)) return false;
-  if (key_rows32 && (f.frame_type != 0 || (key_rows32 & 63) || key_rows32 > f.height || (f.width & 63))) { if (err) *err = "bad 32x32 band"; return false; }
+  if (key_rows32 && (f.frame_type != 0 || (key_rows32 & 63) || key_rows32 > f.height || (f.width & 31))) { if (err) *err = "bad 32x32 band"; return false; }
   FrameView v;
   memset(&v, 0, sizeof(v));
   v.w8 = f.width / 8; v.h8 = f.height / 8; v.key = f.frame_type == 0;
@@ -91,7 +91,8 @@ bool opstream_tiles(const av1mi_obu_frame &f, std::vector<std::vector<uint8_t>> 
         std::fill(cnt32.begin(), cnt32.end(), 0);
         const TokScratch32 ts32 = { mag32, scan32.data() };
         Sum32 sums[kBlocks32];
-        for (int b = 0; b < kBlocks32; b++) block_sums32(v, block_index32(v, sbr, sbc, b), &sums[b]);
+        const bool half = sbc * 8 + 4 >= v.w8;      // width % 64 == 32: the superblock's right blocks lie outside the frame
+        for (int b = 0; b < kBlocks32; b++) if (!(half && (b & 1))) block_sums32(v, block_index32(v, sbr, sbc, b), &sums[b]);
         int nrec[kBlocks32], first[kBlocks32 + 1];
         first[0] = 0;
         for (int b = 0; b < kBlocks32; b++) {        // (the GPU: one lane per block)

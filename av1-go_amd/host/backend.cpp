@@ -80,10 +80,11 @@ static bool Key32TemporalUnit(const av1mi_gop_frame &fr, int seg, const SessionF
   for (int sr = 0; sr * 16 < mi_rows; sr++)
     for (int sc = 0; sc * 16 < mi_cols; sc++) {
       starts.push_back(blocks.size()); starts.push_back(parts.size());
-      if (sr * 64 < hA) {                                // PARTITION_SPLIT at 64x64, four 32x32 blocks
+      if (sr * 64 < hA) {                                // PARTITION_SPLIT at 64x64, four 32x32 blocks (two where the frame ends mid-superblock)
         parts.push_back(3);
         for (int k = 0; k < 4; k++) {
           const int r32 = sr * 2 + (k >> 1), c32 = sc * 2 + (k & 1);
+          if (c32 >= w32) continue;
           const size_t i = (size_t)r32 * w32 + c32;
           parts.push_back(0);
           block(r32 * 8, c32 * 8, 9 /* BLOCK_32X32 */, my[i], muv[i], i * 1024, i * 256);
@@ -165,8 +166,8 @@ int RunBackend(const BackendJob &job, std::string *err) {
     cfg.width = w; cfg.height = h; cfg.bit_depth = y.bd; cfg.base_q_idx = job.quality < 1 ? 1 : job.quality; cfg.gop_length = G; cfg.segments = S;
     cfg.search_range = 8;
     cfg.gpu_entropy = job.gpu_entropy ? 1 : 0;
-    // key frames in 32x32 blocks where the frame allows it (whole superblock columns of the coded frame)
-    cfg.key_block_size = (job.key_block_size == 32 && (w & 63) == 0) ? 32 : 8;
+    // key frames in 32x32 blocks where the frame allows it (the coded width a multiple of 32)
+    cfg.key_block_size = (job.key_block_size == 32 && (w & 31) == 0) ? 32 : 8;
     CHK(av1mi_gop_open(ctx, &cfg, &gop));
     av1::SequenceParams sp; sp.width = y.w; sp.height = y.h; sp.bit_depth = y.bd;
     for (const std::string &side : job.tracks)

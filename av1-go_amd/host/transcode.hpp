@@ -49,7 +49,7 @@ struct BackendJob {
   int threads = 0;         // host threads for entropy coding; 0 = all cores
   int gpu_entropy = 1;     // 1 = the AV1 tile entropy coder runs on the GPU (the host only assembles frames); 0 = north_star's split:
                            // symbols are downloaded and coded on the host cores.  Same bytes either way.
-  int key_block_size = 32; // -av1mi_key_block_size 8 | 32: key frames in 32x32 blocks where the coded width (the source's rounded up to 8) is a multiple of 64 (av1mi_gop_config.key_block_size;
+  int key_block_size = 32; // -av1mi_key_block_size 8 | 32: key frames in 32x32 blocks where the coded width (the source's rounded up to 8) is a multiple of 32 (av1mi_gop_config.key_block_size;
                            // +3.7 dB at equal size on the synthetic key frames at q 128 for ~9 % of the throughput), else 8x8 like every other frame
   std::vector<std::string> tracks;   // -av1mi_tracks <file.mka> (repeatable): Matroska side files whose audio / subtitle tracks are copied
                                      // next to the video (the reference's `-c:a copy -c:s copy`, transcode.go:134-137, after an external demux)

@@ -518,7 +518,7 @@ def main():
     src = [a.reshape(segs, batches, *a.shape[1:]) for a in (Y, U, V)]
     d_src = [[ctx.to_device(np.ascontiguousarray(src[p][:, t])) for p in range(3)] for t in range(batches)]
     t_gen = time.perf_counter() - t_gen
-    kbs = 32 if (args.key_block_size == 32 and W % 64 == 0) else 0
+    kbs = 32 if (args.key_block_size == 32 and W % 32 == 0) else 0
     sess = av1mi.GopSession(ctx, W, H, bd, args.qindex, gop, segs, gpu_entropy=1, key_block_size=kbs)
     stat = {"payload": 0, "frames": 0}
 

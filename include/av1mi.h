@@ -312,7 +312,7 @@ typedef struct av1mi_av1_entropy_job {
   const uint8_t *d_lr_on;                      /* optional: [frame * 3 + plane] 0 switches lr_on[plane] off for that frame */
   int visible_width, visible_height;           /* the true frame size when width / height are it rounded up to 8 (the restoration units
                                                   a tile codes tile the TRUE frame); 0 = width / height */
-  int key_rows32;                              /* key = 1: the first key_rows32 luma rows (whole superblock rows; width % 64 == 0) are coded in
+  int key_rows32;                              /* key = 1: the first key_rows32 luma rows (whole superblock rows; width % 32 == 0) are coded in
                                                   32x32 blocks: their modes one per 32x32 block from entry 0 of d_modes_*, their levels
                                                   block-contiguous over the 32x32 grid; the rows below in 8x8 blocks at their usual places */
 } av1mi_av1_entropy_job;
@@ -365,7 +365,7 @@ typedef struct av1mi_gop_config {
   int coder_streams;
   int key_block_size;    /* 0 / 8: key frames in 8x8 blocks like every frame.  32: key frames in 32x32 blocks (luma 32x32 DCT, chroma 16x16,
                             transform type by mode) over every COMPLETE superblock row, 8x8 blocks in a last partial row: +3.7 dB at equal
-                            size on the synthetic key frames at q 128, +1.85 dB at q 24.  Needs width % 64 == 0 */
+                            size on the synthetic key frames at q 128, +1.85 dB at q 24.  Needs width % 32 == 0 */
 } av1mi_gop_config;
 
 /* Frame-header parameters chosen by the session's policy for one frame (non-normative encoder choices; the bitstream carries

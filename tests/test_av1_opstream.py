@@ -99,7 +99,8 @@ def test_lazy_byte_output_equals_the_eager_coder_including_late_carries():
 
 
 @pytest.mark.parametrize("w,h,bd,q,lr", [(64, 64, 8, 128, False), (192, 128, 8, 60, True), (256, 168, 10, 23, True), (128, 104, 8, 200, False),
-                                         (320, 192, 10, 128, True), (1920, 1080, 8, 128, True)])
+                                         (320, 192, 10, 128, True), (96, 136, 8, 90, True), (224, 64, 10, 150, False), (1440, 1080, 8, 128, True),
+                                         (1920, 1080, 8, 128, True)])
 def test_key_frames_in_32x32_blocks_twin_equals_the_block_writer(O, w, h, bd, q, lr):
     """key frames of a key_block_size 32 session: 32x32 blocks over the complete superblock rows, 8x8 blocks in a last
     partial row.  The serial tile tokenizer of csrc/av1_ops32.hpp + the unchanged chains and range coder (host/av1_opstream.cpp: what
