@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--e2e-segments", type=int, default=8, help="segments in lockstep of the end-to-end leg (GPU entropy coding)")
     ap.add_argument("--key-block-size", type=int, default=32, choices=[8, 32],
                     help="32 (default, what the product's command line uses): key frames in 32x32 blocks (av1mi_gop_config.key_block_size) where "
-                         "the width is a multiple of 64; 8: every frame in 8x8 blocks")
+                         "the width is a multiple of 32; 8: every frame in 8x8 blocks")
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="no GPU: exercise the rank/sharding/timing/aggregation plumbing with a stand-in step (gloo tests)")
     return ap.parse_args()
